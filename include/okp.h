@@ -1,0 +1,194 @@
+/*
+ * okp.h — C ABI of libokp_hip.so: the MI355X (gfx950) keypoint-inference hot path.
+ *
+ * Drop-in boundary for the reference's `perception.models` / `perception.pipeline`
+ * hot path (ethz-asl/object_keypoints).  The reference has no FFI of its own — its
+ * device work is stock PyTorch ops called from Python — so each entry point below
+ * names the reference call site(s) it replaces (file:line under the reference tree).
+ * Plain pointers and sizes only: no torch / HIP types cross this boundary.
+ *
+ * Conventions
+ *   - Every `*_dev` / `void* x` argument is a DEVICE pointer (HBM) owned by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Launch
+ *     functions only enqueue work: no allocation, no synchronisation, graph-capturable.
+ *   - Activations are NHWC ("channels-last"), element type `dtype` (OKP_F32 / OKP_BF16),
+ *     addressed as  base + (pixel * pix_stride + channel) elements, so a tensor argument
+ *     may be a channel slice of a wider tensor (that is how concat / split are free).
+ *   - Return value: 0 on success, negative OKP_E* otherwise; okp_last_error() gives text.
+ *     Shape / dtype / alignment violations are reported, never silently patched —
+ *     the reference's convention is assert / ValueError (pipeline.py:67,183; camera_utils.py:16,144).
+ */
+#ifndef OKP_H
+#define OKP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKP_ABI_VERSION 1
+
+enum { OKP_F32 = 0, OKP_BF16 = 1 };
+enum { OKP_ACT_NONE = 0, OKP_ACT_RELU = 1, OKP_ACT_SIGMOID = 2 };
+enum {
+  OKP_OK = 0,
+  OKP_EINVAL = -1,   /* bad argument (shape, dtype, alignment, capacity) */
+  OKP_EHIP = -2,     /* HIP runtime error */
+  OKP_ENOMEM = -3
+};
+
+const char* okp_last_error(void);
+int okp_abi_version(void);
+/* Number of visible HIP devices and the gfx arch string of device `dev` (e.g. "gfx950"). */
+int okp_device_count(void);
+int okp_device_arch(int dev, char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------
+ * Dense convolution as a tap-list implicit GEMM (MFMA).
+ *
+ * Replaces torch conv2d / conv_transpose2d + batch_norm + add + relu as used by
+ *   convolution            corner_net_lite/core/models/py_utils/utils.py:143-156
+ *   residual               .../py_utils/utils.py:158-185   (conv2 + projected skip + add + relu = ONE plan, 2 sources)
+ *   fire_module 1x1s       .../CornerNet_Squeeze.py:13-15,22-30
+ *   unpool + merge         .../CornerNet_Squeeze.py:35-36, py_utils/modules.py:64-65 (4 sub-pixel plans)
+ *   inter-stack merge      .../py_utils/modules.py:89-91   (two 1x1+BN summed = ONE plan, 2 sources)
+ *   prediction_module      perception/models.py:13-18
+ *
+ * out[n, ho*out_step+out_oy, wo*out_step+out_ox, co] =
+ *     act( bias[co] + residual[...same pixel..., co]
+ *          + sum_taps sum_ci  W_tap[co][ci] * src[tap.src][n, ho*conv_stride+tap.dy, wo*conv_stride+tap.dx, ci] )
+ * with zero for out-of-range source pixels.  BatchNorm (eval mode, perception/models.py:67,81)
+ * is folded into W/bias by the caller before okp_conv_create.
+ * ---------------------------------------------------------------------------------- */
+typedef struct okp_tap {
+  int32_t src;      /* 0 or 1: which source tensor this tap reads */
+  int32_t dy, dx;   /* source pixel = (ho*conv_stride[src] + dy, wo*conv_stride[src] + dx) */
+  const float* w;   /* HOST pointer, row-major [cout][cin[src]] fp32 */
+} okp_tap;
+
+typedef struct okp_conv okp_conv;   /* opaque plan: packed weights + bias + slice table in HBM */
+
+/* cin[s]*sizeof(dtype) must be a multiple of 16 bytes; cout a multiple of 8; n_taps <= 32. */
+okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride,
+                          int32_t cout, int32_t n_taps, const okp_tap* taps,
+                          const float* bias /* HOST [cout] or NULL */, int act);
+void okp_conv_destroy(okp_conv* plan);
+
+typedef struct okp_tensor {        /* an NHWC view */
+  void* data;                      /* device pointer to element (n=0,y=0,x=0,c=0) of the view */
+  int32_t h, w;                    /* spatial size */
+  int32_t pix_stride;              /* elements between consecutive pixels (>= channels of the view) */
+  int64_t bytes;                   /* bytes addressable from `data` (bounds for hardware range checks) */
+} okp_tensor;
+
+typedef struct okp_conv_args {
+  int32_t n;                       /* batch */
+  int32_t ho, wo;                  /* output pixel grid of the GEMM (before out_step mapping) */
+  okp_tensor src[2];
+  okp_tensor out;                  /* out.h/out.w are the FULL output tensor's spatial size */
+  int32_t out_step, out_oy, out_ox;/* sub-pixel placement (1,0,0 for ordinary convs) */
+  okp_tensor res;                  /* optional residual, same spatial mapping as out; data==NULL if none */
+  int32_t tile;                    /* 0 = auto, else 1 (64x64), 2 (128x128), 3 (256x256) */
+} okp_conv_args;
+
+int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
+/* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
+int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
+
+/* ------------------------------------------------------------------------------------
+ * Depth-wise 3x3 convolution (pad 1, stride 1|2) + bias + optional residual + activation.
+ * Replaces fire_module.conv_3x3 + its half of bn2 / skip-add / relu
+ * (corner_net_lite/core/models/CornerNet_Squeeze.py:16-17,25-30).
+ * w: DEVICE fp32 [9][c] (tap-major, BN scale folded), bias: DEVICE fp32 [c].
+ * ---------------------------------------------------------------------------------- */
+int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride,
+                          const okp_tensor* src, const float* w_dev, const float* bias_dev,
+                          const okp_tensor* res, const okp_tensor* out, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Frame packing for the 7x7/s2 stem: NCHW fp32 (n,3,h,w) -> NHWC4 `dtype` with a zero halo,
+ * out dims (n, h+6, out_w, 4), image at (3,3).  The public input layout is the reference's
+ * (perception/pipeline.py:24-28: frames N x 3 x 511 x 511 fp32).
+ * ---------------------------------------------------------------------------------- */
+int okp_pack_frames(int dtype, const float* frames_nchw_dev, int32_t n, int32_t h, int32_t w,
+                    void* out_dev, int32_t out_w, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Final 1x1 convolutions of the three heads, NHWC -> NCHW fp32, optional sigmoid per output.
+ * Replaces prediction_module[-1] (perception/models.py:17) for heat/depth/centre heads and
+ * the deployed wrapper's sigmoid (scripts/package_model.py:28).
+ * Output channel o reads 32 input channels starting at in_c_off[o]; w_dev is [n_out][32] fp32.
+ * out_ptr[o] is the DEVICE address of plane (n=0) of that output; planes of successive frames
+ * are out_n_stride[o] floats apart.
+ * ---------------------------------------------------------------------------------- */
+#define OKP_HEAD_MAX_OUT 32
+typedef struct okp_head_out_args {
+  int32_t n, h, w;
+  okp_tensor src;
+  int32_t n_out;
+  int32_t in_c_off[OKP_HEAD_MAX_OUT];
+  int32_t act[OKP_HEAD_MAX_OUT];
+  float* out_ptr[OKP_HEAD_MAX_OUT];
+  int64_t out_n_stride[OKP_HEAD_MAX_OUT];
+  const float* w_dev;      /* [n_out][32] */
+  const float* bias_dev;   /* [n_out] */
+} okp_head_out_args;
+int okp_head_out_forward(int dtype, const okp_head_out_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-map heat-map peak extraction.  Replaces KeypointExtractionComponent._extract_keypoints /
+ * _compute_points (perception/pipeline.py:46-79) and nms (perception/models.py:55-58):
+ *   box  = 5x5 ones convolution, zero padding, fp32 accumulation in row-major tap order
+ *   peak = box == maxpool5x5(box) (padding ignored)  and  box > 0.5      [bit-exact contract]
+ *   per peak (row-major order): confidence = sum of p over the clipped 5x5 window,
+ *   (x, y) = sum(p * (x, y)) / confidence.
+ * heat: [n_maps][h][w] fp32 (h*w <= 16384).  Outputs per map, capacity `cap` peaks:
+ *   count[n_maps]        total peaks found (may exceed cap; only the first cap are stored)
+ *   yx[n_maps][cap][2]   int32 (y, x)
+ *   xyc[n_maps][cap][3]  fp32 (x, y, confidence)
+ * ---------------------------------------------------------------------------------- */
+int okp_peak_nms(const float* heat_dev, int32_t n_maps, int32_t h, int32_t w, int32_t cap,
+                 int32_t* count_dev, int32_t* yx_dev, float* xyc_dev, void* stream);
+
+/* nms(x, size) = x * (x == max_pool2d(x, size, stride 1, pad size/2)) on [n_maps][h][w] fp32 maps
+ * (perception/models.py:55-58; padding never wins the max).  size must be odd, <= 15. */
+int okp_nms_maxpool(const float* x_dev, int32_t n_maps, int32_t h, int32_t w, int32_t size,
+                    float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Geometry (fp64 on device).
+ * okp_camera: pinhole + Kalibr "equidistant" (OpenCV fisheye) distortion.
+ * ---------------------------------------------------------------------------------- */
+typedef struct okp_camera {
+  double fx, fy, cx, cy;
+  double d[4];
+} okp_camera;
+
+/* Replaces DetectionToPoint.__call__ (perception/pipeline.py:164-171) =
+ * FisheyeCamera.undistort (utils/camera_utils.py:75-81; cv2.fisheye.undistortPoints with P=K)
+ * -> round half-even -> clip to [0,max_x]x[0,max_y] -> z = depth[map][y][x]
+ * -> PinholeCamera.unproject (camera_utils.py:31-34): K^-1 [xu, yu, 1]^T * z.
+ * xy: [m][2] fp32 pixel coords; map_id: [m] int32 index into depth maps [n_maps][h][w] fp32;
+ * out: [m][3] fp64.  Entries with map_id < 0 are skipped (out = NaN). */
+int okp_unproject_depth(const okp_camera* cam, const float* xy_dev, const int32_t* map_id_dev, int32_t m,
+                        const float* depth_dev, int32_t h, int32_t w, int32_t max_x, int32_t max_y,
+                        double* out_dev, void* stream);
+
+/* Replaces StereoCamera.triangulate (utils/camera_utils.py:92-110) and the labelling tool's
+ * 2-view DLT (scripts/label.py:285-305): undistort both views (P=K) -> optional Hartley-Sturm
+ * correction against F (cv2.correctMatches) -> DLT null vector of the 4x4 system built from
+ * P1 = K_l [I 0], P2 = K_r T_RL[:3] -> dehomogenise.  T_RL: row-major 3x4; F: row-major 3x3
+ * (used only when correct_matches != 0).  left/right: [m][2] fp32;  out: [m][3] fp64 (left frame). */
+int okp_triangulate_dlt(const okp_camera* left, const okp_camera* right, const double* T_RL,
+                        const double* F, int correct_matches,
+                        const float* left_xy_dev, const float* right_xy_dev, int32_t m,
+                        double* out_dev, void* stream);
+
+/* Undistort only (FisheyeCamera.undistort, camera_utils.py:75-81): xy [m][2] fp32 -> out [m][2] fp64. */
+int okp_fisheye_undistort(const okp_camera* cam, const float* xy_dev, int32_t m, double* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKP_H */

@@ -1,0 +1,76 @@
+"""Build recipe for libokp_hip.so (gfx950 only, in-tree so it travels with the repo snapshot).
+
+    python -m object_keypoints_amd.build [--force]
+
+hipcc cross-compiles without a GPU; each .hip is compiled to build/*.o in parallel and linked
+into object_keypoints_amd/lib/libokp_hip.so.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libokp_hip.so")
+OBJ_DIR = os.path.join(REPO, "build", "okp")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
+          "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    return [os.path.join(REPO, "include", "okp.h"), os.path.join(CSRC, "okp_internal.h"), os.path.abspath(__file__)]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    if _stale(obj, [src] + _deps()):
+        cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj, True, r.stderr
+    return obj, False, ""
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [o for o, _, _ in results]
+    rebuilt = any(r for _, r, _ in results)
+    if verbose:
+        for _, _, err in results:
+            if err.strip():
+                print(err, file=sys.stderr)
+    if rebuilt or _stale(LIB_PATH, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,207 @@
+// C-ABI glue of libokp_hip.so: error reporting, convolution plans (weight packing + upload),
+// argument validation and launch of the implicit-GEMM kernel.  See include/okp.h.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "okp_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);   // keep NaN a NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+}  // namespace
+
+void okp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int okp_check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return OKP_OK;
+  okp_set_error("%s: %s", what, hipGetErrorString(e));
+  return OKP_EHIP;
+}
+
+extern "C" const char* okp_last_error(void) { return g_err; }
+extern "C" int okp_abi_version(void) { return OKP_ABI_VERSION; }
+
+extern "C" int okp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int okp_device_arch(int dev, char* buf, int buflen) {
+  hipDeviceProp_t prop;
+  if (int e = okp_check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return e;
+  snprintf(buf, buflen, "%s", prop.gcnArchName);
+  return OKP_OK;
+}
+
+extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
+                                     int32_t n_taps, const okp_tap* taps, const float* bias, int act) {
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
+  if (n_src < 1 || n_src > 2 || !cin || !conv_stride || !taps) { okp_set_error("okp_conv_create: bad sources"); return nullptr; }
+  if (n_taps < 1 || n_taps > OKP_MAX_TAPS) { okp_set_error("okp_conv_create: n_taps %d not in [1,%d]", n_taps, OKP_MAX_TAPS); return nullptr; }
+  if (cout < 8 || cout % 8) { okp_set_error("okp_conv_create: cout %d must be a positive multiple of 8", cout); return nullptr; }
+  if (act != OKP_ACT_NONE && act != OKP_ACT_RELU) { okp_set_error("okp_conv_create: activation %d unsupported here", act); return nullptr; }
+  const int esz = dtype == OKP_BF16 ? 2 : 4;
+  const int KE = 128 / esz;            // elements per K-slice
+  for (int s = 0; s < n_src; ++s) {
+    if (cin[s] < 1 || (cin[s] * esz) % 16) { okp_set_error("okp_conv_create: cin[%d]=%d is not a multiple of 16 bytes", s, cin[s]); return nullptr; }
+    if (conv_stride[s] < 1) { okp_set_error("okp_conv_create: conv_stride[%d]=%d", s, conv_stride[s]); return nullptr; }
+  }
+  for (int t = 0; t < n_taps; ++t)
+    if (taps[t].src < 0 || taps[t].src >= n_src || !taps[t].w) { okp_set_error("okp_conv_create: tap %d invalid", t); return nullptr; }
+
+  okp_conv* plan = new okp_conv();
+  std::memset(plan, 0, sizeof(*plan));
+  plan->dtype = dtype; plan->n_src = n_src; plan->cout = cout; plan->act = act; plan->n_taps = n_taps;
+  plan->cout_pad = (cout + 63) / 64 * 64;
+  for (int s = 0; s < 2; ++s) { plan->cin[s] = s < n_src ? cin[s] : 0; plan->conv_stride[s] = s < n_src ? conv_stride[s] : 1; }
+  for (int t = 0; t < n_taps; ++t) { plan->taps[t].dy = taps[t].dy; plan->taps[t].dx = taps[t].dx; plan->taps[t].src = taps[t].src; plan->taps[t].pad = 0; }
+
+  // ---- slice table -------------------------------------------------------------------------
+  std::vector<OkpSlice> slices;
+  for (int t = 0; t < n_taps;) {
+    const int s = taps[t].src, c = cin[s];
+    if (c * esz == 64 && t + 1 < n_taps && taps[t + 1].src == s) {
+      // two half-slice taps share one 128-byte slice (the bf16 stem: 8 px x 4 ch per kernel row)
+      OkpSlice sl{(uint8_t)t, (uint8_t)(t + 1), (uint8_t)s, 8, 0, 0, 0};
+      slices.push_back(sl);
+      t += 2;
+      continue;
+    }
+    for (int c0 = 0; c0 < c; c0 += KE) {
+      const int chunks = ((c - c0) * esz + 15) / 16;
+      OkpSlice sl{(uint8_t)t, (uint8_t)t, (uint8_t)s, (uint8_t)(chunks > 8 ? 8 : chunks), c0, c0 + KE / 2, 0};
+      slices.push_back(sl);
+    }
+    ++t;
+  }
+  plan->n_slices = (int)slices.size();
+
+  // ---- packed weights [slice][cout_pad][KE] ---------------------------------------------------
+  const size_t n_el = (size_t)plan->n_slices * plan->cout_pad * KE;
+  const size_t w_bytes = n_el * esz;
+  if (w_bytes >= 0x7FFF0000ull) { okp_set_error("okp_conv_create: packed weights %zu bytes exceed 2 GiB", w_bytes); delete plan; return nullptr; }
+  std::vector<float> packed(n_el, 0.f);
+  for (int si = 0; si < plan->n_slices; ++si) {
+    const OkpSlice& sl = slices[si];
+    for (int half = 0; half < 2; ++half) {
+      const int t = half ? sl.tap_hi : sl.tap_lo;
+      const int c0 = half ? sl.c0_hi : sl.c0_lo;
+      const int c = cin[taps[t].src];
+      const float* w = taps[t].w;
+      for (int co = 0; co < cout; ++co) {
+        float* dst = &packed[((size_t)si * plan->cout_pad + co) * KE + half * (KE / 2)];
+        for (int e = 0; e < KE / 2; ++e) {
+          const int ci = c0 + e;
+          if (ci < c) dst[e] = w[(size_t)co * c + ci];
+        }
+      }
+    }
+  }
+  // bias is read as float4 per 32-row block of a 256-row tile: pad to a multiple of 256
+  const int bias_pad = (cout + 255) / 256 * 256;
+  std::vector<float> bias_h(bias_pad, 0.f);
+  if (bias) std::memcpy(bias_h.data(), bias, sizeof(float) * cout);
+
+  bool ok = true;
+  ok = ok && !okp_check_hip(hipMalloc(&plan->weights_dev, w_bytes), "hipMalloc(weights)");
+  ok = ok && !okp_check_hip(hipMalloc((void**)&plan->bias_dev, sizeof(float) * bias_pad), "hipMalloc(bias)");
+  ok = ok && !okp_check_hip(hipMalloc((void**)&plan->slices_dev, sizeof(OkpSlice) * slices.size()), "hipMalloc(slices)");
+  if (ok) {
+    if (dtype == OKP_BF16) {
+      std::vector<uint16_t> h(n_el);
+      for (size_t i = 0; i < n_el; ++i) h[i] = f32_to_bf16_rne(packed[i]);
+      ok = !okp_check_hip(hipMemcpy(plan->weights_dev, h.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    } else {
+      ok = !okp_check_hip(hipMemcpy(plan->weights_dev, packed.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    }
+    ok = ok && !okp_check_hip(hipMemcpy(plan->bias_dev, bias_h.data(), sizeof(float) * bias_pad, hipMemcpyHostToDevice), "hipMemcpy(bias)");
+    ok = ok && !okp_check_hip(hipMemcpy(plan->slices_dev, slices.data(), sizeof(OkpSlice) * slices.size(), hipMemcpyHostToDevice), "hipMemcpy(slices)");
+  }
+  if (!ok) { okp_conv_destroy(plan); return nullptr; }
+  plan->w_bytes = (uint32_t)w_bytes;
+  return plan;
+}
+
+extern "C" void okp_conv_destroy(okp_conv* plan) {
+  if (!plan) return;
+  if (plan->weights_dev) (void)hipFree(plan->weights_dev);
+  if (plan->bias_dev) (void)hipFree(plan->bias_dev);
+  if (plan->slices_dev) (void)hipFree(plan->slices_dev);
+  delete plan;
+}
+
+namespace {
+int check_view(const char* name, const okp_tensor& t, int esz, bool required) {
+  if (!t.data) {
+    if (required) { okp_set_error("okp_conv_forward: %s is null", name); return OKP_EINVAL; }
+    return OKP_OK;
+  }
+  if ((t.pix_stride * esz) % 16 || ((uintptr_t)t.data) % 16) { okp_set_error("okp_conv_forward: %s is not 16-byte aligned (pix_stride %d)", name, t.pix_stride); return OKP_EINVAL; }
+  if (t.bytes <= 0 || t.bytes >= 0x7FFF0000ll) { okp_set_error("okp_conv_forward: %s spans %lld bytes; views must be < 2 GiB (sub-batch the frames)", name, (long long)t.bytes); return OKP_EINVAL; }
+  if (t.h < 1 || t.w < 1) { okp_set_error("okp_conv_forward: %s has empty spatial size", name); return OKP_EINVAL; }
+  return OKP_OK;
+}
+}  // namespace
+
+extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, void* stream) {
+  if (!plan || !a) { okp_set_error("okp_conv_forward: null plan/args"); return OKP_EINVAL; }
+  const int esz = plan->dtype == OKP_BF16 ? 2 : 4;
+  if (a->n < 1 || a->ho < 1 || a->wo < 1) { okp_set_error("okp_conv_forward: empty problem n=%d ho=%d wo=%d", a->n, a->ho, a->wo); return OKP_EINVAL; }
+  if ((long)a->n * a->ho * a->wo >= 0x7FFFFFFFl) { okp_set_error("okp_conv_forward: too many output pixels"); return OKP_EINVAL; }
+  for (int s = 0; s < plan->n_src; ++s) {
+    if (int e = check_view(s ? "src[1]" : "src[0]", a->src[s], esz, true)) return e;
+    // cin may span several consecutive pixels of a row (the stem reads 8 px x 4 ch per tap)
+    if (a->src[s].pix_stride < plan->cin[s] && plan->cin[s] % a->src[s].pix_stride != 0) {
+      okp_set_error("okp_conv_forward: src[%d] pix_stride %d incompatible with cin %d", s, a->src[s].pix_stride, plan->cin[s]); return OKP_EINVAL;
+    }
+  }
+  if (int e = check_view("out", a->out, esz, true)) return e;
+  if (int e = check_view("res", a->res, esz, false)) return e;
+  if (a->out_step < 1 || a->out_oy < 0 || a->out_ox < 0 ||
+      (a->ho - 1) * a->out_step + a->out_oy >= a->out.h || (a->wo - 1) * a->out_step + a->out_ox >= a->out.w) {
+    okp_set_error("okp_conv_forward: output grid %dx%d (step %d, offset %d,%d) does not fit out %dx%d", a->ho, a->wo, a->out_step, a->out_oy, a->out_ox, a->out.h, a->out.w);
+    return OKP_EINVAL;
+  }
+  if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
+  if (a->res.data && (a->res.h != a->out.h || a->res.w != a->out.w)) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
+  if (a->tile < 0 || a->tile > 3) { okp_set_error("okp_conv_forward: tile %d", a->tile); return OKP_EINVAL; }
+
+  OkpIgemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  for (int s = 0; s < 2; ++s) {
+    const int ss = s < plan->n_src ? s : 0;
+    p.src[s] = a->src[ss].data; p.src_bytes[s] = (uint32_t)a->src[ss].bytes;
+    p.srcH[s] = a->src[ss].h; p.srcW[s] = a->src[ss].w; p.src_pix_stride[s] = a->src[ss].pix_stride;
+    p.conv_stride[s] = plan->conv_stride[ss];
+  }
+  p.weights = plan->weights_dev; p.w_bytes = plan->w_bytes; p.cout_pad = plan->cout_pad; p.bias = plan->bias_dev;
+  p.slices = plan->slices_dev; p.n_slices = plan->n_slices; p.n_taps = plan->n_taps;
+  p.N = a->n; p.Ho = a->ho; p.Wo = a->wo;
+  p.out = a->out.data; p.OH = a->out.h; p.OW = a->out.w; p.out_step = a->out_step; p.out_oy = a->out_oy; p.out_ox = a->out_ox;
+  p.out_pix_stride = a->out.pix_stride; p.cout = plan->cout;
+  p.res = a->res.data; p.res_pix_stride = a->res.pix_stride; p.act = plan->act;
+  for (int t = 0; t < plan->n_taps; ++t) p.taps[t] = plan->taps[t];
+  return okp_launch_igemm(plan, p, a->tile, (hipStream_t)stream);
+}
+
+extern "C" int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* a) {
+  if (!plan || !a) return 0;
+  int64_t k = 0;
+  for (int t = 0; t < plan->n_taps; ++t) k += plan->cin[plan->taps[t].src];
+  return (int64_t)a->n * a->ho * a->wo * plan->cout * k;
+}

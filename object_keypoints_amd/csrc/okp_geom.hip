@@ -1,0 +1,326 @@
+// Geometry kernels (fp64): fisheye undistortion, depth lookup + unprojection, two-view DLT.
+// One lane per keypoint (pair); the work per frame is tens of points, so these are latency-bound
+// and exist to keep the whole frame->3D path on the device (no host round trip between NMS
+// and the all-gather of 3D keypoints).
+//
+// Restated algorithms (the reference calls OpenCV, which is not vendored in the reference tree;
+// its env pins opencv=3.4.2, corner_net_lite/conda_packagelist.txt:53):
+//   cv2.fisheye.undistortPoints(P=K): normalise, clip theta_d to [-pi/2, pi/2], 10 fixed-point
+//     iterations theta <- theta_d / (1 + k1 t^2 + k2 t^4 + k3 t^6 + k4 t^8), scale = tan(theta)/theta_d
+//   cv2.triangulatePoints: per point the 4x4 system rows x*P[2]-P[0], y*P[2]-P[1] for both views,
+//     solution = right singular vector of the smallest singular value (here: one-sided Jacobi SVD)
+//   cv2.correctMatches: Hartley-Sturm optimal correction (Hartley & Zisserman alg. 12.1)
+#include "okp_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void fisheye_undistort(const okp_camera& cam, double x, double y, double& xu, double& yu) {
+  const double pwx = (x - cam.cx) / cam.fx, pwy = (y - cam.cy) / cam.fy;
+  double theta_d = sqrt(pwx * pwx + pwy * pwy);
+  const double half_pi = 1.5707963267948966;
+  theta_d = fmin(fmax(-half_pi, theta_d), half_pi);
+  double scale = 1.0;
+  if (theta_d > 1e-8) {
+    double theta = theta_d;
+    for (int j = 0; j < 10; ++j) {
+      const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+      theta = theta_d / (1.0 + cam.d[0] * t2 + cam.d[1] * t4 + cam.d[2] * t6 + cam.d[3] * t8);
+    }
+    scale = tan(theta) / theta_d;
+  }
+  xu = cam.fx * (pwx * scale) + cam.cx;   // R = I, P = K
+  yu = cam.fy * (pwy * scale) + cam.cy;
+}
+
+__global__ void okp_undistort_kernel(okp_camera cam, const float* __restrict__ xy, int m, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double xu, yu;
+  fisheye_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
+  out[2 * i] = xu;
+  out[2 * i + 1] = yu;
+}
+
+__global__ void okp_unproject_kernel(okp_camera cam, const float* __restrict__ xy, const int* __restrict__ map_id, int m,
+                                     const float* __restrict__ depth, int H, int W, int max_x, int max_y,
+                                     double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int map = map_id[i];
+  if (map < 0) {
+    const double nan = __builtin_nan("");
+    out[3 * i] = nan; out[3 * i + 1] = nan; out[3 * i + 2] = nan;
+    return;
+  }
+  // cv2 returns the dtype it was given: the reference passes float32 peaks, so the undistorted
+  // point is rounded to float32 before it is used (pipeline.py:167-171).
+  double xu, yu;
+  fisheye_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
+  const float xf = (float)xu, yf = (float)yu;
+  int xi = (int)rintf(xf), yi = (int)rintf(yf);        // numpy round = half to even
+  xi = min(max(xi, 0), max_x);
+  yi = min(max(yi, 0), max_y);
+  const double z = (double)depth[((size_t)map * H + yi) * W + xi];
+  // K^-1 [x y 1]^T * z for an upper-triangular K without skew
+  out[3 * i + 0] = ((double)xf - cam.cx) / cam.fx * z;
+  out[3 * i + 1] = ((double)yf - cam.cy) / cam.fy * z;
+  out[3 * i + 2] = z;
+}
+
+// One-sided (Hestenes) Jacobi on the columns of a 4x4 matrix; returns the column of V that
+// belongs to the smallest singular value, i.e. argmin |A v| over unit v.
+__device__ void null_vector4(double (&A)[4][4], double (&v)[4]) {
+  double V[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 4; ++i) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+        if (gamma == 0.0) continue;
+        off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 4; ++i) {
+          const double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  int best = 0;
+  double bestn = 1e300;
+  for (int j = 0; j < 4; ++j) {
+    double n = 0;
+    for (int i = 0; i < 4; ++i) n += A[i][j] * A[i][j];
+    if (n < bestn) { bestn = n; best = j; }
+  }
+  for (int i = 0; i < 4; ++i) v[i] = V[i][best];
+}
+
+struct TriParams {
+  okp_camera left, right;
+  double T[12];
+  double F[9];
+  int correct;
+};
+
+// ---- Hartley-Sturm correction (cv2.correctMatches) -------------------------------------------
+__device__ void mat3_mul(const double (&A)[3][3], const double (&B)[3][3], double (&C)[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i][k] * B[k][j]; C[i][j] = s; }
+}
+
+// Right null vector of a 3x3 matrix (rank 2): the largest cross product of two rows.
+__device__ void null3(const double (&M)[3][3], double (&e)[3]) {
+  double best = -1;
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    const double c0 = M[a][1] * M[b][2] - M[a][2] * M[b][1];
+    const double c1 = M[a][2] * M[b][0] - M[a][0] * M[b][2];
+    const double c2 = M[a][0] * M[b][1] - M[a][1] * M[b][0];
+    const double n = c0 * c0 + c1 * c1 + c2 * c2;
+    if (n > best) { best = n; e[0] = c0; e[1] = c1; e[2] = c2; }
+  }
+}
+
+__device__ double hs_cost(double t, double a, double b, double c, double d, double f1, double f2) {
+  const double u = a * t + b, v = c * t + d;
+  return t * t / (1.0 + f1 * f1 * t * t) + v * v / (u * u + f2 * f2 * v * v);
+}
+
+// Real roots of a degree-6 polynomial g[0] + g[1] t + ... + g[6] t^6 by Durand-Kerner in complex fp64.
+__device__ int poly6_roots(const double (&g)[7], double (&re)[6], double (&im)[6]) {
+  int deg = 6;
+  double scale = 0;
+  for (int i = 0; i <= 6; ++i) scale = fmax(scale, fabs(g[i]));
+  while (deg > 0 && fabs(g[deg]) <= 1e-14 * scale) --deg;
+  if (deg == 0) return 0;
+  double a[7];
+  for (int i = 0; i <= deg; ++i) a[i] = g[i] / g[deg];
+  double radius = 0;
+  for (int i = 0; i < deg; ++i) radius = fmax(radius, fabs(a[i]));
+  radius = 1.0 + radius;
+  radius = fmin(radius, 1e6);
+  for (int k = 0; k < deg; ++k) {
+    const double ang = 2.0 * 3.141592653589793 * k / deg + 0.4;
+    const double r = radius * (0.5 + 0.07 * k);
+    re[k] = r * cos(ang); im[k] = r * sin(ang);
+  }
+  for (int it = 0; it < 500; ++it) {
+    double change = 0;
+    for (int k = 0; k < deg; ++k) {
+      double pr = 1.0, pi = 0.0;       // p(z) by Horner, monic
+      for (int i = deg - 1; i >= 0; --i) { const double nr = pr * re[k] - pi * im[k] + a[i]; pi = pr * im[k] + pi * re[k]; pr = nr; }
+      double qr = 1.0, qi = 0.0;       // prod (z_k - z_j)
+      for (int j = 0; j < deg; ++j) if (j != k) {
+        const double dr = re[k] - re[j], di = im[k] - im[j];
+        const double nr = qr * dr - qi * di; qi = qr * di + qi * dr; qr = nr;
+      }
+      const double den = qr * qr + qi * qi + 1e-300;
+      const double sr = (pr * qr + pi * qi) / den, si = (pi * qr - pr * qi) / den;
+      re[k] -= sr; im[k] -= si;
+      change = fmax(change, fabs(sr) + fabs(si));
+    }
+    if (change < 1e-14 * radius) break;
+  }
+  return deg;
+}
+
+__device__ void hartley_sturm(const double (&F)[9], double& x1, double& y1, double& x2, double& y2) {
+  // translate both points to the origin: F' = T2^-T F T1^-1 with T^-1 = [[1,0,x],[0,1,y],[0,0,1]]
+  double Fm[3][3], T1i[3][3] = {{1, 0, x1}, {0, 1, y1}, {0, 0, 1}}, T2it[3][3] = {{1, 0, 0}, {0, 1, 0}, {x2, y2, 1}};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fm[i][j] = F[3 * i + j];
+  double tmp[3][3], Fp[3][3];
+  mat3_mul(T2it, Fm, tmp);
+  mat3_mul(tmp, T1i, Fp);
+  double e1[3], e2[3], Ft[3][3];
+  null3(Fp, e1);                                  // F' e1 = 0
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ft[i][j] = Fp[j][i];
+  null3(Ft, e2);                                  // e2^T F' = 0
+  const double n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1]), n2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1]);
+  if (n1 < 1e-300 || n2 < 1e-300) return;
+  for (int i = 0; i < 3; ++i) { e1[i] /= n1; e2[i] /= n2; }
+  double R1[3][3] = {{e1[0], e1[1], 0}, {-e1[1], e1[0], 0}, {0, 0, 1}};
+  double R2[3][3] = {{e2[0], e2[1], 0}, {-e2[1], e2[0], 0}, {0, 0, 1}};
+  double R1t[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R1t[i][j] = R1[j][i];
+  double Fpp[3][3];
+  mat3_mul(R2, Fp, tmp);
+  mat3_mul(tmp, R1t, Fpp);
+  const double f1 = e1[2], f2 = e2[2];
+  const double a = Fpp[1][1], b = Fpp[1][2], c = Fpp[2][1], d = Fpp[2][2];
+  // g(t) = t((at+b)^2 + f2^2 (ct+d)^2)^2 - (ad-bc)(1+f1^2 t^2)^2 (at+b)(ct+d)
+  double g[7] = {0, 0, 0, 0, 0, 0, 0};
+  {
+    // q(t) = (at+b)^2 + f2^2 (ct+d)^2 = q2 t^2 + q1 t + q0
+    const double q2 = a * a + f2 * f2 * c * c, q1 = 2 * (a * b + f2 * f2 * c * d), q0 = b * b + f2 * f2 * d * d;
+    // q^2
+    const double s4 = q2 * q2, s3 = 2 * q2 * q1, s2 = 2 * q2 * q0 + q1 * q1, s1 = 2 * q1 * q0, s0 = q0 * q0;
+    g[5] += s4; g[4] += s3; g[3] += s2; g[2] += s1; g[1] += s0;       // t * q^2
+    const double k = a * d - b * c;
+    // r(t) = (1 + f1^2 t^2)^2 = 1 + 2 f1^2 t^2 + f1^4 t^4 ; w(t) = (at+b)(ct+d) = ac t^2 + (ad+bc) t + bd
+    const double r0 = 1, r2 = 2 * f1 * f1, r4 = f1 * f1 * f1 * f1;
+    const double w2 = a * c, w1 = a * d + b * c, w0 = b * d;
+    g[0] -= k * (r0 * w0);
+    g[1] -= k * (r0 * w1);
+    g[2] -= k * (r0 * w2 + r2 * w0);
+    g[3] -= k * (r2 * w1);
+    g[4] -= k * (r2 * w2 + r4 * w0);
+    g[5] -= k * (r4 * w1);
+    g[6] -= k * (r4 * w2);
+  }
+  double re[6], im[6];
+  const int nroots = poly6_roots(g, re, im);
+  // t = infinity: s = 1/f1^2 + c^2/(a^2 + f2^2 c^2)
+  double best_t = 0, best_s = 1e300;
+  bool inf_best = false;
+  {
+    const double den = a * a + f2 * f2 * c * c;
+    if (f1 != 0.0 && den != 0.0) { best_s = 1.0 / (f1 * f1) + c * c / den; inf_best = true; }
+  }
+  for (int k = 0; k < nroots; ++k) {
+    const double t = re[k];                       // OpenCV evaluates the cost at the real part of every root
+    const double s = hs_cost(t, a, b, c, d, f1, f2);
+    if (s < best_s) { best_s = s; best_t = t; inf_best = false; }
+  }
+  // closest points on l1 = (t f1, 1, -t), l2 = (-f2 (ct+d), at+b, ct+d) to the origin
+  double p1[3], p2[3];
+  if (inf_best) {
+    p1[0] = f1; p1[1] = 0; p1[2] = f1 * f1;       // limit t -> inf of (t^2 f1, t, t^2 f1^2 + 1) / t^2
+    p2[0] = f2 * c * c; p2[1] = -a * c; p2[2] = f2 * f2 * c * c + a * a;
+  } else {
+    const double t = best_t, u = a * t + b, v = c * t + d;
+    p1[0] = t * t * f1; p1[1] = t; p1[2] = t * t * f1 * f1 + 1.0;
+    p2[0] = f2 * v * v; p2[1] = -u * v; p2[2] = f2 * f2 * v * v + u * u;
+  }
+  // back: x = T^-1 R^T p
+  double q1v[3], q2v[3];
+  for (int i = 0; i < 3; ++i) {
+    q1v[i] = R1[0][i] * p1[0] + R1[1][i] * p1[1] + R1[2][i] * p1[2];
+    q2v[i] = R2[0][i] * p2[0] + R2[1][i] * p2[1] + R2[2][i] * p2[2];
+  }
+  if (fabs(q1v[2]) < 1e-300 || fabs(q2v[2]) < 1e-300) return;
+  x1 = q1v[0] / q1v[2] + x1; y1 = q1v[1] / q1v[2] + y1;
+  x2 = q2v[0] / q2v[2] + x2; y2 = q2v[1] / q2v[2] + y2;
+}
+
+__global__ void okp_triangulate_kernel(TriParams tp, const float* __restrict__ lxy, const float* __restrict__ rxy, int m,
+                                       double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double xl, yl, xr, yr;
+  fisheye_undistort(tp.left, (double)lxy[2 * i], (double)lxy[2 * i + 1], xl, yl);
+  fisheye_undistort(tp.right, (double)rxy[2 * i], (double)rxy[2 * i + 1], xr, yr);
+  // cv2 hands float32 back for float32 input (camera_utils.py:93-97)
+  xl = (double)(float)xl; yl = (double)(float)yl; xr = (double)(float)xr; yr = (double)(float)yr;
+  if (tp.correct) {
+    double F[9];
+    for (int k = 0; k < 9; ++k) F[k] = tp.F[k];
+    hartley_sturm(F, xl, yl, xr, yr);
+    xl = (double)(float)xl; yl = (double)(float)yl; xr = (double)(float)xr; yr = (double)(float)yr;
+  }
+  // P1 = K_l [I 0]; P2 = K_r T_RL[:3]
+  double P1[3][4] = {{tp.left.fx, 0, tp.left.cx, 0}, {0, tp.left.fy, tp.left.cy, 0}, {0, 0, 1, 0}};
+  double P2[3][4];
+  for (int j = 0; j < 4; ++j) {
+    P2[0][j] = tp.right.fx * tp.T[j] + tp.right.cx * tp.T[8 + j];
+    P2[1][j] = tp.right.fy * tp.T[4 + j] + tp.right.cy * tp.T[8 + j];
+    P2[2][j] = tp.T[8 + j];
+  }
+  double A[4][4];
+  for (int j = 0; j < 4; ++j) {
+    A[0][j] = xl * P1[2][j] - P1[0][j];
+    A[1][j] = yl * P1[2][j] - P1[1][j];
+    A[2][j] = xr * P2[2][j] - P2[0][j];
+    A[3][j] = yr * P2[2][j] - P2[1][j];
+  }
+  double v[4];
+  null_vector4(A, v);
+  out[3 * i + 0] = v[0] / v[3];
+  out[3 * i + 1] = v[1] / v[3];
+  out[3 * i + 2] = v[2] / v[3];
+}
+
+}  // namespace
+
+extern "C" int okp_fisheye_undistort(const okp_camera* cam, const float* xy, int32_t m, double* out, void* stream) {
+  if (!cam || (m > 0 && (!xy || !out))) { okp_set_error("okp_fisheye_undistort: null argument"); return OKP_EINVAL; }
+  if (m <= 0) return OKP_OK;
+  hipLaunchKernelGGL(okp_undistort_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cam, xy, m, out);
+  return okp_check_hip(hipGetLastError(), "okp_fisheye_undistort launch");
+}
+
+extern "C" int okp_unproject_depth(const okp_camera* cam, const float* xy, const int32_t* map_id, int32_t m,
+                                   const float* depth, int32_t h, int32_t w, int32_t max_x, int32_t max_y,
+                                   double* out, void* stream) {
+  if (!cam || (m > 0 && (!xy || !map_id || !depth || !out))) { okp_set_error("okp_unproject_depth: null argument"); return OKP_EINVAL; }
+  if (m <= 0) return OKP_OK;
+  if (max_x < 0 || max_x >= w || max_y < 0 || max_y >= h) {
+    okp_set_error("okp_unproject_depth: clip box (%d,%d) outside the %dx%d depth map", max_x, max_y, h, w);
+    return OKP_EINVAL;
+  }
+  hipLaunchKernelGGL(okp_unproject_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cam, xy, map_id, m, depth, h, w, max_x, max_y, out);
+  return okp_check_hip(hipGetLastError(), "okp_unproject_depth launch");
+}
+
+extern "C" int okp_triangulate_dlt(const okp_camera* left, const okp_camera* right, const double* T_RL, const double* F,
+                                   int correct_matches, const float* lxy, const float* rxy, int32_t m, double* out,
+                                   void* stream) {
+  if (!left || !right || !T_RL || (correct_matches && !F) || (m > 0 && (!lxy || !rxy || !out))) {
+    okp_set_error("okp_triangulate_dlt: null argument"); return OKP_EINVAL;
+  }
+  if (m <= 0) return OKP_OK;
+  TriParams tp;
+  tp.left = *left; tp.right = *right;
+  for (int i = 0; i < 12; ++i) tp.T[i] = T_RL[i];
+  for (int i = 0; i < 9; ++i) tp.F[i] = F ? F[i] : 0.0;
+  tp.correct = correct_matches;
+  hipLaunchKernelGGL(okp_triangulate_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, tp, lxy, rxy, m, out);
+  return okp_check_hip(hipGetLastError(), "okp_triangulate_dlt launch");
+}

@@ -1,0 +1,307 @@
+// Tap-list implicit-GEMM convolution for gfx950 (MI355X), fp32 and bf16.
+//
+//   D[co][pixel] = sum over K-slices  Wslice[co][128 B of K] . Xslice[pixel][128 B of K]
+//
+// A K-slice is 128 bytes of the reduction dimension per row (64 bf16 or 32 fp32 channels of one
+// tap).  The weight side is pre-packed [slice][cout_pad][128 B]; the pixel side is gathered from
+// NHWC activations with one 16-byte buffer_load per lane (hardware range check returns 0 for the
+// padding halo, so there is no im2col buffer and no border code).  Both tiles are staged in LDS
+// as [row][8 x 16 B] with the 16-B chunk index XOR-swizzled by (row>>1)&7, which makes the
+// ds_read_b128 fragment reads of the 32x32 MFMA conflict-free (two 128-B rows share a 256-B
+// bank row).  D keeps the output channel on the accumulator rows, so every lane owns 4
+// consecutive channels of one pixel per register group; the epilogue adds the bias in registers,
+// transposes through LDS and writes whole NHWC pixel rows (16 B per lane, coalesced) after the
+// optional residual add and ReLU.
+//
+// Reference semantics being computed: torch conv2d/conv_transpose2d + eval-mode batch_norm
+// (folded into W/bias) + add + relu — see include/okp.h for the file:line list.
+#include "okp_internal.h"
+
+namespace {
+
+constexpr uint32_t kInvalidOff = 0x80000000u;   // >= num_records of every tensor we accept (< 2 GiB)
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  // 16 B = 4 fp32 of K per lane: four 32x32x2 MFMAs, lane half h supplies k = 4h+e (K order is
+  // the same on both operands, so any permutation of K inside the slice is legal).
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a);
+    const f32x4 fb = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
+  }
+};
+template <> struct Mma<__bf16> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+  static constexpr int kBytes8 = 32;   // bytes of 8 channels
+  static __device__ __forceinline__ void add8(float (&v)[8], const char* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+  }
+  static __device__ __forceinline__ void store8(const float (&v)[8], char* p) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 16) = b;
+  }
+};
+template <> struct Io<__bf16> {
+  static constexpr int kBytes8 = 16;
+  static __device__ __forceinline__ void add8(float (&v)[8], const char* p) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+  }
+  static __device__ __forceinline__ void store8(const float (&v)[8], char* p) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+
+__device__ __forceinline__ uint32_t swz(int row, int chunk) {   // byte offset of a 16-B chunk in a [row][128 B] tile
+  return (uint32_t)row * 128u + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T, int BCO, int BPX, int WCO, int WPX, int NSRC>
+__global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgemmParams p) {
+  constexpr int NT = 64 * WCO * WPX;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int RPP = NT / 8;                 // tile rows covered by one loader pass (8 chunks per row)
+  constexpr int WROWS = BCO / RPP;
+  constexpr int XROWS = BPX / RPP;
+  constexpr int TCO = BCO / WCO / 32;
+  constexpr int TPX = BPX / WPX / 32;
+  constexpr int STAGE = (BCO + BPX) * 128;
+  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int PASSES = (BPX * BCO * 4 > LDS_BYTES) ? 2 : 1;
+  static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
+  static_assert(BPX * BCO * 4 / PASSES <= LDS_BYTES, "epilogue staging must fit");
+  constexpr int PX_PER_PASS = BPX / PASSES;
+  constexpr int PITCH = BCO * 4;
+
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int co_tile = blockIdx.x % p.n_co_tiles;
+  const int px_tile = blockIdx.x / p.n_co_tiles;
+  const int co0 = co_tile * BCO, px0 = px_tile * BPX;
+  const int HoWo = p.Ho * p.Wo;
+  const int P = p.N * HoWo;
+
+  const int c = tid & 7;        // 16-B chunk handled by this thread in every loader row
+  const int r0 = tid >> 3;
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[0]), 0, (int)p.src_bytes[0], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[NSRC - 1]), 0, (int)p.src_bytes[NSRC - 1], 0x00020000);
+
+  // ---- per-thread row state -------------------------------------------------------------
+  uint32_t wbase[WROWS];
+#pragma unroll
+  for (int i = 0; i < WROWS; ++i) {
+    const int co = co0 + r0 + i * RPP;
+    wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)c * 16u : kInvalidOff;
+  }
+  uint32_t xbase[NSRC][XROWS];
+  uint32_t xmask[XROWS];
+#pragma unroll
+  for (int i = 0; i < XROWS; ++i) {
+    const int pix = px0 + r0 + i * RPP;
+    const bool valid = pix < P;
+    const int pp = valid ? pix : 0;
+    const int n = pp / HoWo;
+    const int rem = pp - n * HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const int hi0 = ho * p.conv_stride[s], wi0 = wo * p.conv_stride[s];
+      xbase[s][i] = (uint32_t)(((n * p.srcH[s] + hi0) * p.srcW[s] + wi0) * p.src_pix_stride[s]) * (uint32_t)ESZ + (uint32_t)(c & 3) * 16u;
+    }
+    uint32_t m = 0;
+    for (int t = 0; t < p.n_taps; ++t) {
+      const int s = (NSRC == 1) ? 0 : p.taps[t].src;
+      const int hi = ho * p.conv_stride[s] + p.taps[t].dy;
+      const int wi = wo * p.conv_stride[s] + p.taps[t].dx;
+      const bool ok = valid && hi >= 0 && hi < p.srcH[s] && wi >= 0 && wi < p.srcW[s];
+      m |= (ok ? 1u : 0u) << t;
+    }
+    xmask[i] = m;
+  }
+
+  f32x16 acc[TCO][TPX];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TPX; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  u32x4 wreg[WROWS], xreg[XROWS];
+
+  auto load_slice = [&](int s) {
+    const OkpSlice sl = p.slices[s];
+    const int src = (NSRC == 1) ? 0 : (int)sl.src;
+    const int W = p.srcW[src], ps = p.src_pix_stride[src];
+    const int d_lo = ((p.taps[sl.tap_lo].dy * W + p.taps[sl.tap_lo].dx) * ps + sl.c0_lo) * ESZ;
+    const int d_hi = ((p.taps[sl.tap_hi].dy * W + p.taps[sl.tap_hi].dx) * ps + sl.c0_hi) * ESZ;
+    const bool hi_half = c >= 4;
+    const uint32_t delta = (uint32_t)(hi_half ? d_hi : d_lo);
+    const int tap = hi_half ? (int)sl.tap_hi : (int)sl.tap_lo;
+    const bool chunk_ok = c < (int)sl.nvalid;
+    const uint32_t wslice = (uint32_t)s * (uint32_t)p.cout_pad * 128u;
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i)
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase[i] + wslice), 0, 0);
+#pragma unroll
+    for (int i = 0; i < XROWS; ++i) {
+      const bool ok = chunk_ok && ((xmask[i] >> tap) & 1u);
+      const uint32_t base = (NSRC == 1 || src == 0) ? xbase[0][i] : xbase[NSRC - 1][i];
+      const uint32_t off = ok ? base + delta : kInvalidOff;
+      xreg[i] = (NSRC == 1 || src == 0) ? __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)off, 0, 0)
+                                        : __builtin_amdgcn_raw_buffer_load_b128(rs_x1, (int)off, 0, 0);
+    }
+  };
+
+  auto store_slice = [&](int stage) {
+    char* wt = smem + stage * STAGE;
+    char* xt = wt + BCO * 128;
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) *reinterpret_cast<u32x4*>(wt + swz(r0 + i * RPP, c)) = wreg[i];
+#pragma unroll
+    for (int i = 0; i < XROWS; ++i) *reinterpret_cast<u32x4*>(xt + swz(r0 + i * RPP, c)) = xreg[i];
+  };
+
+  const int fr = lane & 31, fh = lane >> 5;
+  auto compute = [&](int stage) {
+    const char* wt = smem + stage * STAGE;
+    const char* xt = wt + BCO * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 a[TCO], b[TPX];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz((wco * TCO + i) * 32 + fr, 2 * kk + fh));
+#pragma unroll
+      for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz((wpx * TPX + j) * 32 + fr, 2 * kk + fh));
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+    }
+  };
+
+  // ---- main loop: register-staged double buffer, one barrier per K-slice -------------------
+  const int S = p.n_slices;
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const int stage = s & 1;
+    if (s + 1 < S) load_slice(s + 1);      // global loads fly under the MFMAs of slice s
+    compute(stage);
+    if (s + 1 < S) store_slice(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias in registers, transpose through LDS, coalesced NHWC rows ----------------
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (PASSES == 1 || wpx == pass) {
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co_l = (wco * TCO + i) * 32 + 8 * g + 4 * fh;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co0 + co_l);   // bias is padded to n_co_tiles*BCO
+#pragma unroll
+          for (int j = 0; j < TPX; ++j) {
+            const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * 32 + fr;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+            *reinterpret_cast<f32x4*>(smem + prow * PITCH + (((co_l >> 2) ^ (prow & 7)) << 4)) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int GROUPS = BCO / 8;
+    constexpr int ITEMS = PX_PER_PASS * GROUPS;
+    for (int it = tid; it < ITEMS; it += NT) {
+      const int q = it % GROUPS;
+      const int prow = it / GROUPS;
+      const int pix = px0 + pass * PX_PER_PASS + prow;
+      const int co = co0 + q * 8;
+      if (pix < P && co < p.cout) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q) ^ (prow & 7)) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q + 1) ^ (prow & 7)) << 4));
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int n = pix / HoWo;
+        const int rem = pix - n * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + p.out_oy)) * p.OW + (size_t)(wo * p.out_step + p.out_ox);
+        if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
+        if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        Io<T>::store8(v, static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ);
+      }
+    }
+    if (pass + 1 < PASSES) __syncthreads();
+  }
+}
+
+template <typename T, int BCO, int BPX, int WCO, int WPX>
+int launch_cfg(const okp_conv* plan, OkpIgemmParams p, hipStream_t stream) {
+  const int P = p.N * p.Ho * p.Wo;
+  p.n_co_tiles = (p.cout_pad + BCO - 1) / BCO;
+  const int n_px_tiles = (P + BPX - 1) / BPX;
+  const dim3 grid((unsigned)(p.n_co_tiles * n_px_tiles));
+  const dim3 block(64 * WCO * WPX);
+  if (plan->n_src == 1)
+    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, 1>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, 2>), grid, block, 0, stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_igemm launch");
+}
+
+template <typename T>
+int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
+  switch (tile) {
+    case 3: return launch_cfg<T, 256, 256, 4, 2>(plan, p, stream);
+    case 2: return launch_cfg<T, 128, 128, 2, 2>(plan, p, stream);
+    default: return launch_cfg<T, 64, 64, 2, 2>(plan, p, stream);
+  }
+}
+
+}  // namespace
+
+int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
+  if (tile == 0) {
+    // Fill the 256 CUs first; only then grow the tile (bigger tiles re-read less from L2).
+    const long P = (long)p.N * p.Ho * p.Wo;
+    auto tiles = [&](int b) { return ((P + b - 1) / b) * ((p.cout_pad + b - 1) / b); };
+    if (tiles(256) >= 256 && p.cout_pad >= 192) tile = 3;
+    else if (tiles(128) >= 256) tile = 2;
+    else tile = 1;
+  }
+  if (plan->dtype == OKP_BF16) return launch_tile<__bf16>(plan, p, tile, stream);
+  return launch_tile<float>(plan, p, tile, stream);
+}

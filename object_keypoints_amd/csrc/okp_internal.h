@@ -1,0 +1,70 @@
+// Internal declarations shared by the HIP translation units of libokp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "okp.h"
+
+#define OKP_MAX_TAPS 32
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// One K-slice of the implicit GEMM = 128 bytes of K per row (64 bf16 / 32 fp32):
+// chunks 0-3 (64 B) come from tap_lo at channel c0_lo, chunks 4-7 from tap_hi at c0_hi.
+struct OkpSlice {
+  uint8_t tap_lo, tap_hi, src, nvalid;   // nvalid: number of 16-B chunks that carry data (1..8)
+  int32_t c0_lo, c0_hi;                  // first channel (elements) of each half
+  int32_t pad;
+};
+
+struct OkpTapDev {
+  int32_t dy, dx, src, pad;
+};
+
+struct OkpIgemmParams {
+  const void* src[2];
+  uint32_t src_bytes[2];
+  int32_t srcH[2], srcW[2], src_pix_stride[2], conv_stride[2];
+  const void* weights;     // [n_slices][cout_pad][128 B]
+  uint32_t w_bytes;
+  int32_t cout_pad;
+  const float* bias;       // [cout_pad]
+  const OkpSlice* slices;
+  int32_t n_slices;
+  int32_t n_taps;
+  int32_t N, Ho, Wo;
+  void* out;
+  int32_t OH, OW, out_step, out_oy, out_ox, out_pix_stride;
+  int32_t cout;
+  const void* res;
+  int32_t res_pix_stride;
+  int32_t act;
+  int32_t n_co_tiles;
+  OkpTapDev taps[OKP_MAX_TAPS];
+};
+
+struct okp_conv {
+  int dtype;
+  int n_src;
+  int32_t cin[2];
+  int32_t conv_stride[2];
+  int32_t cout, cout_pad;
+  int32_t n_taps;
+  OkpTapDev taps[OKP_MAX_TAPS];
+  int32_t n_slices;
+  int act;
+  void* weights_dev;
+  uint32_t w_bytes;
+  float* bias_dev;
+  OkpSlice* slices_dev;
+};
+
+void okp_set_error(const char* fmt, ...);
+int okp_check_hip(hipError_t e, const char* what);
+
+// launchers implemented in the .hip files
+int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);

@@ -1,0 +1,150 @@
+// Heat-map peak extraction: one workgroup per (frame, keypoint-type) map, the whole map and its
+// 5x5 box sums resident in LDS, ordered compaction with wave-level ballot/prefix reductions.
+//
+// Restates KeypointExtractionComponent._extract_keypoints/_compute_points
+// (reference perception/pipeline.py:46-79) and nms (perception/models.py:55-58).
+// The index contract is bit-exact: the box sum is accumulated in fp32 in row-major tap order
+// (dy outer, dx inner) starting from 0 with zero padding — any other association changes which
+// pixels tie with their 5x5 maximum (SURVEY.md §7 "Bit-exact peaks").
+#include "okp_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int cap,
+                                                           int* __restrict__ count, int* __restrict__ yx,
+                                                           float* __restrict__ xyc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W;
+  float* prob = lds;            // [HW]
+  float* box = lds + HW;        // [HW]
+  __shared__ int wave_tot[4];
+  const int map = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* src = heat + (size_t)map * HW;
+  for (int i = tid; i < HW; i += 256) prob[i] = src[i];
+  __syncthreads();
+  for (int i = tid; i < HW; i += 256) {
+    const int y = i / W, x = i - y * W;
+    float s = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int yy = y + dy;
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int xx = x + dx;
+        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? prob[yy * W + xx] : 0.f;
+        s = s + v;     // sequential fp32, row-major taps: the reference's accumulation order
+      }
+    }
+    box[i] = s;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  int running = 0;
+  int* my_yx = yx + (size_t)map * cap * 2;
+  float* my_xyc = xyc + (size_t)map * cap * 3;
+  for (int base = 0; base < HW; base += 256) {
+    const int i = base + tid;
+    bool peak = false;
+    int y = 0, x = 0;
+    if (i < HW) {
+      y = i / W; x = i - y * W;
+      const float b = box[i];
+      float m = b;
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int xx = x + dx;
+          if (xx < 0 || xx >= W) continue;
+          m = fmaxf(m, box[yy * W + xx]);
+        }
+      }
+      peak = (b == m) && (b > 0.5f);
+    }
+    const unsigned long long ball = __ballot(peak);
+    const int before = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(ball);
+    __syncthreads();
+    int off = running + before;
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int t = wave_tot[w];
+      if (w < wave) off += t;
+      tot += t;
+    }
+    if (peak && off < cap) {
+      const int y0 = max(y - 2, 0), y1 = min(y + 3, H), x0 = max(x - 2, 0), x1 = min(x + 3, W);
+      float sp = 0.f, sy = 0.f, sx = 0.f;
+      for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) {
+          const float pv = prob[yy * W + xx];
+          sp += pv;
+          sy += pv * (float)yy;
+          sx += pv * (float)xx;
+        }
+      my_yx[off * 2 + 0] = y;
+      my_yx[off * 2 + 1] = x;
+      my_xyc[off * 3 + 0] = sx / sp;
+      my_xyc[off * 3 + 1] = sy / sp;
+      my_xyc[off * 3 + 2] = sp;
+    }
+    running += tot;
+    __syncthreads();
+  }
+  if (tid == 0) count[map] = running;
+}
+
+__global__ __launch_bounds__(256) void okp_nms_maxpool_kernel(const float* __restrict__ x, int H, int W, int size,
+                                                              long total, float* __restrict__ out) {
+  const int r = size / 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(idx % W);
+    const long t = idx / W;
+    const int yy = (int)(t % H);
+    const float* m = x + (t / H) * (long)H * W;
+    const float v = m[yy * W + xx];
+    float mx = v;
+    for (int dy = -r; dy <= r; ++dy) {
+      const int y2 = yy + dy;
+      if (y2 < 0 || y2 >= H) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int x2 = xx + dx;
+        if (x2 < 0 || x2 >= W) continue;
+        mx = fmaxf(mx, m[y2 * W + x2]);
+      }
+    }
+    out[idx] = v * ((v == mx) ? 1.f : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int okp_nms_maxpool(const float* x, int32_t n_maps, int32_t h, int32_t w, int32_t size, float* out, void* stream) {
+  if (!x || !out) { okp_set_error("okp_nms_maxpool: null argument"); return OKP_EINVAL; }
+  if (size < 1 || size > 15 || !(size & 1)) { okp_set_error("okp_nms_maxpool: size %d must be odd and <= 15", size); return OKP_EINVAL; }
+  const long total = (long)n_maps * h * w;
+  if (total <= 0) return OKP_OK;
+  long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(okp_nms_maxpool_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, h, w, size, total, out);
+  return okp_check_hip(hipGetLastError(), "okp_nms_maxpool launch");
+}
+
+extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_t w, int32_t cap, int32_t* count,
+                            int32_t* yx, float* xyc, void* stream) {
+  if (!heat || !count || !yx || !xyc) { okp_set_error("okp_peak_nms: null argument"); return OKP_EINVAL; }
+  if (n_maps < 0 || h < 1 || w < 1 || cap < 1) { okp_set_error("okp_peak_nms: bad sizes n_maps=%d h=%d w=%d cap=%d", n_maps, h, w, cap); return OKP_EINVAL; }
+  if ((long)h * w > 16384) { okp_set_error("okp_peak_nms: map %dx%d exceeds the 16384-pixel LDS-resident limit", h, w); return OKP_EINVAL; }
+  if (n_maps == 0) return OKP_OK;
+  const size_t lds = (size_t)h * w * 2 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (int e = okp_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(okp_peak_nms_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 2 * sizeof(float)),
+                              "okp_peak_nms: hipFuncSetAttribute"))
+      return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream, heat, h, w, cap, count, yx, xyc);
+  return okp_check_hip(hipGetLastError(), "okp_peak_nms launch");
+}

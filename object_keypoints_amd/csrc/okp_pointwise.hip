@@ -1,0 +1,233 @@
+// HBM-bound kernels around the implicit GEMM: depth-wise 3x3 (fire-module tail), frame packing
+// for the stem, and the final 1x1 of the heads (NHWC -> NCHW fp32 + sigmoid).
+// All of them move 16 bytes per lane per access and keep channels contiguous across lanes.
+#include "okp_internal.h"
+
+namespace {
+
+template <typename T> struct Vec;      // 16 bytes of channels
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const char* p, float (&v)[4]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e];
+  }
+  static __device__ __forceinline__ void store(char* p, const float (&v)[4]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = a;
+  }
+};
+template <> struct Vec<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const char* p, float (&v)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+  }
+  static __device__ __forceinline__ void store(char* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+
+struct DwParams {
+  const void* src; int32_t H, W, src_ps;
+  const float* w; const float* bias;
+  const void* res; int32_t res_ps;
+  void* out; int32_t Ho, Wo, out_ps;
+  int32_t N, C, stride, act;
+};
+
+// One lane = one output pixel x 16 bytes of channels.  Lanes of a wave walk the channel
+// dimension first, so every tap read and the final store are contiguous across the wave.
+template <typename T>
+__global__ __launch_bounds__(256) void okp_dwconv3x3_kernel(const DwParams p) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int ESZ = (int)sizeof(T);
+  const int cgroups = p.C / VN;
+  const long total = (long)p.N * p.Ho * p.Wo * cgroups;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgroups);
+    const long pix = idx / cgroups;
+    const int wo = (int)(pix % p.Wo);
+    const long t = pix / p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int c0 = cg * VN;
+    float acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = p.bias[c0 + e];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * p.stride + dy - 1;
+      if (hi < 0 || hi >= p.H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * p.stride + dx - 1;
+        if (wi < 0 || wi >= p.W) continue;
+        float x[VN];
+        Vec<T>::load(static_cast<const char*>(p.src) + (((size_t)n * p.H + hi) * p.W + wi) * (size_t)p.src_ps * ESZ + (size_t)c0 * ESZ, x);
+        const float* wt = p.w + (dy * 3 + dx) * p.C + c0;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = fmaf(x[e], wt[e], acc[e]);
+      }
+    }
+    const size_t opix = ((size_t)n * p.Ho + ho) * p.Wo + wo;
+    if (p.res) {
+      float r[VN];
+      Vec<T>::load(static_cast<const char*>(p.res) + (opix * p.res_ps + c0) * ESZ, r);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc[e] += r[e];
+    }
+    if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    Vec<T>::store(static_cast<char*>(p.out) + (opix * p.out_ps + c0) * ESZ, acc);
+  }
+}
+
+// NCHW fp32 frames -> NHWC4 with a zero halo of 3 (the 7x7 stem reads 8 pixels x 4 channels =
+// one contiguous K half-slice per kernel row).  One lane per output pixel: three strided plane
+// reads (coalesced along x) and one 8/16-byte store.
+template <typename T>
+__global__ __launch_bounds__(256) void okp_pack_frames_kernel(const float* __restrict__ in, int N, int H, int W,
+                                                               T* __restrict__ out, int OHt, int OWt) {
+  const long total = (long)N * OHt * OWt;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % OWt);
+    const long t = idx / OWt;
+    const int y = (int)(t % OHt);
+    const int n = (int)(t / OHt);
+    const int sy = y - 3, sx = x - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+      const float* base = in + ((size_t)n * 3 * H + sy) * W + sx;
+      v[0] = base[0];
+      v[1] = base[(size_t)H * W];
+      v[2] = base[2 * (size_t)H * W];
+    }
+    T* o = out + idx * 4;
+    o[0] = (T)v[0]; o[1] = (T)v[1]; o[2] = (T)v[2]; o[3] = (T)0.f;
+  }
+}
+
+struct HeadParams {
+  const void* src; int32_t src_ps;
+  int32_t N, HW, n_out;
+  const float* w; const float* bias;
+  int32_t in_c_off[OKP_HEAD_MAX_OUT];
+  int32_t act[OKP_HEAD_MAX_OUT];
+  float* out_ptr[OKP_HEAD_MAX_OUT];
+  int64_t out_n_stride[OKP_HEAD_MAX_OUT];
+};
+
+// One lane per pixel; outputs are written plane by plane, so stores are contiguous across lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void okp_head_out_kernel(const HeadParams p) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int ESZ = (int)sizeof(T);
+  __shared__ float sw[OKP_HEAD_MAX_OUT * 32];
+  __shared__ float sb[OKP_HEAD_MAX_OUT];
+  for (int i = threadIdx.x; i < p.n_out * 32; i += blockDim.x) sw[i] = p.w[i];
+  for (int i = threadIdx.x; i < p.n_out; i += blockDim.x) sb[i] = p.bias[i];
+  __syncthreads();
+  const long total = (long)p.N * p.HW;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(pix / p.HW);
+    const int hw = (int)(pix - (long)n * p.HW);
+    const char* row = static_cast<const char*>(p.src) + (size_t)pix * p.src_ps * ESZ;
+    int cached_off = -1;
+    float x[32];
+    for (int o = 0; o < p.n_out; ++o) {
+      const int off = p.in_c_off[o];
+      if (off != cached_off) {           // outputs of one head share their 32 input channels
+#pragma unroll
+        for (int k = 0; k < 32 / VN; ++k) {
+          float t[VN];
+          Vec<T>::load(row + (size_t)(off + k * VN) * ESZ, t);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) x[k * VN + e] = t[e];
+        }
+        cached_off = off;
+      }
+      float acc = sb[o];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(x[k], sw[o * 32 + k], acc);
+      if (p.act[o] == OKP_ACT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
+      else if (p.act[o] == OKP_ACT_RELU) acc = fmaxf(acc, 0.f);
+      p.out_ptr[o][(size_t)n * p.out_n_stride[o] + hw] = acc;
+    }
+  }
+}
+
+int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride, const okp_tensor* src,
+                                     const float* w_dev, const float* bias_dev, const okp_tensor* res,
+                                     const okp_tensor* out, int act, void* stream) {
+  if (!src || !out || !src->data || !out->data || !w_dev || !bias_dev) { okp_set_error("okp_dwconv3x3_forward: null argument"); return OKP_EINVAL; }
+  const int esz = dtype == OKP_BF16 ? 2 : 4;
+  const int vn = 16 / esz;
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_dwconv3x3_forward: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (conv_stride != 1 && conv_stride != 2) { okp_set_error("okp_dwconv3x3_forward: stride %d unsupported", conv_stride); return OKP_EINVAL; }
+  if (c <= 0 || c % vn) { okp_set_error("okp_dwconv3x3_forward: channels %d not a multiple of %d", c, vn); return OKP_EINVAL; }
+  if (src->pix_stride % vn || out->pix_stride % vn || (res && res->data && res->pix_stride % vn)) {
+    okp_set_error("okp_dwconv3x3_forward: pixel strides must be multiples of %d elements", vn); return OKP_EINVAL;
+  }
+  const int ho = (src->h + 2 - 3) / conv_stride + 1, wo = (src->w + 2 - 3) / conv_stride + 1;
+  if (out->h != ho || out->w != wo) { okp_set_error("okp_dwconv3x3_forward: out is %dx%d, expected %dx%d", out->h, out->w, ho, wo); return OKP_EINVAL; }
+  DwParams p;
+  p.src = src->data; p.H = src->h; p.W = src->w; p.src_ps = src->pix_stride;
+  p.w = w_dev; p.bias = bias_dev;
+  p.res = (res && res->data) ? res->data : nullptr; p.res_ps = res ? res->pix_stride : 0;
+  p.out = out->data; p.Ho = ho; p.Wo = wo; p.out_ps = out->pix_stride;
+  p.N = n; p.C = c; p.stride = conv_stride; p.act = act;
+  const long total = (long)n * ho * wo * (c / vn);
+  const int grid = grid_for(total, 256);
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(okp_dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_dwconv3x3 launch");
+}
+
+extern "C" int okp_pack_frames(int dtype, const float* frames, int32_t n, int32_t h, int32_t w, void* out, int32_t out_w, void* stream) {
+  if (!frames || !out) { okp_set_error("okp_pack_frames: null argument"); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_pack_frames: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (out_w < w + 6) { okp_set_error("okp_pack_frames: out_w %d < w+6", out_w); return OKP_EINVAL; }
+  const long total = (long)n * (h + 6) * out_w;
+  const int grid = grid_for(total, 256);
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (__bf16*)out, h + 6, out_w);
+  else hipLaunchKernelGGL(okp_pack_frames_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (float*)out, h + 6, out_w);
+  return okp_check_hip(hipGetLastError(), "okp_pack_frames launch");
+}
+
+extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void* stream) {
+  if (!a || !a->src.data || !a->w_dev || !a->bias_dev) { okp_set_error("okp_head_out_forward: null argument"); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_head_out_forward: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (a->n_out < 1 || a->n_out > OKP_HEAD_MAX_OUT) { okp_set_error("okp_head_out_forward: n_out %d out of range", a->n_out); return OKP_EINVAL; }
+  const int vn = dtype == OKP_BF16 ? 8 : 4;
+  if (a->src.pix_stride % vn) { okp_set_error("okp_head_out_forward: pixel stride must be a multiple of %d", vn); return OKP_EINVAL; }
+  HeadParams p;
+  p.src = a->src.data; p.src_ps = a->src.pix_stride;
+  p.N = a->n; p.HW = a->h * a->w; p.n_out = a->n_out;
+  p.w = a->w_dev; p.bias = a->bias_dev;
+  for (int o = 0; o < a->n_out; ++o) {
+    if (a->in_c_off[o] % vn || !a->out_ptr[o]) { okp_set_error("okp_head_out_forward: output %d misaligned or null", o); return OKP_EINVAL; }
+    p.in_c_off[o] = a->in_c_off[o]; p.act[o] = a->act[o]; p.out_ptr[o] = a->out_ptr[o]; p.out_n_stride[o] = a->out_n_stride[o];
+  }
+  const long total = (long)p.N * p.HW;
+  const int grid = grid_for(total, 256);
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_head_out_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(okp_head_out_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_head_out launch");
+}

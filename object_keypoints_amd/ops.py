@@ -1,0 +1,264 @@
+"""Thin, torch-aware wrappers over the C ABI (include/okp.h).
+
+torch is used for device memory and streams only: every computation below is a call into
+libokp_hip.so on `torch.cuda.current_stream()`.  Nothing here has a CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import OKP_BF16, OKP_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, OkpError
+
+_DTYPES = {torch.float32: OKP_F32, torch.bfloat16: OKP_BF16}
+
+
+def okp_dtype(torch_dtype):
+    try:
+        return _DTYPES[torch_dtype]
+    except KeyError:
+        raise OkpError(f"unsupported activation dtype {torch_dtype}; use torch.float32 or torch.bfloat16")
+
+
+def stream_handle():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise OkpError(f"{what} must be a device tensor: the HIP path has no CPU fallback")
+
+
+class Act:
+    """NHWC activation view: a contiguous device tensor [N,H,W,Ctot] and a channel window."""
+
+    __slots__ = ("t", "c0", "c", "orig_hw")
+
+    def __init__(self, t, c0=0, c=None):
+        self.orig_hw = None          # set by pack_frames: (H, W) of the un-padded frame
+        require_cuda(t, "activation")
+        if t.dim() != 4 or not t.is_contiguous():
+            raise OkpError("activation must be a contiguous [N,H,W,C] tensor")
+        self.t = t
+        self.c0 = c0
+        self.c = t.shape[3] - c0 if c is None else c
+        if self.c0 < 0 or self.c0 + self.c > t.shape[3]:
+            raise OkpError("channel window outside tensor")
+
+    n = property(lambda s: s.t.shape[0])
+    h = property(lambda s: s.t.shape[1])
+    w = property(lambda s: s.t.shape[2])
+    dtype = property(lambda s: s.t.dtype)
+
+    def slice(self, c0, c):
+        return Act(self.t, self.c0 + c0, c)
+
+    def view(self):
+        esz = self.t.element_size()
+        return _lib.okp_tensor(self.t.data_ptr() + self.c0 * esz, self.h, self.w, self.t.shape[3],
+                               self.t.numel() * esz - self.c0 * esz)
+
+    @staticmethod
+    def empty(n, h, w, c, dtype, device):
+        return Act(torch.empty((n, h, w, c), dtype=dtype, device=device))
+
+    @staticmethod
+    def from_nchw(x, dtype):
+        """Layout change at the public boundary (torch copy kernels; not part of the hot path)."""
+        require_cuda(x, "input")
+        return Act(x.permute(0, 2, 3, 1).contiguous().to(dtype))
+
+    def to_nchw(self):
+        return self.t[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
+
+
+_NULL_TENSOR = _lib.okp_tensor(None, 0, 0, 0, 0)
+
+
+class ConvPlan:
+    """One okp_conv plan.  taps: [(src, dy, dx, weight[cout, cin_src] float32)]."""
+
+    def __init__(self, dtype, cins, strides, cout, taps, bias=None, relu=False, alg_k=None):
+        L = _lib.lib()
+        self.dtype = dtype
+        self.cout = cout
+        self.n_src = len(cins)
+        self.cins = list(cins)
+        n_taps = len(taps)
+        arr_t = (_lib.okp_tap * n_taps)()
+        keep = []
+        k = 0
+        for i, (src, dy, dx, w) in enumerate(taps):
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            if w.shape != (cout, cins[src]):
+                raise OkpError(f"tap {i}: weight shape {w.shape} != {(cout, cins[src])}")
+            keep.append(w)
+            arr_t[i] = _lib.okp_tap(src, dy, dx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+            k += cins[src]
+        self.alg_k = k if alg_k is None else alg_k      # algorithmic reduction length per output element
+        b = None
+        if bias is not None:
+            b = np.ascontiguousarray(bias, dtype=np.float32)
+            if b.shape != (cout,):
+                raise OkpError("bias shape")
+        cin_arr = (ctypes.c_int32 * 2)(*(list(cins) + [0])[:2])
+        st_arr = (ctypes.c_int32 * 2)(*(list(strides) + [1])[:2])
+        self._h = L.okp_conv_create(okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t,
+                                    b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if b is not None else None,
+                                    ACT_RELU if relu else ACT_NONE)
+        if not self._h:
+            raise OkpError("okp_conv_create: " + L.okp_last_error().decode())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib._lib is not None:
+            _lib._lib.okp_conv_destroy(h)
+
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0):
+        a = _lib.okp_conv_args()
+        a.n, a.ho, a.wo = out.n, ho, wo
+        for i, s in enumerate(srcs):
+            if s.dtype != self.dtype:
+                raise OkpError("source dtype differs from plan dtype")
+            a.src[i] = s.view()
+        if out.dtype != self.dtype or out.c != self.cout:
+            raise OkpError(f"out has {out.c} channels / {out.dtype}, plan has {self.cout} / {self.dtype}")
+        a.out = out.view()
+        a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
+        a.res = res.view() if res is not None else _NULL_TENSOR
+        a.tile = tile or FORCE_TILE
+        _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
+        COUNTERS["macs"] += out.n * ho * wo * self.cout * self.alg_k
+        COUNTERS["launches"] += 1
+
+
+COUNTERS = {"macs": 0, "launches": 0}
+FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256), 0 = heuristic
+
+
+def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):
+    dt = okp_dtype(src.dtype)
+    sv, ov = src.view(), out.view()
+    rv = res.view() if res is not None else None
+    _lib.check(_lib.lib().okp_dwconv3x3_forward(dt, src.n, src.c, stride, ctypes.byref(sv), w_dev.data_ptr(), bias_dev.data_ptr(),
+                                                ctypes.byref(rv) if rv is not None else None, ctypes.byref(ov),
+                                                ACT_RELU if relu else ACT_NONE, stream_handle()), "okp_dwconv3x3_forward")
+    COUNTERS["macs"] += out.n * out.h * out.w * src.c * 9
+    COUNTERS["launches"] += 1
+
+
+def stem_packed_width(w):
+    wo = (w + 6 - 7) // 2 + 1
+    need = max(w + 6, 2 * (wo - 1) + 8)
+    return (need + 3) // 4 * 4
+
+
+def pack_frames(frames, dtype):
+    """NCHW fp32 frames -> NHWC4 with zero halo 3 (input layout of the 7x7/s2 stem)."""
+    require_cuda(frames, "frames")
+    if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3:
+        raise OkpError("frames must be float32 [N,3,H,W]")
+    frames = frames.contiguous()
+    n, _, h, w = frames.shape
+    wp = stem_packed_width(w)
+    out = torch.empty((n, h + 6, wp, 4), dtype=dtype, device=frames.device)
+    _lib.check(_lib.lib().okp_pack_frames(okp_dtype(dtype), frames.data_ptr(), n, h, w, out.data_ptr(), wp, stream_handle()), "okp_pack_frames")
+    COUNTERS["launches"] += 1
+    act = Act(out)
+    act.orig_hw = (h, w)
+    return act
+
+
+def head_out(src, outputs, w_dev, bias_dev):
+    """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
+    a = _lib.okp_head_out_args()
+    a.n, a.h, a.w = src.n, src.h, src.w
+    a.src = src.view()
+    a.n_out = len(outputs)
+    for i, (off, act, t, ch) in enumerate(outputs):
+        a.in_c_off[i] = off
+        a.act[i] = act
+        a.out_ptr[i] = t.data_ptr() + ch * t.shape[2] * t.shape[3] * 4
+        a.out_n_stride[i] = t.shape[1] * t.shape[2] * t.shape[3]
+    a.w_dev, a.bias_dev = w_dev.data_ptr(), bias_dev.data_ptr()
+    _lib.check(_lib.lib().okp_head_out_forward(okp_dtype(src.dtype), ctypes.byref(a), stream_handle()), "okp_head_out_forward")
+    COUNTERS["macs"] += src.n * src.h * src.w * 32 * len(outputs)
+    COUNTERS["launches"] += 1
+
+
+def peak_nms(heat, cap=64):
+    """heat [N,K,H,W] fp32 (device) -> count [N,K] int32, yx [N,K,cap,2] int32, xyc [N,K,cap,3] fp32 (device)."""
+    require_cuda(heat, "heat")
+    if heat.dtype != torch.float32 or heat.dim() != 4:
+        raise OkpError("heat must be float32 [N,K,H,W]")
+    heat = heat.contiguous()
+    n, k, h, w = heat.shape
+    count = torch.zeros((n, k), dtype=torch.int32, device=heat.device)
+    yx = torch.zeros((n, k, cap, 2), dtype=torch.int32, device=heat.device)
+    xyc = torch.zeros((n, k, cap, 3), dtype=torch.float32, device=heat.device)
+    _lib.check(_lib.lib().okp_peak_nms(heat.data_ptr(), n * k, h, w, cap, count.data_ptr(), yx.data_ptr(), xyc.data_ptr(), stream_handle()), "okp_peak_nms")
+    return count, yx, xyc
+
+
+def nms_maxpool(x, size=5):
+    """x * (x == maxpool_{size}(x)) on [N,C,H,W] fp32 device maps (perception/models.py:55-58)."""
+    require_cuda(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise OkpError("nms expects float32 [N,C,H,W]")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    n, c, h, w = x.shape
+    _lib.check(_lib.lib().okp_nms_maxpool(x.data_ptr(), n * c, h, w, size, out.data_ptr(), stream_handle()), "okp_nms_maxpool")
+    return out
+
+
+def make_camera(K, D):
+    K = np.asarray(K, dtype=np.float64)
+    D = np.asarray(D, dtype=np.float64).reshape(-1)
+    if abs(K[0, 1]) > 1e-12 or abs(K[1, 0]) > 1e-12:
+        raise OkpError("camera matrix with skew is not supported")
+    cam = _lib.okp_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    for i in range(4):
+        cam.d[i] = D[i] if i < D.size else 0.0
+    return cam
+
+
+def fisheye_undistort(cam, xy):
+    require_cuda(xy, "xy")
+    xy = xy.to(torch.float32).contiguous()
+    out = torch.empty((xy.shape[0], 2), dtype=torch.float64, device=xy.device)
+    _lib.check(_lib.lib().okp_fisheye_undistort(ctypes.byref(cam), xy.data_ptr(), xy.shape[0], out.data_ptr(), stream_handle()), "okp_fisheye_undistort")
+    return out
+
+
+def unproject_depth(cam, xy, map_id, depth, max_x, max_y):
+    """xy [M,2] fp32, map_id [M] int32, depth [NM,H,W] fp32 -> [M,3] fp64 (all device)."""
+    require_cuda(xy, "xy")
+    xy = xy.to(torch.float32).contiguous()
+    map_id = map_id.to(torch.int32).contiguous()
+    depth = depth.contiguous()
+    if depth.dtype != torch.float32 or depth.dim() != 3:
+        raise OkpError("depth must be float32 [maps,H,W]")
+    out = torch.empty((xy.shape[0], 3), dtype=torch.float64, device=xy.device)
+    _lib.check(_lib.lib().okp_unproject_depth(ctypes.byref(cam), xy.data_ptr(), map_id.data_ptr(), xy.shape[0], depth.data_ptr(),
+                                              depth.shape[1], depth.shape[2], max_x, max_y, out.data_ptr(), stream_handle()), "okp_unproject_depth")
+    return out
+
+
+def triangulate_dlt(cam_l, cam_r, T_RL, left_xy, right_xy, F=None):
+    require_cuda(left_xy, "left_xy")
+    left_xy = left_xy.to(torch.float32).contiguous()
+    right_xy = right_xy.to(torch.float32).contiguous()
+    if left_xy.shape != right_xy.shape:
+        raise OkpError("left/right point counts differ")
+    T = np.ascontiguousarray(np.asarray(T_RL, dtype=np.float64)[:3, :4])
+    Fp = None
+    if F is not None:
+        Fa = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(3, 3))
+        Fp = Fa.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    out = torch.empty((left_xy.shape[0], 3), dtype=torch.float64, device=left_xy.device)
+    _lib.check(_lib.lib().okp_triangulate_dlt(ctypes.byref(cam_l), ctypes.byref(cam_r), T.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), Fp,
+                                              1 if F is not None else 0, left_xy.data_ptr(), right_xy.data_ptr(), left_xy.shape[0],
+                                              out.data_ptr(), stream_handle()), "okp_triangulate_dlt")
+    return out

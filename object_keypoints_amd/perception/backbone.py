@@ -1,0 +1,319 @@
+"""CornerNet-Squeeze stacked hourglass on the HIP path.
+
+Each class keeps the reference module's parameters under the reference's attribute names (the
+`state_dict` wire format) and, in forward(), runs hand-written HIP kernels
+through the C ABI on NHWC activations (`ops.Act`).  Eval mode only: BatchNorm running
+statistics are folded into the convolution weights when a plan is first built.
+
+Reference modules mirrored (file:line under the reference tree):
+  convolution   perception/corner_net_lite/core/models/py_utils/utils.py:143-156
+  residual      .../py_utils/utils.py:158-185
+  fire_module   .../core/models/CornerNet_Squeeze.py:10-30 (+ factories :32-51)
+  hg_module     .../py_utils/modules.py:25-66
+  hg            .../py_utils/modules.py:68-93
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..ops import Act, ConvPlan, OkpError
+
+
+# ------------------------------------------------------------------------------------------
+# folding helpers (host side, once per plan)
+# ------------------------------------------------------------------------------------------
+
+def _np(t):
+    return t.detach().to("cpu", torch.float32).numpy()
+
+
+def fold_bn(weight, bn, conv_bias=None):
+    """(w * scale[co], bias) for eval-mode BatchNorm2d after a conv with out-channel dim 0."""
+    w = _np(weight).astype(np.float64)
+    cout = w.shape[0]
+    if isinstance(bn, nn.BatchNorm2d):
+        scale = _np(bn.weight).astype(np.float64) / np.sqrt(_np(bn.running_var).astype(np.float64) + bn.eps)
+        shift = _np(bn.bias).astype(np.float64) - _np(bn.running_mean).astype(np.float64) * scale
+    else:
+        scale, shift = np.ones(cout), np.zeros(cout)
+    b = shift if conv_bias is None else shift + _np(conv_bias).astype(np.float64) * scale
+    w = w * scale.reshape((-1,) + (1,) * (w.ndim - 1))
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def conv_taps(w, src=0, pad=None):
+    """OIHW folded weight -> tap list [(src, dy, dx, W[co, ci])] in row-major kernel order."""
+    kh, kw = w.shape[2], w.shape[3]
+    ph = (kh - 1) // 2 if pad is None else pad
+    pw = (kw - 1) // 2 if pad is None else pad
+    return [(src, r - ph, s - pw, np.ascontiguousarray(w[:, :, r, s])) for r in range(kh) for s in range(kw)]
+
+
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+class _HipModule(nn.Module):
+    """Plan cache shared by the mirrored modules; plans are rebuilt when weights are reloaded."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._plans.clear())
+
+    def _plan(self, key, build):
+        if self.training:
+            raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
+        p = self._plans.get(key)
+        if p is None:
+            p = build()
+            self._plans[key] = p
+        return p
+
+    def _apply(self, fn, *a, **k):          # .to()/.cuda() moves parameters: device constants must follow
+        self._plans.clear()
+        return super()._apply(fn, *a, **k)
+
+
+class convolution(_HipModule):
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        pad = (k - 1) // 2
+        self.k, self.stride, self.pad, self.inp_dim, self.out_dim = k, stride, pad, inp_dim, out_dim
+        self.conv = nn.Conv2d(inp_dim, out_dim, (k, k), padding=(pad, pad), stride=(stride, stride), bias=not with_bn)
+        self.bn = nn.BatchNorm2d(out_dim) if with_bn else nn.Sequential()
+
+    def _build(self, dtype):
+        w, b = fold_bn(self.conv.weight, self.bn, self.conv.bias)
+        if self.inp_dim == 3:
+            if self.k != 7 or self.stride != 2:
+                raise OkpError("3-channel input is supported for the 7x7/s2 stem only")
+            # one tap per kernel row: 8 pixels x 4 channels of the packed frame = 32 contiguous elements
+            taps = []
+            for r in range(7):
+                m = np.zeros((self.out_dim, 8, 4), dtype=np.float32)
+                m[:, :7, :3] = np.transpose(w[:, :, r, :], (0, 2, 1))
+                taps.append((0, r, 0, m.reshape(self.out_dim, 32)))
+            return ConvPlan(dtype, [32], [2], self.out_dim, taps, b, relu=True, alg_k=147)
+        return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
+
+    def forward(self, x):
+        plan = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
+        if self.inp_dim == 3:       # x is the packed frame tensor [N, H+6, Wp, 4]
+            if x.orig_hw is None:
+                raise OkpError("stem input must come from ops.pack_frames")
+            h, w = x.orig_hw
+            ho, wo = conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3)
+        else:
+            ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
+        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        plan([x], out, ho, wo)
+        return out
+
+
+class residual(_HipModule):
+    def __init__(self, inp_dim, out_dim, k=3, stride=1):
+        super().__init__()
+        p = (k - 1) // 2
+        self.k, self.stride, self.pad, self.inp_dim, self.out_dim = k, stride, p, inp_dim, out_dim
+        self.conv1 = nn.Conv2d(inp_dim, out_dim, (k, k), padding=(p, p), stride=(stride, stride), bias=False)
+        self.bn1 = nn.BatchNorm2d(out_dim)
+        self.conv2 = nn.Conv2d(out_dim, out_dim, (k, k), padding=(p, p), bias=False)
+        self.bn2 = nn.BatchNorm2d(out_dim)
+        self.projected = stride != 1 or inp_dim != out_dim
+        self.skip = nn.Sequential(nn.Conv2d(inp_dim, out_dim, (1, 1), stride=(stride, stride), bias=False),
+                                  nn.BatchNorm2d(out_dim)) if self.projected else nn.Sequential()
+
+    def _build(self, dtype):
+        w1, b1 = fold_bn(self.conv1.weight, self.bn1)
+        p1 = ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w1), b1, relu=True)
+        w2, b2 = fold_bn(self.conv2.weight, self.bn2)
+        taps = conv_taps(w2)
+        if self.projected:
+            # conv2 + projected skip + add + relu as ONE GEMM: the 1x1 skip is a tenth tap on a second source
+            ws, bs = fold_bn(self.skip[0].weight, self.skip[1])
+            taps = taps + [(1, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))]
+            p2 = ConvPlan(dtype, [self.out_dim, self.inp_dim], [1, self.stride], self.out_dim, taps, b2 + bs, relu=True)
+        else:
+            p2 = ConvPlan(dtype, [self.out_dim], [1], self.out_dim, taps, b2, relu=True)
+        return p1, p2
+
+    def forward(self, x):
+        p1, p2 = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
+        ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
+        t = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        p1([x], t, ho, wo)
+        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        if self.projected:
+            p2([t, x], out, ho, wo)
+        else:
+            p2([t], out, ho, wo, res=x)
+        return out
+
+
+class fire_module(_HipModule):
+    def __init__(self, inp_dim, out_dim, sr=2, stride=1):
+        super().__init__()
+        self.inp_dim, self.out_dim, self.mid, self.stride = inp_dim, out_dim, out_dim // sr, stride
+        self.conv1 = nn.Conv2d(inp_dim, out_dim // sr, kernel_size=1, stride=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_dim // sr)
+        self.conv_1x1 = nn.Conv2d(out_dim // sr, out_dim // 2, kernel_size=1, stride=stride, bias=False)
+        self.conv_3x3 = nn.Conv2d(out_dim // sr, out_dim // 2, kernel_size=3, padding=1, stride=stride,
+                                  groups=out_dim // sr, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_dim)
+        self.skip = (stride == 1 and inp_dim == out_dim)
+        if self.mid != out_dim // 2:
+            raise OkpError("fire_module: only sr=2 (depth multiplier 1) is implemented")
+
+    def _build(self, dtype, device):
+        half = self.out_dim // 2
+        w1, b1 = fold_bn(self.conv1.weight, self.bn1)
+        squeeze = ConvPlan(dtype, [self.inp_dim], [1], self.mid, conv_taps(w1), b1, relu=False)
+        # bn2 acts per channel on the concatenation: fold its two halves into the two branches
+        scale2 = _np(self.bn2.weight).astype(np.float64) / np.sqrt(_np(self.bn2.running_var).astype(np.float64) + self.bn2.eps)
+        shift2 = _np(self.bn2.bias).astype(np.float64) - _np(self.bn2.running_mean).astype(np.float64) * scale2
+        wa = (_np(self.conv_1x1.weight).astype(np.float64) * scale2[:half, None, None, None]).astype(np.float32)
+        expand = ConvPlan(dtype, [self.mid], [self.stride], half, conv_taps(wa), shift2[:half].astype(np.float32), relu=True)
+        wd = _np(self.conv_3x3.weight).astype(np.float64)[:, 0] * scale2[half:, None, None]      # [C,3,3]
+        wd = np.ascontiguousarray(np.transpose(wd, (1, 2, 0)).reshape(9, half)).astype(np.float32)   # tap-major [9][C]
+        return (squeeze, expand, torch.from_numpy(wd).to(device), torch.from_numpy(shift2[half:].astype(np.float32)).to(device))
+
+    def forward(self, x):
+        squeeze, expand, wd, bd = self._plan(("p", x.dtype), lambda: self._build(x.dtype, x.t.device))
+        half = self.out_dim // 2
+        s = Act.empty(x.n, x.h, x.w, self.mid, x.dtype, x.t.device)
+        squeeze([x], s, x.h, x.w)
+        ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
+        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        # concat is free: both branches write their channel window of the same NHWC tensor
+        expand([s], out.slice(0, half), ho, wo, res=x.slice(0, half) if self.skip else None)
+        ops.dwconv3x3(s, wd, bd, out.slice(half, half), self.stride, res=x.slice(half, half) if self.skip else None, relu=True)
+        return out
+
+
+def make_pool_layer(dim):
+    return nn.Sequential()
+
+
+class unpool_merge(_HipModule):
+    """ConvTranspose2d(dim, dim, 4, 2, 1) with bias, fused with the hourglass merge add.
+
+    Holds the transposed-conv parameters as `weight` / `bias` so that, assigned to `hg_module.up2`,
+    the state_dict keys are the reference's `...up2.weight` / `...up2.bias`
+    (CornerNet_Squeeze.py:35-36; merge: py_utils/utils.py:139-141, modules.py:64-65).
+    Lowered to four sub-pixel 2x2 convolutions (one per output parity), each writing its quarter
+    of the output with the `up1` tensor added in the epilogue.
+    """
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        ref = nn.ConvTranspose2d(dim, dim, kernel_size=4, stride=2, padding=1)
+        self.weight = ref.weight          # (Cin, Cout, 4, 4)
+        self.bias = ref.bias
+
+    def _build(self, dtype):
+        w = _np(self.weight)              # [ci, co, ky, kx]
+        b = _np(self.bias)
+        # output row 2i+a gathers input rows i+dy with kernel row ky:  a=0: (0,1), (-1,3);  a=1: (1,0), (0,2)
+        sel = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
+        plans = {}
+        for a in (0, 1):
+            for bb in (0, 1):
+                taps = [(0, dy, dx, np.ascontiguousarray(w[:, :, ky, kx].T)) for dy, ky in sel[a] for dx, kx in sel[bb]]
+                plans[(a, bb)] = ConvPlan(dtype, [self.dim], [1], self.dim, taps, b, relu=False)
+        return plans
+
+    def forward(self, low, up1):
+        plans = self._plan(("p", low.dtype), lambda: self._build(low.dtype))
+        if up1.h != 2 * low.h or up1.w != 2 * low.w:
+            raise OkpError("unpool_merge: up1 must be twice the size of low")
+        out = Act.empty(low.n, 2 * low.h, 2 * low.w, self.dim, low.dtype, low.t.device)
+        for (a, b), plan in plans.items():
+            plan([low], out, low.h, low.w, res=up1, out_step=2, oy=a, ox=b)
+        return out
+
+
+def make_unpool_layer(dim):
+    return unpool_merge(dim)
+
+
+class _FireSeq(nn.Sequential):
+    def forward(self, x):
+        for m in self:
+            x = m(x)
+        return x
+
+
+def make_layer(inp_dim, out_dim, modules):
+    return _FireSeq(*([fire_module(inp_dim, out_dim)] + [fire_module(out_dim, out_dim) for _ in range(1, modules)]))
+
+
+def make_layer_revr(inp_dim, out_dim, modules):
+    return _FireSeq(*([fire_module(inp_dim, inp_dim) for _ in range(modules - 1)] + [fire_module(inp_dim, out_dim)]))
+
+
+def make_hg_layer(inp_dim, out_dim, modules):
+    return _FireSeq(*([fire_module(inp_dim, out_dim, stride=2)] + [fire_module(out_dim, out_dim) for _ in range(1, modules)]))
+
+
+class hg_module(nn.Module):
+    def __init__(self, n, dims, modules):
+        super().__init__()
+        curr_dim, next_dim = dims[0], dims[1]
+        self.n = n
+        self.up1 = make_layer(curr_dim, curr_dim, modules[0])
+        self.max1 = make_pool_layer(curr_dim)
+        self.low1 = make_hg_layer(curr_dim, next_dim, modules[0])
+        self.low2 = hg_module(n - 1, dims[1:], modules[1:]) if n > 1 else make_layer(next_dim, next_dim, modules[1])
+        self.low3 = make_layer_revr(next_dim, curr_dim, modules[0])
+        self.up2 = make_unpool_layer(curr_dim)
+
+    def forward(self, x):
+        up1 = self.up1(x)
+        low3 = self.low3(self.low2(self.low1(x)))      # max1 is the identity (CornerNet_Squeeze.py:32-33)
+        return self.up2(low3, up1)
+
+
+class _MergeMod(nn.Sequential):
+    def __init__(self):
+        super().__init__(nn.Conv2d(256, 256, (1, 1), bias=False), nn.BatchNorm2d(256))
+
+
+class hg(_HipModule):
+    DIMS = [256, 256, 384, 384, 512]
+    MODULES = [2, 2, 2, 2, 4]
+
+    def __init__(self, stacks=2):
+        super().__init__()
+        self.pre = nn.Sequential(convolution(7, 3, 128, stride=2), residual(128, 256, stride=2), residual(256, 256, stride=2))
+        self.hgs = nn.ModuleList([hg_module(4, self.DIMS, self.MODULES) for _ in range(stacks)])
+        self.cnvs = nn.ModuleList([convolution(3, 256, 256) for _ in range(stacks)])
+        self.inters = nn.ModuleList([residual(256, 256) for _ in range(stacks - 1)])
+        self.inters_ = nn.ModuleList([_MergeMod() for _ in range(stacks - 1)])
+        self.cnvs_ = nn.ModuleList([_MergeMod() for _ in range(stacks - 1)])
+
+    def _build_merge(self, i, dtype):
+        # relu(inters_[i](inter) + cnvs_[i](cnv)): two 1x1+BN summed = one GEMM over two sources
+        wa, ba = fold_bn(self.inters_[i][0].weight, self.inters_[i][1])
+        wb, bb = fold_bn(self.cnvs_[i][0].weight, self.cnvs_[i][1])
+        taps = [(0, 0, 0, np.ascontiguousarray(wa[:, :, 0, 0])), (1, 0, 0, np.ascontiguousarray(wb[:, :, 0, 0]))]
+        return ConvPlan(dtype, [256, 256], [1, 1], 256, taps, ba + bb, relu=True)
+
+    def forward(self, x):
+        """x: packed frames (ops.pack_frames).  Returns [cnv0, cnv1] as NHWC activations."""
+        inter = x
+        for m in self.pre:
+            inter = m(inter)
+        cnvs = []
+        last = len(self.hgs) - 1
+        for i, (hg_, cnv_) in enumerate(zip(self.hgs, self.cnvs)):
+            cnv = cnv_(hg_(inter))
+            cnvs.append(cnv)
+            if i < last:
+                merge = self._plan(("m", i, inter.dtype), lambda: self._build_merge(i, inter.dtype))
+                merged = Act.empty(inter.n, inter.h, inter.w, 256, inter.dtype, inter.t.device)
+                merge([inter, cnv], merged, inter.h, inter.w)
+                inter = self.inters[i](merged)
+        return cnvs

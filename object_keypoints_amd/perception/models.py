@@ -1,0 +1,146 @@
+"""Drop-in for the reference's `perception/models.py` on the HIP path.
+
+Public surface (reference perception/models.py:13-85): prediction_module, HeatmapHead, DepthHead,
+CenterHead, nms, KeypointNet — same constructor arguments, same `state_dict` keys (906 entries for
+features=128), same output nesting `((hm1, hm2), (d1, d2), (c1, c2))` with NCHW fp32 tensors.
+The deployed wrapper of scripts/package_model.py:21-28 is `KeypointNet.deployed(frames)`.
+
+Device work is done by libokp_hip.so; inputs must be CUDA(HIP) tensors and the module must be in
+eval mode.  There is no CPU path here (the CPU restatement lives in oracle/ and is test-only).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..ops import Act, ConvPlan, OkpError
+from .backbone import convolution, fold_bn, hg, _HipModule, _np
+
+
+class prediction_module(nn.Sequential):
+    """1x1 256->F +BN+ReLU, 1x1 F->32 +BN+ReLU, 1x1 32->out +bias  (models.py:13-18)."""
+
+    def __init__(self, int_features, features_out):
+        super().__init__(convolution(1, 256, int_features, with_bn=True),
+                         convolution(1, int_features, 32, with_bn=True),
+                         nn.Conv2d(32, features_out, (1, 1), bias=True))
+        self.features_out = features_out
+
+    def forward(self, x, sigmoid=False):
+        """x: NHWC activation (ops.Act) -> NCHW fp32 tensor [N, out, H, W]."""
+        y = self[1](self[0](x))
+        w = self[2].weight.detach().reshape(self.features_out, 32).float().contiguous().to(y.t.device)
+        b = self[2].bias.detach().float().contiguous().to(y.t.device)
+        out = torch.empty((y.n, self.features_out, y.h, y.w), dtype=torch.float32, device=y.t.device)
+        act = ops.ACT_SIGMOID if sigmoid else ops.ACT_NONE
+        ops.head_out(y, [(0, act, out, o) for o in range(self.features_out)], w, b)
+        return out
+
+
+class _TwoStackHead(nn.Module):
+    def __init__(self, features, out_channels):
+        super().__init__()
+        self.output_head1 = prediction_module(features, out_channels)
+        self.output_head2 = prediction_module(features, out_channels)
+
+    def forward(self, x):
+        return self.output_head1(x[0]), self.output_head2(x[1])
+
+
+class HeatmapHead(_TwoStackHead):
+    def __init__(self, features, heatmaps):
+        super().__init__(features, heatmaps)
+        self.output_head1[-1].bias.data.fill_(0.01 / 0.99)
+        self.output_head2[-1].bias.data.fill_(0.01 / 0.99)
+
+
+class DepthHead(_TwoStackHead):
+    pass
+
+
+class CenterHead(_TwoStackHead):
+    def __init__(self, features, heatmaps):
+        self.outputs = heatmaps - 1
+        super().__init__(features, self.outputs * 2)
+
+    def forward(self, x):
+        out1, out2 = super().forward(x)
+        n, _, h, w = out2.shape
+        return out1.reshape(n, self.outputs, 2, h, w), out2.reshape(n, self.outputs, 2, h, w)
+
+
+def nms(x, size=5):
+    """x * (x == max_pool2d(x, size, stride 1, pad size//2))  (models.py:55-58)."""
+    return ops.nms_maxpool(x, size)
+
+
+class KeypointNet(_HipModule):
+    """CornerNet-Squeeze hourglass backbone + heat/depth/centre heads (models.py:60-85).
+
+    `compute_dtype` selects the activation/weight precision of the HIP path: torch.float32
+    (parity configuration) or torch.bfloat16 (MFMA throughput configuration, fp32 accumulate).
+    """
+
+    def __init__(self, output_size=None, features=128, heatmaps_out=2, dropout=0.1, compute_dtype=torch.float32):
+        super().__init__()
+        self.backbone = hg()
+        self.heatmap_head = HeatmapHead(features, heatmaps_out)
+        self.depth_head = DepthHead(features, heatmaps_out)
+        self.center_head = CenterHead(features, heatmaps_out)
+        self.dropout = nn.Dropout(p=dropout)       # identity in eval mode; kept for the interface
+        self.features = features
+        self.heatmaps_out = heatmaps_out
+        self.compute_dtype = compute_dtype
+
+    # ---- fused three-head plan for one stack ------------------------------------------------
+    def _build_heads(self, stack, dtype, device):
+        heads = [getattr(h, f"output_head{stack + 1}") for h in (self.heatmap_head, self.depth_head, self.center_head)]
+        F = self.features
+        w1, b1, w2, b2 = [], [], np.zeros((96, 3 * F), dtype=np.float32), []
+        for i, pm in enumerate(heads):
+            w, b = fold_bn(pm[0].conv.weight, pm[0].bn)
+            w1.append(w[:, :, 0, 0]); b1.append(b)
+            w, b = fold_bn(pm[1].conv.weight, pm[1].bn)
+            w2[32 * i:32 * i + 32, F * i:F * i + F] = w[:, :, 0, 0]      # block diagonal: heads do not mix
+            b2.append(b)
+        l1 = ConvPlan(dtype, [256], [1], 3 * F, [(0, 0, 0, np.concatenate(w1, 0))], np.concatenate(b1), relu=True)
+        l2 = ConvPlan(dtype, [3 * F], [1], 96, [(0, 0, 0, w2)], np.concatenate(b2), relu=True, alg_k=F)
+        w3 = np.concatenate([_np(pm[2].weight).reshape(-1, 32) for pm in heads], 0)
+        b3 = np.concatenate([_np(pm[2].bias) for pm in heads], 0)
+        return l1, l2, torch.from_numpy(w3).to(device), torch.from_numpy(b3).to(device)
+
+    def _run_heads(self, stack, cnv, sigmoid):
+        l1, l2, w3, b3 = self._plan(("heads", stack, cnv.dtype), lambda: self._build_heads(stack, cnv.dtype, cnv.t.device))
+        K = self.heatmaps_out
+        n, h, w = cnv.n, cnv.h, cnv.w
+        a1 = Act.empty(n, h, w, 3 * self.features, cnv.dtype, cnv.t.device)
+        l1([cnv], a1, h, w)
+        a2 = Act.empty(n, h, w, 96, cnv.dtype, cnv.t.device)
+        l2([a1], a2, h, w)
+        heat = torch.empty((n, K, h, w), dtype=torch.float32, device=cnv.t.device)
+        depth = torch.empty((n, K, h, w), dtype=torch.float32, device=cnv.t.device)
+        centers = torch.empty((n, 2 * (K - 1), h, w), dtype=torch.float32, device=cnv.t.device)
+        outs = [(0, ops.ACT_SIGMOID if sigmoid else ops.ACT_NONE, heat, k) for k in range(K)]
+        outs += [(32, ops.ACT_NONE, depth, k) for k in range(K)]
+        outs += [(64, ops.ACT_NONE, centers, k) for k in range(2 * (K - 1))]
+        ops.head_out(a2, outs, w3, b3)
+        return heat, depth, centers.reshape(n, K - 1, 2, h, w)
+
+    def _features(self, x):
+        ops.require_cuda(x, "frames")
+        if self.training:
+            raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
+        return self.backbone(ops.pack_frames(x.float(), self.compute_dtype))
+
+    def forward(self, x):
+        """frames [N,3,H,W] fp32 -> ((hm1,hm2),(d1,d2),(c1,c2)), raw logits for the heat maps."""
+        feats = self._features(x)
+        h1, d1, c1 = self._run_heads(0, feats[0], sigmoid=False)
+        h2, d2, c2 = self._run_heads(1, feats[1], sigmoid=False)
+        return (h1, h2), (d1, d2), (c1, c2)
+
+    def deployed(self, x):
+        """What the packaged model returns (scripts/package_model.py:26-28):
+        sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed."""
+        feats = self._features(x)
+        return self._run_heads(1, feats[1], sigmoid=True)

@@ -1,0 +1,126 @@
+"""HIP implicit-GEMM convolution vs a plain PyTorch fp32 reference of the same op (CPU conv2d),
+through the C ABI.  Covers all three tile shapes, both dtypes, partial tiles, stride 2,
+two-source plans (fused projected skip), residual epilogue and sub-pixel output placement."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _tol(dtype, ref):
+    scale = float(ref.abs().max())
+    return (2e-4 + 1e-5 * scale) if dtype == torch.float32 else 0.02 * scale + 0.02
+
+
+def _rand(shape, seed):
+    from object_keypoints_amd import synth
+    return torch.from_numpy(synth.normal_like(f"convtest{seed}", shape, seed))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
+    (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
+    (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
+    (1, 1, 192, 96, 2, 9, 7),       # 1x1, cout not a multiple of 64
+    (1, 2, 16, 8, 1, 8, 8),         # tiny channel counts (partial K slice)
+    (3, 1, 8, 16, 1, 5, 5),         # one partial slice per tap
+])
+def test_conv_matches_torch(dtype, tile, k, stride, cin, cout, n, h, w):
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps, conv_out_size
+    dev = _dev()
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2) * (1.0 / np.sqrt(cin * k * k))
+    b = _rand((cout,), 3) * 0.1
+    pad = (k - 1) // 2
+    if dtype == torch.bfloat16:      # compare against the same rounded operands
+        x = x.bfloat16().float(); wt = wt.bfloat16().float()
+    ref = F.relu(F.conv2d(x, wt, b, stride=stride, padding=pad))
+    plan = ops.ConvPlan(dtype, [cin], [stride], cout, conv_taps(wt.numpy()), b.numpy(), relu=True)
+    xa = ops.Act.from_nchw(x.to(dev), dtype)
+    ho, wo = conv_out_size(h, k, stride, pad), conv_out_size(w, k, stride, pad)
+    out = ops.Act.empty(n, ho, wo, cout, dtype, dev)
+    plan([xa], out, ho, wo, tile=tile)
+    got = out.to_nchw().cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(dtype, ref), f"max err {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_source_residual_block(dtype):
+    """relu(conv3x3(t) + conv1x1_s2(x) + bias): the fused conv2 + projected skip of `residual`."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = _dev()
+    n, c0, c1, cout, h, w = 2, 32, 16, 64, 10, 12
+    t = _rand((n, c0, h, w), 4); x = _rand((n, c1, 2 * h, 2 * w), 5)
+    w2 = _rand((cout, c0, 3, 3), 6) / np.sqrt(c0 * 9); ws = _rand((cout, c1, 1, 1), 7) / np.sqrt(c1)
+    b = _rand((cout,), 8) * 0.1
+    if dtype == torch.bfloat16:
+        t, x, w2, ws = [v.bfloat16().float() for v in (t, x, w2, ws)]
+    ref = F.relu(F.conv2d(t, w2, b, padding=1) + F.conv2d(x, ws, stride=2))
+    taps = conv_taps(w2.numpy()) + [(1, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))]
+    plan = ops.ConvPlan(dtype, [c0, c1], [1, 2], cout, taps, b.numpy(), relu=True)
+    out = ops.Act.empty(n, h, w, cout, dtype, dev)
+    plan([ops.Act.from_nchw(t.to(dev), dtype), ops.Act.from_nchw(x.to(dev), dtype)], out, h, w)
+    got = out.to_nchw().cpu()
+    assert float((got - ref).abs().max()) <= _tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_epilogue_and_channel_window(dtype):
+    """1x1 conv writing channels [8,24) of a 32-channel tensor with a residual read from a window."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = _dev()
+    n, cin, cout, h, w = 2, 24, 16, 6, 7
+    x = _rand((n, cin, h, w), 9); r = _rand((n, 32, h, w), 10)
+    wt = _rand((cout, cin, 1, 1), 11) / np.sqrt(cin)
+    if dtype == torch.bfloat16:
+        x, r, wt = [v.bfloat16().float() for v in (x, r, wt)]
+    ref = F.relu(F.conv2d(x, wt) + r[:, 8:24])
+    plan = ops.ConvPlan(dtype, [cin], [1], cout, conv_taps(wt.numpy()), None, relu=True)
+    big = ops.Act(torch.full((n, h, w, 32), -7.0, dtype=dtype, device=dev))
+    ra = ops.Act.from_nchw(r.to(dev), dtype)
+    plan([ops.Act.from_nchw(x.to(dev), dtype)], big.slice(8, 16), h, w, res=ra.slice(8, 16))
+    full = big.t.float().cpu()
+    got = full[..., 8:24].permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= _tol(dtype, ref)
+    assert bool((full[..., :8] == -7.0).all()) and bool((full[..., 24:] == -7.0).all())   # neighbours untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_as_subpixel_convs(dtype):
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import unpool_merge
+    dev = _dev()
+    n, c, h, w = 2, 16, 5, 7
+    m = unpool_merge(c).eval()
+    with torch.no_grad():
+        m.weight.copy_(_rand((c, c, 4, 4), 12) / np.sqrt(4 * c)); m.bias.copy_(_rand((c,), 13) * 0.1)
+    low = _rand((n, c, h, w), 14); up1 = _rand((n, c, 2 * h, 2 * w), 15)
+    if dtype == torch.bfloat16:
+        low, up1 = low.bfloat16().float(), up1.bfloat16().float()
+        wq = m.weight.detach().bfloat16().float()
+    else:
+        wq = m.weight.detach()
+    ref = up1 + F.conv_transpose2d(low, wq, m.bias.detach(), stride=2, padding=1)
+    got = m(ops.Act.from_nchw(low.to(dev), dtype), ops.Act.from_nchw(up1.to(dev), dtype)).to_nchw().cpu()
+    assert float((got - ref).abs().max()) <= _tol(dtype, ref)
+
+
+def test_bad_arguments_are_reported():
+    from object_keypoints_amd import ops
+    with pytest.raises(ops.OkpError):
+        ops.ConvPlan(torch.float32, [6], [1], 8, [(0, 0, 0, np.zeros((8, 6), np.float32))])   # cin not 16-byte multiple
+    with pytest.raises(ops.OkpError):
+        ops.Act(torch.zeros(1, 2, 2, 8))                                                        # CPU tensor: no fallback
