@@ -146,12 +146,12 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
 }
 
 namespace {
-int check_view(const char* name, const okp_tensor& t, int esz, bool required) {
+int check_view(const char* name, const okp_tensor& t, int esz, bool required, int align = 16) {
   if (!t.data) {
     if (required) { okp_set_error("okp_conv_forward: %s is null", name); return OKP_EINVAL; }
     return OKP_OK;
   }
-  if ((t.pix_stride * esz) % 16 || ((uintptr_t)t.data) % 16) { okp_set_error("okp_conv_forward: %s is not 16-byte aligned (pix_stride %d)", name, t.pix_stride); return OKP_EINVAL; }
+  if ((t.pix_stride * esz) % align || ((uintptr_t)t.data) % align) { okp_set_error("okp_conv_forward: %s is not %d-byte aligned (pix_stride %d)", name, align, t.pix_stride); return OKP_EINVAL; }
   if (t.bytes <= 0 || t.bytes >= 0x7FFF0000ll) { okp_set_error("okp_conv_forward: %s spans %lld bytes; views must be < 2 GiB (sub-batch the frames)", name, (long long)t.bytes); return OKP_EINVAL; }
   if (t.h < 1 || t.w < 1) { okp_set_error("okp_conv_forward: %s has empty spatial size", name); return OKP_EINVAL; }
   return OKP_OK;
@@ -164,7 +164,9 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   if (a->n < 1 || a->ho < 1 || a->wo < 1) { okp_set_error("okp_conv_forward: empty problem n=%d ho=%d wo=%d", a->n, a->ho, a->wo); return OKP_EINVAL; }
   if ((long)a->n * a->ho * a->wo >= 0x7FFFFFFFl) { okp_set_error("okp_conv_forward: too many output pixels"); return OKP_EINVAL; }
   for (int s = 0; s < plan->n_src; ++s) {
-    if (int e = check_view(s ? "src[1]" : "src[0]", a->src[s], esz, true)) return e;
+    // sources are read with dword-aligned 16-byte buffer loads (the packed stem frame has 8-byte bf16 pixels);
+    // out/res rows are written/read as aligned 16-byte vectors
+    if (int e = check_view(s ? "src[1]" : "src[0]", a->src[s], esz, true, 8)) return e;
     // cin may span several consecutive pixels of a row (the stem reads 8 px x 4 ch per tap)
     if (a->src[s].pix_stride < plan->cin[s] && plan->cin[s] % a->src[s].pix_stride != 0) {
       okp_set_error("okp_conv_forward: src[%d] pix_stride %d incompatible with cin %d", s, a->src[s].pix_stride, plan->cin[s]); return OKP_EINVAL;
