@@ -175,6 +175,14 @@ int okp_unproject_depth(const okp_camera* cam, const float* xy_dev, const int32_
                         const float* depth_dev, int32_t h, int32_t w, int32_t max_x, int32_t max_y,
                         double* out_dev, void* stream);
 
+/* Device-resident form of the same lifting for a whole batch: consumes okp_peak_nms outputs in place
+ * (no host round trip between NMS and 3D).  For map i, peak j < min(count[i], cap):
+ * out[i][j] = (X, Y, Z, confidence) with (X,Y,Z) as in okp_unproject_depth using depth map i;
+ * the remaining slots are filled with NaN.  out: [n_maps][cap][4] fp64. */
+int okp_lift_peaks(const okp_camera* cam, const int32_t* count_dev, const float* xyc_dev, int32_t n_maps, int32_t cap,
+                   const float* depth_dev, int32_t h, int32_t w, int32_t max_x, int32_t max_y,
+                   double* out_dev, void* stream);
+
 /* Replaces StereoCamera.triangulate (utils/camera_utils.py:92-110) and the labelling tool's
  * 2-view DLT (scripts/label.py:285-305): undistort both views (P=K) -> optional Hartley-Sturm
  * correction against F (cv2.correctMatches) -> DLT null vector of the 4x4 system built from

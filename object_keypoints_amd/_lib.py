@@ -61,6 +61,7 @@ SIGNATURES = [
     ("okp_peak_nms", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("okp_nms_maxpool", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_unproject_depth", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    ("okp_lift_peaks", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_triangulate_dlt", c_int, [POINTER(okp_camera), POINTER(okp_camera), POINTER(c_double), POINTER(c_double), c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_fisheye_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),
 ]

@@ -67,6 +67,32 @@ __global__ void okp_unproject_kernel(okp_camera cam, const float* __restrict__ x
   out[3 * i + 2] = z;
 }
 
+__global__ void okp_lift_peaks_kernel(okp_camera cam, const int* __restrict__ count, const float* __restrict__ xyc, int n_maps,
+                                      int cap, const float* __restrict__ depth, int H, int W, int max_x, int max_y,
+                                      double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_maps * cap) return;
+  const int map = i / cap, j = i - map * cap;
+  double* o = out + (size_t)i * 4;
+  if (j >= count[map]) {
+    const double nan = __builtin_nan("");
+    o[0] = nan; o[1] = nan; o[2] = nan; o[3] = nan;
+    return;
+  }
+  const float* pk = xyc + (size_t)i * 3;
+  double xu, yu;
+  fisheye_undistort(cam, (double)pk[0], (double)pk[1], xu, yu);
+  const float xf = (float)xu, yf = (float)yu;
+  int xi = (int)rintf(xf), yi = (int)rintf(yf);
+  xi = min(max(xi, 0), max_x);
+  yi = min(max(yi, 0), max_y);
+  const double z = (double)depth[((size_t)map * H + yi) * W + xi];
+  o[0] = ((double)xf - cam.cx) / cam.fx * z;
+  o[1] = ((double)yf - cam.cy) / cam.fy * z;
+  o[2] = z;
+  o[3] = (double)pk[2];
+}
+
 // One-sided (Hestenes) Jacobi on the columns of a 4x4 matrix; returns the column of V that
 // belongs to the smallest singular value, i.e. argmin |A v| over unit v.
 __device__ void null_vector4(double (&A)[4][4], double (&v)[4]) {
@@ -307,6 +333,19 @@ extern "C" int okp_unproject_depth(const okp_camera* cam, const float* xy, const
   }
   hipLaunchKernelGGL(okp_unproject_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cam, xy, map_id, m, depth, h, w, max_x, max_y, out);
   return okp_check_hip(hipGetLastError(), "okp_unproject_depth launch");
+}
+
+extern "C" int okp_lift_peaks(const okp_camera* cam, const int32_t* count, const float* xyc, int32_t n_maps, int32_t cap,
+                              const float* depth, int32_t h, int32_t w, int32_t max_x, int32_t max_y, double* out, void* stream) {
+  if (!cam || !count || !xyc || !depth || !out) { okp_set_error("okp_lift_peaks: null argument"); return OKP_EINVAL; }
+  if (n_maps <= 0 || cap <= 0) return OKP_OK;
+  if (max_x < 0 || max_x >= w || max_y < 0 || max_y >= h) {
+    okp_set_error("okp_lift_peaks: clip box (%d,%d) outside the %dx%d depth map", max_x, max_y, h, w);
+    return OKP_EINVAL;
+  }
+  const int total = n_maps * cap;
+  hipLaunchKernelGGL(okp_lift_peaks_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *cam, count, xyc, n_maps, cap, depth, h, w, max_x, max_y, out);
+  return okp_check_hip(hipGetLastError(), "okp_lift_peaks launch");
 }
 
 extern "C" int okp_triangulate_dlt(const okp_camera* left, const okp_camera* right, const double* T_RL, const double* F,

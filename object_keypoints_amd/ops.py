@@ -112,8 +112,11 @@ class ConvPlan:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
-            _lib._lib.okp_conv_destroy(h)
+        try:
+            if h and _lib is not None and _lib._lib is not None:
+                _lib._lib.okp_conv_destroy(h)
+        except Exception:       # interpreter shutdown: the process is going away with its HBM
+            pass
 
     def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0):
         a = _lib.okp_conv_args()
@@ -243,6 +246,19 @@ def unproject_depth(cam, xy, map_id, depth, max_x, max_y):
     out = torch.empty((xy.shape[0], 3), dtype=torch.float64, device=xy.device)
     _lib.check(_lib.lib().okp_unproject_depth(ctypes.byref(cam), xy.data_ptr(), map_id.data_ptr(), xy.shape[0], depth.data_ptr(),
                                               depth.shape[1], depth.shape[2], max_x, max_y, out.data_ptr(), stream_handle()), "okp_unproject_depth")
+    return out
+
+
+def lift_peaks(cam, count, xyc, depth, max_x, max_y):
+    """count [N,K] int32, xyc [N,K,cap,3] fp32, depth [N,K,H,W] fp32 (device) -> [N,K,cap,4] fp64 (X,Y,Z,conf)."""
+    require_cuda(xyc, "xyc")
+    n, k, cap, _ = xyc.shape
+    depth = depth.contiguous()
+    if depth.dtype != torch.float32 or depth.shape[:2] != (n, k):
+        raise OkpError("depth must be float32 [N,K,H,W] matching the peak tensors")
+    out = torch.empty((n, k, cap, 4), dtype=torch.float64, device=xyc.device)
+    _lib.check(_lib.lib().okp_lift_peaks(ctypes.byref(cam), count.data_ptr(), xyc.data_ptr(), n * k, cap, depth.data_ptr(),
+                                         depth.shape[2], depth.shape[3], max_x, max_y, out.data_ptr(), stream_handle()), "okp_lift_peaks")
     return out
 
 

@@ -1,0 +1,295 @@
+"""Drop-in for the reference's perception/pipeline.py on the HIP path.
+
+Same classes, constructor / __call__ signatures and return nesting as the reference
+(perception/pipeline.py:13-209): InferenceComponent, KeypointExtractionComponent, ObjectExtraction,
+DetectionToPoint, ObjectKeypointPipeline, LearnedKeypointTrackingPipeline, plus the
+TriangulationComponent the reference's test expects (test/test_pipeline.py:171-177).
+
+Device work (network, peak extraction, undistort + depth lifting, DLT) goes through libokp_hip.so;
+the object-grouping glue (ObjectExtraction) is host logic as in the reference.  BatchedKeypointPipeline
+is the data-parallel form of the same path: a whole batch of frames stays on the device from the
+packed input to the per-peak 3D points (one D2H copy at the end).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..ops import OkpError
+from . import models
+from .utils import camera_utils  # noqa: F401  (re-exported like the reference module does)
+
+DEFAULT_PEAK_CAPACITY = 64
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise OkpError("the keypoint pipeline runs on the HIP device; no GPU is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
+    """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
+    TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet."""
+    device = device or _device()
+    if isinstance(model, models.KeypointNet):
+        return model.to(device).eval()
+    if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
+        try:
+            sd = torch.jit.load(model, map_location="cpu").state_dict()
+        except Exception:
+            sd = torch.load(model, map_location="cpu")
+            if isinstance(sd, dict) and "state_dict" in sd:
+                sd = sd["state_dict"]
+    else:
+        sd = model
+    if not isinstance(sd, dict):
+        raise OkpError("cannot interpret model argument")
+    clean = {}
+    for k, v in sd.items():
+        for prefix in ("model.model.", "model."):          # TorchScript wrapper / Lightning module prefixes
+            if k.startswith(prefix):
+                k = k[len(prefix):]
+                break
+        clean[k] = v
+    heat_out = clean["heatmap_head.output_head2.2.weight"].shape[0]
+    features = clean["heatmap_head.output_head2.0.conv.weight"].shape[0]
+    net = models.KeypointNet(features=features, heatmaps_out=heat_out, compute_dtype=compute_dtype)
+    net.load_state_dict(clean)
+    return net.to(device).eval()
+
+
+class InferenceComponent:
+    name = "inference"
+
+    def __init__(self, model, cuda=True, compute_dtype=torch.float32):
+        if not cuda:
+            raise OkpError("InferenceComponent(cuda=False): this build has no CPU path (the CPU restatement is oracle/, test-only)")
+        self.cuda = cuda
+        self.model = load_keypoint_net(model, compute_dtype)
+
+    def __call__(self, frames):
+        frames = frames.to(_device())
+        with torch.no_grad():
+            heatmaps, depth, centers = [t.cpu() for t in self.model.deployed(frames)]
+        return heatmaps, depth, centers
+
+
+class KeypointExtractionComponent:
+    name = "keypoints"
+    PROBABILITY_CUTOFF = 0.1
+
+    def __init__(self, keypoint_config, prediction_size, bandwidth=1.0, capacity=DEFAULT_PEAK_CAPACITY):
+        self.keypoint_config = [1] + keypoint_config['keypoint_config']     # centre map first
+        self.n_keypoints = sum(self.keypoint_config)
+        self.prediction_size = prediction_size
+        self.capacity = capacity
+
+    def extract_device(self, frames):
+        """frames N x K x H x W (device or host) -> device tensors (count, yx, xyc)."""
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames.astype(np.float32)))
+        frames = frames.to(_device(), torch.float32)
+        assert frames.shape[1] == len(self.keypoint_config)
+        return ops.peak_nms(frames, cap=self.capacity)
+
+    def __call__(self, frames):
+        count, _, xyc = self.extract_device(frames)
+        count, xyc = count.cpu().numpy(), xyc.cpu().numpy()
+        if int(count.max(initial=0)) > self.capacity:
+            raise OkpError(f"a heat map has {int(count.max())} peaks, above the capacity {self.capacity}; "
+                           "raise `capacity` (the reference has no cap)")
+        keypoints, confidence = [], []
+        for n in range(count.shape[0]):
+            kp, cf = [], []
+            for k in range(count.shape[1]):
+                c = int(count[n, k])
+                kp.append([xyc[n, k, j, :2].copy() for j in range(c)])          # (x, y) float32
+                cf.append([xyc[n, k, j, 2] for j in range(c)])
+            keypoints.append(kp)
+            confidence.append(cf)
+        return keypoints, confidence
+
+
+class ObjectExtraction:
+    """Centre-vector voting (pipeline.py:93-153): every non-centre peak votes for the object whose centre is
+    nearest to `pixel centre + predicted offset`, votes further than 20 px are dropped, and surplus detections
+    of a type are reduced to the configured count (arg-max confidence, or k-means for multi-instance types)."""
+
+    def __init__(self, keypoint_config, prediction_size):
+        self.keypoint_config = keypoint_config['keypoint_config']
+        self.prediction_size = prediction_size
+        self.max = np.array(self.prediction_size[::-1], dtype=np.int32) - 1
+        self.min = np.zeros(2, dtype=np.int32)
+        h, w = self.prediction_size
+        self.image_indices = np.stack(np.meshgrid(np.arange(w) + 0.5, np.arange(h) + 0.5, indexing="xy"))   # (2,h,w) = (x,y)
+
+    def __call__(self, keypoints, confidence, centers):
+        if len(keypoints[0]) == 0:
+            return []
+        p_centers = self.image_indices + centers
+        center_points = np.stack(keypoints[0])
+        n_types = len(keypoints) - 1
+        objects = [{'center': c, 'heatmap_points': [[] for _ in range(n_types)], 'p_centers': [],
+                    'confidence': [[] for _ in range(n_types)]} for c in center_points]
+        for i, points in enumerate(keypoints[1:]):
+            for j, point in enumerate(points):
+                xy = np.clip(point.round().astype(np.int32), self.min, self.max)
+                predicted_center = p_centers[i, :, xy[1], xy[0]]
+                distances = np.linalg.norm(center_points - predicted_center[None], 2, axis=1)
+                if distances.min() > 20.0:
+                    continue
+                obj = objects[distances.argmin(axis=0)]
+                obj['p_centers'].append(predicted_center)
+                obj['heatmap_points'][i].append(point)
+                obj['confidence'][i].append(confidence[i + 1][j])
+        for obj in objects:
+            for i in range(n_types):
+                if len(obj['heatmap_points'][i]) == 0:
+                    obj['heatmap_points'][i] = np.array([])
+                    continue
+                points = np.stack(obj['heatmap_points'][i])
+                confidences = np.stack(obj['confidence'][i])
+                if points.shape[0] > self.keypoint_config[i]:
+                    if self.keypoint_config[i] == 1:
+                        points = points[confidences.argmax(axis=0)][None]
+                    else:
+                        from sklearn import cluster
+                        clusterer = cluster.KMeans(init='random', n_clusters=self.keypoint_config[i], n_init=10)
+                        points = clusterer.fit(points).cluster_centers_
+                obj['heatmap_points'][i] = points
+        return objects
+
+
+class DetectionToPoint:
+    def reset(self, camera):
+        self.camera = camera
+        self.min_index = np.zeros(2, dtype=int)
+        self.max_index = camera.image_size.astype(int) - 1
+
+    def __call__(self, xy, p_depth):
+        """xy (n,2) pixels + one depth map (H,W) -> (n,3) float64 camera-frame points (device kernel)."""
+        if xy.shape[0] == 0:
+            return None
+        dev = _device()
+        depth = torch.from_numpy(np.ascontiguousarray(p_depth, dtype=np.float32))[None].to(dev)
+        pts = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32)).to(dev)
+        ids = torch.zeros(xy.shape[0], dtype=torch.int32, device=dev)
+        # the reference clips x against image_size[0]-1 and y against image_size[1]-1 (pipeline.py:161-169)
+        out = ops.unproject_depth(self.camera.okp(), pts, ids, depth, int(self.max_index[0]), int(self.max_index[1]))
+        return out.cpu().numpy()
+
+
+class ObjectKeypointPipeline:
+    def __init__(self, prediction_size, points_3d, keypoint_config):
+        self.keypoint_extraction = KeypointExtractionComponent(keypoint_config, prediction_size)
+        self.object_extraction = ObjectExtraction(keypoint_config, prediction_size)
+        self.detection_to_point = DetectionToPoint()
+
+    def reset(self, camera):
+        self.detection_to_point.reset(camera)
+
+    def __call__(self, heatmap, p_depth, p_centers):
+        assert heatmap.shape[0] == 1, "One at the time, please."
+        heatmap = heatmap.numpy() if isinstance(heatmap, torch.Tensor) else np.asarray(heatmap)
+        p_centers = (p_centers[0].numpy() if isinstance(p_centers, torch.Tensor) else np.asarray(p_centers)[0])
+        p_depth = (p_depth[0].numpy() if isinstance(p_depth, torch.Tensor) else np.asarray(p_depth)[0])
+        points, confidence = self.keypoint_extraction(heatmap)
+        detected_objects = self.object_extraction(points[0], confidence[0], p_centers)
+        objects = []
+        for obj in detected_objects:
+            world_points = [self.detection_to_point(obj['center'][None], p_depth[0])]
+            for i in range(len(obj['heatmap_points'])):
+                world_points.append(self.detection_to_point(obj['heatmap_points'][i], p_depth[1 + i]))
+            objects.append({'p_centers': obj['p_centers'],
+                            'keypoints': [obj['center'][None]] + obj['heatmap_points'],
+                            'p_C': world_points})
+        return objects
+
+
+class LearnedKeypointTrackingPipeline(ObjectKeypointPipeline):
+    def __init__(self, model, cuda=True, *args, **kwargs):
+        compute_dtype = kwargs.pop("compute_dtype", torch.float32)
+        super().__init__(*args, **kwargs)
+        self.inference = InferenceComponent(model, cuda, compute_dtype=compute_dtype)
+
+    def __call__(self, frame):
+        heatmap, depth, centers = self.inference(frame)
+        return super().__call__(heatmap, depth, centers), heatmap
+
+
+class TriangulationComponent:
+    """reset(stereo_camera); __call__(left (n,2), right (n,2)) -> (n,3) in the left camera frame."""
+
+    def reset(self, stereo_camera):
+        self.stereo_camera = stereo_camera
+
+    def __call__(self, left_keypoints, right_keypoints):
+        return self.stereo_camera.triangulate(left_keypoints, right_keypoints)
+
+
+class BatchedKeypointPipeline:
+    """Frames -> heat/depth/centre maps -> peaks -> per-peak 3D points for a whole batch, device-resident.
+
+    forward_device(frames) returns device tensors
+        heat [N,K,H,W], depth [N,K,H,W], centers [N,K-1,2,H,W],
+        count [N,K] int32, xyc [N,K,cap,3] fp32 (x, y, confidence), points [N,K,cap,4] fp64 (X, Y, Z, confidence)
+    `points` is the fixed-capacity payload that is all-gathered across ranks (object_keypoints_amd.distributed).
+    objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points.
+    """
+
+    def __init__(self, net, keypoint_config, camera, prediction_size=(64, 64), capacity=DEFAULT_PEAK_CAPACITY):
+        self.net = net
+        self.config = keypoint_config
+        self.capacity = capacity
+        self.prediction_size = list(prediction_size)
+        self.object_extraction = ObjectExtraction(keypoint_config, self.prediction_size)
+        self.camera = camera
+        self.cam = camera.okp()
+        self.max_index = camera.image_size.astype(int) - 1
+
+    def forward_device(self, frames):
+        heat, depth, centers = self.net.deployed(frames)
+        return self.postprocess_device(heat, depth, centers)
+
+    def postprocess_device(self, heat, depth, centers):
+        """Peaks + per-peak 3D points from (post-sigmoid) heat, depth and centre maps on the device."""
+        count, yx, xyc = ops.peak_nms(heat, cap=self.capacity)
+        points = ops.lift_peaks(self.cam, count, xyc, depth, int(self.max_index[0]), int(self.max_index[1]))
+        return {"heat": heat, "depth": depth, "centers": centers, "count": count, "yx": yx, "xyc": xyc, "points": points}
+
+    def objects(self, out, n):
+        """Host-side grouping of frame n of a forward_device() result (one D2H copy per tensor)."""
+        count = out["count"][n].cpu().numpy()
+        xyc = out["xyc"][n].cpu().numpy()
+        pts3 = out["points"][n].cpu().numpy()
+        centers = out["centers"][n].cpu().numpy()
+        if int(count.max(initial=0)) > self.capacity:
+            raise OkpError("peak capacity exceeded")
+        keypoints = [[xyc[k, j, :2].copy() for j in range(int(count[k]))] for k in range(count.shape[0])]
+        confidence = [[xyc[k, j, 2] for j in range(int(count[k]))] for k in range(count.shape[0])]
+        lifted = {}
+        for k in range(count.shape[0]):
+            for j in range(int(count[k])):
+                lifted[(k, xyc[k, j, 0].tobytes(), xyc[k, j, 1].tobytes())] = pts3[k, j, :3]
+        detected = self.object_extraction(keypoints, confidence, centers)
+        d2p = None
+        objects = []
+        for obj in detected:
+            groups = [obj['center'][None]] + obj['heatmap_points']
+            world = []
+            for k, pts in enumerate(groups):
+                if pts.shape[0] == 0:
+                    world.append(None)
+                    continue
+                rows = []
+                for p in pts:
+                    key = (k, np.float32(p[0]).tobytes(), np.float32(p[1]).tobytes())
+                    if key in lifted:
+                        rows.append(lifted[key])
+                    else:                      # k-means centre: not a detected peak, lift it on demand
+                        if d2p is None:
+                            d2p = DetectionToPoint(); d2p.reset(self.camera)
+                        rows.append(d2p(np.asarray(p, dtype=np.float32)[None], out["depth"][n, k].cpu().numpy())[0])
+                world.append(np.stack(rows))
+            objects.append({'p_centers': obj['p_centers'], 'keypoints': groups, 'p_C': world})
+        return objects

@@ -1,0 +1,133 @@
+"""Drop-in for the hot-path part of the reference's perception/utils/camera_utils.py (:7-110,119-189).
+
+Same classes and method signatures (PinholeCamera, FisheyeCamera, StereoCamera, camera_matrix,
+projection_matrix, load_calibration_params, scale_camera_matrix, fundamental_matrix); the OpenCV
+calls of the reference (cv2.fisheye.undistortPoints, cv2.correctMatches, cv2.triangulatePoints) are
+replaced by fp64 HIP kernels behind the C ABI (okp_fisheye_undistort, okp_triangulate_dlt).
+NumPy arrays in, NumPy arrays out, as in the reference; there is no CPU implementation here.
+`project` (used by labelling / dataset code, not by inference) is not part of the hot path and is
+not provided.
+"""
+import numpy as np
+import torch
+import yaml
+
+from ... import ops
+from . import linalg
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise ops.OkpError("camera geometry runs on the HIP device; no GPU is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class PinholeCamera:
+    def __init__(self, K, D, image_size):
+        self.K = K
+        self.Kinv = np.linalg.inv(K)
+        self.D = D
+        self.image_size = np.array(image_size)     # height, width
+        assert np.abs(K[0, 2] * 2.0 - image_size[1]) < 0.05 * image_size[1]
+
+    def scale(self, scale):
+        K = scale_camera_matrix(self.K, np.ones(2) * scale)
+        return FisheyeCamera(K, self.D, self.image_size * scale)
+
+    def cut(self, offset):
+        K = self.K.copy()
+        K[0, 2] = self.K[0, 2] - offset[0]
+        K[1, 2] = self.K[1, 2] - offset[1]
+        return FisheyeCamera(K, self.D, self.image_size - 2.0 * offset[::-1])
+
+    def unproject(self, xys, zs):
+        xs = np.concatenate([xys, np.ones((xys.shape[0], 1))], axis=1)
+        return (self.Kinv @ xs[:, :, None])[:, :, 0] * zs[:, None]
+
+    def in_frame(self, x):
+        under = (x <= 0.0).any(axis=1)
+        over = (x >= self.image_size).any(axis=1)
+        return np.bitwise_or(under, over) == False  # noqa: E712
+
+    def okp(self):
+        return ops.make_camera(self.K, self.D)
+
+
+class FisheyeCamera(PinholeCamera):
+    def undistort(self, xy):
+        """xy: N x 2 image points -> N x 2 undistorted points, in the dtype given (as cv2 does)."""
+        xy = np.asarray(xy)
+        out = ops.fisheye_undistort(self.okp(), torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32)).to(_device()))
+        out = out.cpu().numpy()
+        return out.astype(xy.dtype) if xy.dtype in (np.float32, np.float64) else out
+
+
+class StereoCamera:
+    def __init__(self, left_camera, right_camera, T_RL):
+        self.left_camera = left_camera
+        self.right_camera = right_camera
+        self.T_RL = T_RL
+        self.T_LR = linalg.inv_transform(T_RL)
+        self.F = fundamental_matrix(T_RL, self.left_camera.K, self.right_camera.K)
+
+    def triangulate(self, left_keypoints, right_keypoints, correct_matches=True):
+        dev = _device()
+        l = torch.from_numpy(np.ascontiguousarray(left_keypoints, dtype=np.float32)).to(dev)
+        r = torch.from_numpy(np.ascontiguousarray(right_keypoints, dtype=np.float32)).to(dev)
+        out = ops.triangulate_dlt(self.left_camera.okp(), self.right_camera.okp(), self.T_RL, l, r,
+                                  F=self.F if correct_matches else None)
+        return out.cpu().numpy()
+
+    @classmethod
+    def from_file(cls, calibration_file):
+        camera = load_calibration_params(calibration_file)
+        left_camera = FisheyeCamera(camera['K'], camera['D'], camera['image_size'])
+        right_camera = FisheyeCamera(camera['Kp'], camera['Dp'], camera['image_size'])
+        return cls(left_camera, right_camera, camera['T_RL'])
+
+
+def camera_matrix(intrinsics):
+    fx, fy, cx, cy = intrinsics
+    return np.array([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]])
+
+
+def projection_matrix(camera_matrix, T_CW):
+    return camera_matrix @ T_CW[:3, :]
+
+
+def from_calibration(calibration_file):
+    with open(calibration_file, 'rt') as f:
+        camera = yaml.load(f.read(), Loader=yaml.SafeLoader)['cam0']
+    K = camera_matrix(camera['intrinsics'])
+    D = np.array(camera['distortion_coeffs'])
+    if camera['distortion_model'] == 'equidistant' and camera['camera_model'] == 'pinhole':
+        return FisheyeCamera(K, D, camera['resolution'][::-1])
+    raise ValueError(f"Unrecognized calibration type {camera['distortion_model']}.")
+
+
+def load_calibration_params(calibration_file):
+    with open(calibration_file, 'rt') as f:
+        calibration = yaml.load(f.read(), Loader=yaml.SafeLoader)
+    left, right = calibration['cam0'], calibration['cam1']
+    T_RL = np.array(right['T_cn_cnm1'])
+    return {
+        'K': camera_matrix(left['intrinsics']), 'Kp': camera_matrix(right['intrinsics']),
+        'D': np.array(left['distortion_coeffs']), 'Dp': np.array(right['distortion_coeffs']),
+        'T_LR': linalg.inv_transform(T_RL), 'T_RL': T_RL, 'image_size': right['resolution'][::-1],
+    }
+
+
+def scale_camera_matrix(K, scaling_factor):
+    out = K.copy()
+    out[0, 0] = K[0, 0] * scaling_factor[0]
+    out[1, 1] = K[1, 1] * scaling_factor[1]
+    out[0, 2] = K[0, 2] * scaling_factor[0]
+    out[1, 2] = K[1, 2] * scaling_factor[1]
+    return out
+
+
+def fundamental_matrix(T_RL, K, Kp):
+    R = T_RL[:3, :3]
+    t = T_RL[:3, 3]
+    C = linalg.skew_matrix(K @ R.T @ t)
+    return np.linalg.inv(Kp).T @ R @ K.T @ C

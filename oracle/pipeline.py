@@ -1,0 +1,210 @@
+"""ORACLE (test infrastructure, not product code): NumPy restatement of the reference's
+post-network pipeline.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it.
+
+Reference being restated (perception/pipeline.py, file:line):
+  KeypointExtractionComponent   :30-91   (5x5 ones box-sum, nms, >0.5 gate, per-peak centroid)
+  ObjectExtraction              :93-153  (centre-vector voting, 20 px gate, arg-max / k-means de-dup)
+  DetectionToPoint              :155-171 (undistort, round, clip, depth gather, unproject)
+  ObjectKeypointPipeline        :173-200
+  nms                           perception/models.py:55-58
+
+Parity status: PINNED for extraction / object grouping / depth lifting by tests/golden/pipeline.npz,
+produced by running the reference classes (tests/golden/make_goldens_pipeline.py).  The k-means
+de-dup branch (pipeline.py:143-148) is nondeterministic in the reference (init='random', no seed)
+and is checked at set level only.
+"""
+import numpy as np
+
+from . import geometry
+
+
+def box_sum5(p):
+    """5x5 ones convolution with zero padding, accumulated in fp32 in row-major tap order — the
+    association the reference's conv2d produces bit-for-bit."""
+    p = np.asarray(p, dtype=np.float32)
+    h, w = p.shape
+    padded = np.zeros((h + 4, w + 4), dtype=np.float32)
+    padded[2:-2, 2:-2] = p
+    acc = np.zeros((h, w), dtype=np.float32)
+    for dy in range(5):
+        for dx in range(5):
+            acc = (acc + padded[dy:dy + h, dx:dx + w]).astype(np.float32)
+    return acc
+
+
+def nms5(x, size=5):
+    """x * (x == max over the size x size window), window clipped at the border."""
+    r = size // 2
+    h, w = x.shape
+    padded = np.full((h + 2 * r, w + 2 * r), -np.inf, dtype=x.dtype)
+    padded[r:r + h, r:r + w] = x
+    m = np.full((h, w), -np.inf, dtype=x.dtype)
+    for dy in range(size):
+        for dx in range(size):
+            m = np.maximum(m, padded[dy:dy + h, dx:dx + w])
+    return x * (x == m).astype(x.dtype)
+
+
+def peak_indices(p):
+    """(P,2) int32 (y,x) of the peaks of one map in row-major order."""
+    s = nms5(box_sum5(p))
+    ys, xs = np.nonzero(s > np.float32(0.5))
+    return np.stack([ys, xs], axis=1).astype(np.int32)
+
+
+def refine_peaks(p, indices):
+    """Probability-weighted centroid over the clipped 5x5 window and its mass (fp32)."""
+    p = np.asarray(p, dtype=np.float32)
+    h, w = p.shape
+    points, conf = [], []
+    for y, x in indices:
+        y0, y1, x0, x1 = max(y - 2, 0), min(y + 3, h), max(x - 2, 0), min(x + 3, w)
+        win = p[y0:y1, x0:x1]
+        yy, xx = np.meshgrid(np.arange(y0, y1, dtype=np.float32), np.arange(x0, x1, dtype=np.float32), indexing="ij")
+        mass = win.sum(dtype=np.float32)
+        cy = (win * yy).sum(dtype=np.float32) / mass
+        cx = (win * xx).sum(dtype=np.float32) / mass
+        points.append(np.array([cx, cy], dtype=np.float32))      # (x, y)
+        conf.append(np.float32(mass))
+    return points, conf
+
+
+class KeypointExtractionComponent:
+    def __init__(self, keypoint_config, prediction_size, bandwidth=1.0):
+        self.keypoint_config = [1] + keypoint_config["keypoint_config"]
+        self.n_keypoints = sum(self.keypoint_config)
+        self.prediction_size = prediction_size
+
+    def _extract_keypoints(self, heatmap):
+        assert heatmap.shape[0] == len(self.keypoint_config)
+        out_points, confidences = [], []
+        for i in range(len(self.keypoint_config)):
+            p = heatmap[i].astype(np.float32)
+            pts, conf = refine_peaks(p, peak_indices(p))
+            out_points.append(pts)
+            confidences.append(conf)
+        return out_points, confidences
+
+    def __call__(self, frames):
+        keypoints, confidence = [], []
+        for i in range(frames.shape[0]):
+            kp, c = self._extract_keypoints(frames[i])
+            keypoints.append(kp)
+            confidence.append(c)
+        return keypoints, confidence
+
+
+def _kmeans(points, k, iters=50):
+    """Lloyd's algorithm with farthest-point init (deterministic stand-in for sklearn KMeans)."""
+    centers = [points[0]]
+    for _ in range(1, k):
+        d = np.min([np.linalg.norm(points - c, axis=1) for c in centers], axis=0)
+        centers.append(points[int(d.argmax())])
+    centers = np.stack(centers).astype(np.float64)
+    for _ in range(iters):
+        assign = np.argmin(np.linalg.norm(points[:, None] - centers[None], axis=2), axis=1)
+        new = np.stack([points[assign == j].mean(axis=0) if (assign == j).any() else centers[j] for j in range(k)])
+        if np.allclose(new, centers):
+            break
+        centers = new
+    return centers
+
+
+class ObjectExtraction:
+    def __init__(self, keypoint_config, prediction_size):
+        self.keypoint_config = keypoint_config["keypoint_config"]
+        self.prediction_size = prediction_size
+        self.max = np.array(prediction_size[::-1], dtype=np.int32) - 1
+        self.min = np.zeros(2, dtype=np.int32)
+        h, w = prediction_size
+        ys, xs = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+        self.image_indices = np.stack([xs, ys])          # (2,h,w): pixel centres (x, y)
+
+    def __call__(self, keypoints, confidence, centers):
+        if len(keypoints[0]) == 0:
+            return []
+        p_centers = self.image_indices + centers          # (K-1, 2, h, w) predicted object centre per pixel
+        center_points = np.stack(keypoints[0])
+        objects = [{"center": c, "heatmap_points": [[] for _ in keypoints[1:]],
+                    "confidence": [[] for _ in keypoints[1:]], "p_centers": []} for c in center_points]
+        for i, points in enumerate(keypoints[1:]):
+            for j, point in enumerate(points):
+                xy = np.clip(point.round().astype(np.int32), self.min, self.max)
+                predicted = p_centers[i, :, xy[1], xy[0]]
+                dist = np.linalg.norm(center_points - predicted[None], 2, axis=1)
+                if dist.min() > 20.0:
+                    continue                               # outlier: votes for no known centre
+                obj = objects[int(dist.argmin())]
+                obj["p_centers"].append(predicted)
+                obj["heatmap_points"][i].append(point)
+                obj["confidence"][i].append(confidence[i + 1][j])
+        for obj in objects:
+            for i in range(len(obj["heatmap_points"])):
+                if len(obj["heatmap_points"][i]) == 0:
+                    obj["heatmap_points"][i] = np.array([])
+                    continue
+                pts = np.stack(obj["heatmap_points"][i])
+                conf = np.stack(obj["confidence"][i])
+                want = self.keypoint_config[i]
+                if pts.shape[0] > want:
+                    pts = pts[conf.argmax(axis=0)][None] if want == 1 else _kmeans(pts, want)
+                obj["heatmap_points"][i] = pts
+        return objects
+
+
+class DetectionToPoint:
+    def reset(self, camera):
+        self.camera = camera
+        self.min_index = np.zeros(2, dtype=int)
+        self.max_index = camera.image_size.astype(int) - 1
+
+    def __call__(self, xy, p_depth):
+        if xy.shape[0] == 0:
+            return None
+        xy = self.camera.undistort(xy)
+        xy_int = np.clip(xy.round().astype(int), self.min_index, self.max_index)
+        zs = p_depth[xy_int[:, 1], xy_int[:, 0]]
+        return self.camera.unproject(xy, zs)
+
+
+class ObjectKeypointPipeline:
+    def __init__(self, prediction_size, points_3d, keypoint_config):
+        self.keypoint_extraction = KeypointExtractionComponent(keypoint_config, prediction_size)
+        self.object_extraction = ObjectExtraction(keypoint_config, prediction_size)
+        self.detection_to_point = DetectionToPoint()
+
+    def reset(self, camera):
+        self.detection_to_point.reset(camera)
+
+    def __call__(self, heatmap, p_depth, p_centers):
+        heatmap, p_depth, p_centers = (np.asarray(t) for t in (heatmap, p_depth, p_centers))
+        assert heatmap.shape[0] == 1, "One at the time, please."
+        points, confidence = self.keypoint_extraction(heatmap)
+        detected = self.object_extraction(points[0], confidence[0], p_centers[0])
+        objects = []
+        for obj in detected:
+            world = [self.detection_to_point(obj["center"][None], p_depth[0][0])]
+            for i, pts in enumerate(obj["heatmap_points"]):
+                world.append(self.detection_to_point(pts, p_depth[0][1 + i]))
+            objects.append({"p_centers": obj["p_centers"], "keypoints": [obj["center"][None]] + obj["heatmap_points"],
+                            "p_C": world})
+        return objects
+
+
+class TriangulationComponent:
+    """API the reference's test expects (test/test_pipeline.py:171-177): reset(stereo); __call__(p_L, p_R) -> (n,3)."""
+
+    def reset(self, stereo_camera):
+        self.stereo_camera = stereo_camera
+
+    def __call__(self, left_keypoints, right_keypoints):
+        return self.stereo_camera.triangulate(left_keypoints, right_keypoints)
+
+
+def eval_camera(calibration_file, prediction_size=64, height=720, width=1280, resized=511):
+    """The 64x64-space camera of scripts/eval_model.py:61-69 (scale to 511, centre-crop, scale to 64)."""
+    params = geometry.load_calibration_params(calibration_file)
+    camera = geometry.FisheyeCamera(params["K"], params["D"], params["image_size"])
+    camera = camera.scale(resized / height)
+    offset = np.array([(resized / height * width - float(resized)) / 2.0, 0.0])
+    return camera.cut(offset).scale(prediction_size / resized)

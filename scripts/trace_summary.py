@@ -1,0 +1,26 @@
+"""Summarise a rocprofv3 kernel-trace CSV: per-dispatch durations of the LAST forward (from the
+last okp_pack_frames launch on) and totals per kernel family."""
+import csv, sys, collections, re
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+packs = [i for i, r in enumerate(rows) if "okp_pack_frames" in r["Kernel_Name"]]
+sel = rows[packs[-1]:]
+def short(n):
+    if "okp_igemm" in n:
+        m = re.search(r"okp_igemm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)E", n)
+        return f"igemm<{ 'bf16' if 'DF16b' in m.group(1) else 'f32'},{m.group(2)}x{m.group(3)},src{m.group(4)}>"
+    for k in ("okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_peak_nms"):
+        if k in n: return k
+    return n[:40]
+t0 = int(sel[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in sel)
+tot = collections.Counter(); cnt = collections.Counter()
+thr = int(sys.argv[2]) * 1000 if len(sys.argv) > 2 else None
+for r in sel:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    k = short(r["Kernel_Name"])
+    tot[k] += d; cnt[k] += 1
+    if thr is not None and d > thr:
+        print(f"{(int(r['Start_Timestamp'])-t0)/1e3:9.1f}us  {d/1e3:8.1f}us  grid {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):6d} wg  {k}")
+print(f"last forward: wall {(t1-t0)/1e3:.1f} us, sum of kernels {sum(tot.values())/1e3:.1f} us, {len(sel)} dispatches")
+for k, v in tot.most_common():
+    print(f"  {k:32s} n={cnt[k]:4d}  {v/1e3:9.1f} us")

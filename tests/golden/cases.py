@@ -36,3 +36,48 @@ NET_CASES = {
     "valve_k3": dict(heatmaps_out=3, weight_seed=0, frame_seed=1, frame_index=0),   # config/valve.json [1,3]
     "cups_k4":  dict(heatmaps_out=4, weight_seed=0, frame_seed=1, frame_index=1),   # config/cups.json [1,1,1]
 }
+
+
+# ---------------------------------------------------------------------------------------------
+# post-network pipeline cases: heat / depth / centre maps generated procedurally
+# ---------------------------------------------------------------------------------------------
+import numpy as _np
+
+
+def _bump(size, cx, cy, length_scale=2.0, gain=1.0):
+    ys, xs = _np.meshgrid(_np.arange(size, dtype=_np.float32), _np.arange(size, dtype=_np.float32), indexing="ij")
+    d2 = (xs - _np.float32(cx)) ** 2 + (ys - _np.float32(cy)) ** 2
+    return (_np.float32(gain) * _np.exp(-d2 / _np.float32(length_scale ** 2))).astype(_np.float32)
+
+
+def pipeline_case(name):
+    """-> dict(config=..., heat (K,64,64), depth (K,64,64), centers (K-1,2,64,64)) float32."""
+    from object_keypoints_amd import synth
+    size = 64
+    if name == "valve_one":
+        s = synth.bump_scene([1, 3], n_objects=1, seed=3, index=0)
+        return dict(config=[1, 3], heat=s["heat"], depth=s["depth"], centers=s["centers"])
+    if name == "valve_two":
+        s = synth.bump_scene([1, 3], n_objects=2, seed=3, index=2)
+        return dict(config=[1, 3], heat=s["heat"], depth=s["depth"], centers=s["centers"])
+    if name == "cups_four":
+        s = synth.bump_scene([1, 1, 1], n_objects=4, seed=3, index=1)
+        return dict(config=[1, 1, 1], heat=s["heat"], depth=s["depth"], centers=s["centers"])
+    if name == "special":
+        heat = _np.zeros((4, size, size), dtype=_np.float32)
+        heat[0] = _bump(size, 20.5, 30.0)                              # symmetric: two tied maxima survive
+        heat[1] = _np.clip(_bump(size, 0.3, 0.2) + _bump(size, 63.0, 31.0) + _bump(size, 40.0, 63.0), 0, 1)   # border peaks
+        heat[2] = _np.clip(3.0 * _bump(size, 33.0, 17.0, length_scale=3.0), 0, 1)    # saturated 1.0 plateau
+        heat[3] = 0.0                                                   # empty map
+        return dict(config=[1, 1, 1], heat=heat, depth=_np.ones_like(heat), centers=_np.zeros((3, 2, size, size), _np.float32))
+    if name == "noise":
+        heat = _np.stack([synth.uniform(f"noise{k}", (size, size), 7, 0.0, 0.12) for k in range(4)])
+        return dict(config=[1, 1, 1], heat=heat.astype(_np.float32), depth=_np.ones_like(heat), centers=_np.zeros((3, 2, size, size), _np.float32))
+    if name == "weak":
+        heat = _np.stack([_bump(size, 10 + 9 * k, 12 + 7 * k, gain=g) for k, g in enumerate((0.03, 0.11, 0.12, 0.3))])
+        return dict(config=[1, 1, 1], heat=heat, depth=_np.ones_like(heat), centers=_np.zeros((3, 2, size, size), _np.float32))
+    raise KeyError(name)
+
+
+PIPELINE_CASES = ["valve_one", "valve_two", "cups_four", "special", "noise", "weak"]
+OBJECT_CASES = ["valve_one", "valve_two", "cups_four"]       # cases with consistent centre / depth maps

@@ -1,0 +1,191 @@
+"""GPU parity of the post-network path (peak-NMS, lifting, DLT) through the C ABI:
+against golden vectors produced by the reference, against the oracle on seeded inputs, and by
+size-independent properties at the benchmark's batch size."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import geometry as og
+from oracle import pipeline as op
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALIB = os.path.join(REPO, "config", "calibration.yaml")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(REPO, "tests", "golden", "pipeline.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def known():
+    with open(os.path.join(REPO, "tests", "golden", "known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", cases.PIPELINE_CASES)
+def test_peak_nms_matches_reference_golden(golden, name):
+    from object_keypoints_amd import ops
+    c = cases.pipeline_case(name)
+    heat = torch.from_numpy(c["heat"][None]).cuda()
+    count, yx, xyc = [t.cpu().numpy() for t in ops.peak_nms(heat, cap=128)]
+    for k, g in enumerate(golden["extraction"][name]):
+        n = len(g["indices"])
+        assert int(count[0, k]) == n
+        assert yx[0, k, :n].tolist() == g["indices"]          # bit-exact indices, row-major order
+        if n:
+            np.testing.assert_allclose(xyc[0, k, :n, :2], np.array(g["points"]), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(xyc[0, k, :n, 2], np.array(g["confidence"]), rtol=1e-6, atol=1e-6)
+
+
+def test_peak_capacity_overflow_is_explicit(golden):
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.pipeline import KeypointExtractionComponent
+    c = cases.pipeline_case("noise")
+    heat = torch.from_numpy(c["heat"][None]).cuda()
+    count, yx, _ = [t.cpu().numpy() for t in ops.peak_nms(heat, cap=16)]
+    for k, g in enumerate(golden["extraction"]["noise"]):
+        assert int(count[0, k]) == len(g["indices"])           # total is reported even when it exceeds the capacity
+        assert yx[0, k].tolist() == g["indices"][:16]          # the first `cap` peaks in row-major order are kept
+    comp = KeypointExtractionComponent({"keypoint_config": c["config"]}, [64, 64], capacity=16)
+    with pytest.raises(ops.OkpError):
+        comp(c["heat"][None])
+
+
+def test_nms_function_matches_oracle():
+    from object_keypoints_amd.perception.models import nms
+    from oracle import net as onet
+    x = torch.from_numpy(np.stack([cases.pipeline_case("special")["heat"], cases.pipeline_case("noise")["heat"]]))
+    got = nms(x.cuda()).cpu()
+    assert torch.equal(got, onet.nms(x))
+    assert torch.equal(nms(x.cuda(), size=3).cpu(), onet.nms(x, size=3))
+
+
+@pytest.mark.parametrize("name", cases.PIPELINE_CASES)
+def test_extraction_component_matches_reference_golden(golden, name):
+    from object_keypoints_amd.perception.pipeline import KeypointExtractionComponent
+    c = cases.pipeline_case(name)
+    comp = KeypointExtractionComponent({"keypoint_config": c["config"]}, [64, 64], capacity=128)
+    points, conf = comp(c["heat"][None])
+    assert len(points) == 1 and len(points[0]) == c["heat"].shape[0]
+    for k, g in enumerate(golden["extraction"][name]):
+        assert len(points[0][k]) == len(g["points"])
+        for p, gp in zip(points[0][k], g["points"]):
+            assert p.dtype == np.float32 and p.shape == (2,)
+            np.testing.assert_allclose(p, gp, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", cases.OBJECT_CASES)
+def test_object_pipeline_matches_reference_golden(golden, name):
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    c = cases.pipeline_case(name)
+    cfg = {"keypoint_config": c["config"]}
+    params = cu.load_calibration_params(CALIB)
+    camera = cu.FisheyeCamera(params["K"], params["D"], params["image_size"]).scale(511 / 720)
+    camera_small = camera.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511)
+    np.testing.assert_allclose(camera_small.K, np.array(golden["camera_small"]["K"]), rtol=1e-12)
+    pipe = pp.ObjectKeypointPipeline([64, 64], None, cfg)
+    pipe.reset(camera_small)
+    res = pipe(torch.from_numpy(c["heat"][None]), torch.from_numpy(c["depth"][None]), torch.from_numpy(c["centers"][None]))
+    gp = golden["pipeline"][name]
+    assert len(res) == len(gp)
+    for o, go in zip(res, gp):
+        assert set(o.keys()) == {"p_centers", "keypoints", "p_C"}
+        for a, b in zip(o["keypoints"], go["keypoints"]):
+            np.testing.assert_allclose(a, np.array(b).reshape(np.asarray(a).shape), atol=2e-5)
+        for a, b in zip(o["p_C"], go["p_C"]):
+            if b is None:
+                assert a is None
+            else:
+                assert a.dtype == np.float64
+                np.testing.assert_allclose(a, np.array(b), rtol=0, atol=1e-4)      # north_star: 1e-4 m
+                assert np.abs(a - np.array(b)).max() < 1e-6
+    # the batched, device-resident form gives the same objects
+    batched = pp.BatchedKeypointPipeline(None, cfg, camera_small)
+    out = batched.postprocess_device(torch.from_numpy(c["heat"][None]).cuda(), torch.from_numpy(c["depth"][None]).cuda(),
+                                     torch.from_numpy(c["centers"][None]).cuda())
+    objs = batched.objects(out, 0)
+    assert len(objs) == len(res)
+    for o, r in zip(objs, res):
+        for a, b in zip(o["p_C"], r["p_C"]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                np.testing.assert_array_equal(a, b)
+
+
+def test_triangulation_known_answer_and_oracle(known):
+    from object_keypoints_amd.perception.pipeline import TriangulationComponent
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    stereo = cu.StereoCamera.from_file(CALIB)
+    tri = TriangulationComponent()
+    tri.reset(stereo)
+    kp = np.array(known["keypoints_distinct"])
+    pts = np.concatenate([kp.mean(axis=0)[None], kp])
+    p_w = tri(np.array(known["points_left_distinct"]), np.array(known["points_right_distinct"]))
+    assert p_w.shape == (4, 3)
+    assert np.linalg.norm(p_w - pts, axis=1).max() < known["triangulation_tolerance_m"]      # the reference test's bound
+    assert np.linalg.norm(p_w - pts, axis=1).max() < 1e-4                                      # north_star bound
+    # noisy correspondences: Hartley-Sturm + DLT against the oracle restatement
+    ostereo = og.StereoCamera.from_file(CALIB)
+    rng = np.random.default_rng(3)
+    X = np.stack([rng.uniform(-0.4, 0.4, 64), rng.uniform(-0.25, 0.25, 64), rng.uniform(0.6, 2.0, 64)], axis=1)
+    pl = ostereo.left_camera.project(X) + rng.normal(0, 0.5, (64, 2))
+    pr = ostereo.right_camera.project(X, ostereo.T_RL) + rng.normal(0, 0.5, (64, 2))
+    got = stereo.triangulate(pl, pr)
+    want = ostereo.triangulate(pl, pr)
+    assert np.abs(got - want).max() < 1e-4
+    got2 = stereo.triangulate(pl, pr, correct_matches=False)
+    want2 = ostereo.triangulate(pl, pr, correct=False)
+    assert np.abs(got2 - want2).max() < 1e-6
+
+
+def test_undistort_matches_oracle():
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    p = cu.load_calibration_params(CALIB)
+    cam = cu.FisheyeCamera(p["K"], p["D"], p["image_size"])
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.uniform(0, 1280, 500), rng.uniform(0, 720, 500)], axis=1)
+    got = cam.undistort(xy)
+    want = og.fisheye_undistort(xy.astype(np.float32).astype(np.float64), p["K"], p["D"], P=p["K"])
+    assert got.dtype == np.float64
+    assert np.abs(got - want).max() < 1e-9
+    assert cam.undistort(xy.astype(np.float32)).dtype == np.float32
+
+
+def test_batch64_properties():
+    """BASELINE batch size: every frame of a 64-frame batch gives the peaks it gives alone (frames are
+    independent), peaks are sorted row-major, and lifted points agree with the oracle on sampled frames."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    scenes = [synth.bump_scene([1, 1, 1], n_objects=1 + (i % 4), seed=11, index=i) for i in range(64)]
+    heat = torch.from_numpy(np.stack([s["heat"] for s in scenes])).cuda()
+    depth = torch.from_numpy(np.stack([s["depth"] for s in scenes])).cuda()
+    count, yx, xyc = ops.peak_nms(heat, cap=64)
+    cam_o = op.eval_camera(CALIB)
+    cam = cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size)
+    pts = ops.lift_peaks(cam.okp(), count, xyc, depth, 63, 63).cpu().numpy()
+    count, yx, xyc = count.cpu().numpy(), yx.cpu().numpy(), xyc.cpu().numpy()
+    assert count.sum() > 64 * 4
+    lin = yx[..., 0].astype(np.int64) * 64 + yx[..., 1]
+    for n in range(64):
+        for k in range(4):
+            c = int(count[n, k])
+            assert (np.diff(lin[n, k, :c]) > 0).all()                       # row-major order
+            assert np.isnan(pts[n, k, c:]).all() and not np.isnan(pts[n, k, :c]).any()
+    d2p = op.DetectionToPoint(); d2p.reset(cam_o)
+    for n in (0, 17, 63):
+        single = ops.peak_nms(heat[n:n + 1], cap=64)
+        assert torch.equal(single[1].cpu(), torch.from_numpy(yx[n:n + 1]))
+        for k in range(4):
+            idx = op.peak_indices(scenes[n]["heat"][k])
+            assert yx[n, k, :len(idx)].tolist() == idx.tolist()
+            if len(idx):
+                want = d2p(xyc[n, k, :len(idx), :2], scenes[n]["depth"][k])
+                assert np.abs(pts[n, k, :len(idx), :3] - want).max() < 1e-6

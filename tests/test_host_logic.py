@@ -1,0 +1,145 @@
+"""CPU-side checks that need no GPU: the C-ABI library loads and exports every symbol include/okp.h
+declares, the product's host logic (ObjectExtraction, weight folding, stem tap layout) agrees with the
+reference goldens / the oracle, and the product refuses to run without a device."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    from object_keypoints_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol():
+    path = _ensure_built()
+    header = open(os.path.join(REPO, "include", "okp.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(okp_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/okp.h but not exported"
+    from object_keypoints_amd import _lib
+    bound = {n for n, _, _ in _lib.SIGNATURES}
+    assert declared == bound, f"ctypes binding and header disagree: {declared ^ bound}"
+    assert _lib.lib().okp_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    from object_keypoints_amd import _lib
+    assert ctypes.sizeof(_lib.okp_tensor) == 32
+    assert ctypes.sizeof(_lib.okp_tap) == 24
+    assert ctypes.sizeof(_lib.okp_camera) == 64
+    assert _lib.okp_conv_args.src.offset == 16 and _lib.okp_conv_args.out.offset == 80
+    assert _lib.okp_conv_args.res.offset == 128 and ctypes.sizeof(_lib.okp_conv_args) == 168
+
+
+def test_no_cpu_fallback():
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.models import KeypointNet
+    with pytest.raises(ops.OkpError):
+        ops.Act(torch.zeros(1, 4, 4, 8))
+    if not torch.cuda.is_available():
+        net = KeypointNet(features=16, heatmaps_out=3).eval()
+        with pytest.raises(ops.OkpError):
+            net.deployed(torch.zeros(1, 3, 63, 63))
+        from object_keypoints_amd.perception.pipeline import InferenceComponent
+        with pytest.raises(ops.OkpError):
+            InferenceComponent(net, cuda=False)
+
+
+def test_bad_plan_arguments_are_reported_without_a_gpu():
+    from object_keypoints_amd import _lib
+    L = _lib.lib()
+    cin = (ctypes.c_int32 * 2)(6, 0)
+    st = (ctypes.c_int32 * 2)(1, 1)
+    w = np.zeros((8, 6), np.float32)
+    tap = (_lib.okp_tap * 1)(_lib.okp_tap(0, 0, 0, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    assert not L.okp_conv_create(0, 1, cin, st, 8, 1, tap, None, 0)
+    assert b"16 bytes" in L.okp_last_error()
+    assert L.okp_peak_nms(None, 1, 64, 64, 8, None, None, None, None) == -1
+
+
+def test_fold_bn_and_stem_taps_reproduce_the_oracle_convolution():
+    """Host-side weight preparation: folding BN into (w, b) and the 8px x 4ch stem tap layout are linear
+    algebra that can be checked on the CPU against the oracle's conv + BN."""
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    o = onet.load_synthetic(onet.convolution(7, 3, 16, stride=2), seed=5)
+    shapes = {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    m = bb.convolution(7, 3, 16, stride=2)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.fill_state_dict(shapes, seed=5).items()})
+    w, b = bb.fold_bn(m.conv.weight, m.bn)
+    x = torch.from_numpy(synth.normal_like("stemx", (1, 3, 21, 21), 2))
+    want = o(x)
+    got = torch.relu(torch.nn.functional.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), stride=2, padding=3))
+    assert torch.allclose(got, want, atol=1e-5)
+    # stem taps: out[co] = sum_r sum_{kx<8,c<4} T_r[co, kx*4+c] * packed[2*ho + r, 2*wo + kx, c]
+    packed = torch.zeros(1, 21 + 6, 32, 4)
+    packed[0, 3:24, 3:24, :3] = x[0].permute(1, 2, 0)
+    taps = []
+    for r in range(7):
+        t = np.zeros((16, 8, 4), np.float32)
+        t[:, :7, :3] = np.transpose(w[:, :, r, :], (0, 2, 1))
+        taps.append(torch.from_numpy(t.reshape(16, 32)))
+    ho = wo = 11
+    acc = torch.zeros(16, ho, wo)
+    for r in range(7):
+        for i in range(ho):
+            for j in range(wo):
+                acc[:, i, j] += taps[r] @ packed[0, 2 * i + r, 2 * j:2 * j + 8, :].reshape(32)
+    assert torch.allclose(torch.relu(acc + torch.from_numpy(b)[:, None, None]), want[0], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", cases.OBJECT_CASES)
+def test_product_object_extraction_matches_reference_golden(name):
+    """ObjectExtraction is host logic in the product too; feed it oracle-extracted peaks."""
+    from object_keypoints_amd.perception.pipeline import ObjectExtraction
+    from oracle import pipeline as op
+    with open(os.path.join(REPO, "tests", "golden", "pipeline.json")) as f:
+        golden = json.load(f)
+    c = cases.pipeline_case(name)
+    cfg = {"keypoint_config": c["config"]}
+    points, conf = op.KeypointExtractionComponent(cfg, [64, 64])(c["heat"][None])
+    objs = ObjectExtraction(cfg, [64, 64])(points[0], conf[0], c["centers"])
+    g = golden["objects"][name]
+    assert len(objs) == len(g)
+    for o, go in zip(objs, g):
+        np.testing.assert_allclose(o["center"], go["center"], atol=2e-5)
+        for a, b in zip(o["heatmap_points"], go["heatmap_points"]):
+            assert np.asarray(a).shape == np.asarray(b).shape
+            if np.asarray(b).size:
+                np.testing.assert_allclose(a, b, atol=2e-5)
+        np.testing.assert_allclose(np.array(o["p_centers"]), np.array(go["p_centers"]), atol=2e-5)
+
+
+def test_kmeans_branch_set_level():
+    """More detections of a multi-instance type than configured: the reference clusters them with an unseeded
+    KMeans (pipeline.py:143-148), so only the set of cluster centres is comparable."""
+    from object_keypoints_amd.perception.pipeline import ObjectExtraction
+    from oracle import pipeline as op
+    cfg = {"keypoint_config": [1, 2]}
+    center = [np.array([30.0, 30.0], np.float32)]
+    pts = [np.array(p, np.float32) for p in ([20.0, 30.0], [20.6, 30.2], [40.0, 31.0], [40.5, 30.5])]
+    keypoints = [center, [np.array([30.0, 20.0], np.float32)], pts]
+    conf = [[np.float32(5)], [np.float32(4)], [np.float32(c) for c in (3, 2, 4, 1)]]
+    centers = np.zeros((2, 2, 64, 64), np.float32)
+    for p in pts + [keypoints[1][0]]:
+        x, y = int(round(float(p[0]))), int(round(float(p[1])))
+        centers[:, 0, y, x] = 30.0 - (x + 0.5)
+        centers[:, 1, y, x] = 30.0 - (y + 0.5)
+    got = ObjectExtraction(cfg, [64, 64])(keypoints, conf, centers)[0]["heatmap_points"][1]
+    want = op.ObjectExtraction(cfg, [64, 64])(keypoints, conf, centers)[0]["heatmap_points"][1]
+    key = lambda a: sorted(map(tuple, np.round(np.asarray(a, dtype=np.float64), 4).tolist()))
+    assert key(got) == key(want)
