@@ -93,6 +93,8 @@ typedef struct okp_conv_args {
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
+/* The tile (1..3) the launch heuristic picks for these args when args->tile == 0. */
+int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* args);
 /* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
 int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
 

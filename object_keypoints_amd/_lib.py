@@ -54,6 +54,7 @@ SIGNATURES = [
     ("okp_conv_create", c_void_p, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(c_float), c_int]),
     ("okp_conv_destroy", None, [c_void_p]),
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
+    ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_dwconv3x3_forward", c_int, [c_int, c_int32, c_int32, c_int32, POINTER(okp_tensor), c_void_p, c_void_p, POINTER(okp_tensor), POINTER(okp_tensor), c_int, c_void_p]),
     ("okp_pack_frames", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),

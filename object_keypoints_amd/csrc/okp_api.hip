@@ -201,6 +201,12 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   return okp_launch_igemm(plan, p, a->tile, (hipStream_t)stream);
 }
 
+extern "C" int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* a) {
+  if (!plan || !a) return 0;
+  if (a->tile) return a->tile;
+  return okp_select_tile(plan->cout_pad, (long)a->n * a->ho * a->wo);
+}
+
 extern "C" int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* a) {
   if (!plan || !a) return 0;
   int64_t k = 0;

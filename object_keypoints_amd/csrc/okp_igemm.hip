@@ -293,15 +293,16 @@ int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStre
 
 }  // namespace
 
+int okp_select_tile(int cout_pad, long P) {
+  // Fill the 256 CUs first; only then grow the tile (bigger tiles re-read less from L2).
+  auto tiles = [&](int b) { return ((P + b - 1) / b) * ((cout_pad + b - 1) / b); };
+  if (tiles(256) >= 256 && cout_pad >= 192) return 3;
+  if (tiles(128) >= 256) return 2;
+  return 1;
+}
+
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
-  if (tile == 0) {
-    // Fill the 256 CUs first; only then grow the tile (bigger tiles re-read less from L2).
-    const long P = (long)p.N * p.Ho * p.Wo;
-    auto tiles = [&](int b) { return ((P + b - 1) / b) * ((p.cout_pad + b - 1) / b); };
-    if (tiles(256) >= 256 && p.cout_pad >= 192) tile = 3;
-    else if (tiles(128) >= 256) tile = 2;
-    else tile = 1;
-  }
+  if (tile == 0) tile = okp_select_tile(p.cout_pad, (long)p.N * p.Ho * p.Wo);
   if (plan->dtype == OKP_BF16) return launch_tile<__bf16>(plan, p, tile, stream);
   return launch_tile<float>(plan, p, tile, stream);
 }

@@ -1,0 +1,66 @@
+"""Frame-parallel data parallelism: one process per GPU, frames sharded in contiguous blocks, no
+data-path collective except ONE all-gather of the fixed-capacity 3D-keypoint tensor per batch
+(RCCL over xGMI when the backend is "nccl"; gloo on CPU for tests).
+
+The reference processes one frame at a time and has no collective on this path
+(perception/pipeline.py:183); frames are independent, so this is pure
+weak-scaling data parallelism with replicated weights.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def shard(total, rank, world):
+    """Contiguous block of `total` frames owned by `rank`: (start, count).  Blocks differ by at most one frame."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def all_gather_keypoints(points):
+    """points: [frames_local, K, cap, 4] (same shape on every rank) -> [world*frames_local, K, cap, 4],
+    ordered by rank, i.e. by global frame index for contiguous shards.  One collective, no padding logic:
+    the tensor is fixed-capacity by construction (NaN rows mark unused peak slots)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return points
+    world = dist.get_world_size()
+    points = points.contiguous()
+    out = torch.empty((world * points.shape[0],) + tuple(points.shape[1:]), dtype=points.dtype, device=points.device)
+    dist.all_gather_into_tensor(out, points)
+    return out
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

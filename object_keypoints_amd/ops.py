@@ -131,12 +131,20 @@ class ConvPlan:
         a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
         a.res = res.view() if res is not None else _NULL_TENSOR
         a.tile = tile or FORCE_TILE
+        macs = out.n * ho * wo * self.cout * self.alg_k
+        hook = LAUNCH_HOOK
+        if hook is not None:
+            a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
+            token = hook.before(self, a.tile, macs)
         _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
-        COUNTERS["macs"] += out.n * ho * wo * self.cout * self.alg_k
+        if hook is not None:
+            hook.after(token)
+        COUNTERS["macs"] += macs
         COUNTERS["launches"] += 1
 
 
 COUNTERS = {"macs": 0, "launches": 0}
+LAUNCH_HOOK = None      # bench.py: object with before(plan, tile, macs) / after(token) bracketing conv launches
 FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256), 0 = heuristic
 
 
