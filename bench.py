@@ -82,12 +82,24 @@ def build_net(dtype):
     return net.eval()
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds):
     """The oracle (a port: torch-CPU fp32 restatement + NumPy post-processing) on the host cores."""
     from oracle import net as onet
     from oracle import pipeline as op
     from object_keypoints_amd import synth
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     net = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=3), seed=0)
     cam = op.eval_camera(os.path.join(REPO, "config", "calibration.yaml"))

@@ -78,6 +78,13 @@ def lib():
             raise OkpError(f"{LIB_PATH} not found: build it with `python -m object_keypoints_amd.build`; "
                            "there is no CPU fallback for the HIP path")
         try:
+            # One HIP runtime per process: torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Load
+            # torch's copy first so that libokp_hip.so binds to the runtime that owns torch's streams and
+            # allocations; two runtime instances do not share devices ("no ROCm-capable device is detected").
+            import torch
+            bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(bundled):
+                ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as e:
             raise OkpError(f"cannot load {LIB_PATH}: {e}") from e
