@@ -90,6 +90,7 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
     ++t;
   }
   plan->n_slices = (int)slices.size();
+  if (plan->n_slices > 256) { okp_set_error("okp_conv_create: %d K-slices exceed the 256-entry in-LDS slice table", plan->n_slices); delete plan; return nullptr; }
 
   // ---- packed weights [slice][cout_pad][KE] ---------------------------------------------------
   const size_t n_el = (size_t)plan->n_slices * plan->cout_pad * KE;

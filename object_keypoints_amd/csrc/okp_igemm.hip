@@ -74,6 +74,14 @@ __device__ __forceinline__ uint32_t swz(int row, int chunk) {   // byte offset o
   return (uint32_t)row * 128u + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+struct SliceMeta {            // per-slice gather constants, built once per workgroup in LDS
+  int32_t d_lo, d_hi;         // byte deltas of the two 64-byte halves relative to the pixel's base offset
+  uint32_t packed;            // tap_lo | tap_hi << 8 | nvalid << 16 | src << 24
+  uint32_t pad;
+};
+constexpr int kMetaMax = 256;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <typename T, int BCO, int BPX, int WCO, int WPX, int NSRC>
 __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgemmParams p) {
   constexpr int NT = 64 * WCO * WPX;
@@ -86,12 +94,15 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   constexpr int STAGE = (BCO + BPX) * 128;
   constexpr int LDS_BYTES = 2 * STAGE;
   constexpr int PASSES = (BPX * BCO * 4 > LDS_BYTES) ? 2 : 1;
+  static_assert(RPP % 16 == 0, "loader swizzle assumes the pass height keeps (row>>1)&7");
   static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
   static_assert(BPX * BCO * 4 / PASSES <= LDS_BYTES, "epilogue staging must fit");
   constexpr int PX_PER_PASS = BPX / PASSES;
   constexpr int PITCH = BCO * 4;
 
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta)];
+  SliceMeta* const meta = reinterpret_cast<SliceMeta*>(smem + LDS_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,12 +114,29 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   const int HoWo = p.Ho * p.Wo;
   const int P = p.N * HoWo;
 
-  const int c = tid & 7;        // 16-B chunk handled by this thread in every loader row
+  // Loader geometry.  One `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B = 8 tile rows linearly into LDS,
+  // so lane (row r0 = tid>>3, position tid&7) must FETCH the logical chunk that the read-side swizzle expects
+  // at that position: c = pos ^ ((row>>1)&7)  (swizzle on the source address, linear destination).
   const int r0 = tid >> 3;
+  const int c = (tid & 7) ^ ((r0 >> 1) & 7);
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[0]), 0, (int)p.src_bytes[0], 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[NSRC - 1]), 0, (int)p.src_bytes[NSRC - 1], 0x00020000);
+
+  // ---- slice constants -> LDS (one thread per slice) -------------------------------------------
+  for (int s = tid; s < p.n_slices; s += NT) {
+    const OkpSlice sl = p.slices[s];
+    const int src = (NSRC == 1) ? 0 : (int)sl.src;
+    const int W = src ? p.srcW[NSRC - 1] : p.srcW[0];
+    const int ps = src ? p.src_pix_stride[NSRC - 1] : p.src_pix_stride[0];
+    SliceMeta m;
+    m.d_lo = ((p.taps[sl.tap_lo].dy * W + p.taps[sl.tap_lo].dx) * ps + sl.c0_lo) * ESZ;
+    m.d_hi = ((p.taps[sl.tap_hi].dy * W + p.taps[sl.tap_hi].dx) * ps + sl.c0_hi) * ESZ;
+    m.packed = (uint32_t)sl.tap_lo | ((uint32_t)sl.tap_hi << 8) | ((uint32_t)sl.nvalid << 16) | ((uint32_t)src << 24);
+    m.pad = 0;
+    meta[s] = m;
+  }
 
   // ---- per-thread row state -------------------------------------------------------------
   uint32_t wbase[WROWS];
@@ -152,39 +180,36 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  u32x4 wreg[WROWS], xreg[XROWS];
-
-  auto load_slice = [&](int s) {
-    const OkpSlice sl = p.slices[s];
-    const int src = (NSRC == 1) ? 0 : (int)sl.src;
-    const int W = p.srcW[src], ps = p.src_pix_stride[src];
-    const int d_lo = ((p.taps[sl.tap_lo].dy * W + p.taps[sl.tap_lo].dx) * ps + sl.c0_lo) * ESZ;
-    const int d_hi = ((p.taps[sl.tap_hi].dy * W + p.taps[sl.tap_hi].dx) * ps + sl.c0_hi) * ESZ;
+  // Issue the LDS-DMA gather of slice `s` (constants `m`) into `stage`.  Masked lanes (padding halo, rows
+  // beyond the problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then
+  // writes zeros to LDS (verified by scripts/hwtests/dma_oob.hip).
+  auto issue_slice = [&](int s, const SliceMeta& m, int stage) {
     const bool hi_half = c >= 4;
-    const uint32_t delta = (uint32_t)(hi_half ? d_hi : d_lo);
-    const int tap = hi_half ? (int)sl.tap_hi : (int)sl.tap_lo;
-    const bool chunk_ok = c < (int)sl.nvalid;
+    const uint32_t delta = (uint32_t)(hi_half ? m.d_hi : m.d_lo);
+    const uint32_t tap = hi_half ? ((m.packed >> 8) & 0xffu) : (m.packed & 0xffu);
+    const uint32_t chunk_ok = ((uint32_t)c < ((m.packed >> 16) & 0xffu)) ? 1u : 0u;
+    const int src = (NSRC == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(m.packed >> 24));
     const uint32_t wslice = (uint32_t)s * (uint32_t)p.cout_pad * 128u;
+    char* const wt = smem + stage * STAGE + wave * 1024;
+    char* const xt = wt + BCO * 128;
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase[i] + wslice), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * 128), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+    if (NSRC == 1 || src == 0) {
 #pragma unroll
-    for (int i = 0; i < XROWS; ++i) {
-      const bool ok = chunk_ok && ((xmask[i] >> tap) & 1u);
-      const uint32_t base = (NSRC == 1 || src == 0) ? xbase[0][i] : xbase[NSRC - 1][i];
-      const uint32_t off = ok ? base + delta : kInvalidOff;
-      xreg[i] = (NSRC == 1 || src == 0) ? __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)off, 0, 0)
-                                        : __builtin_amdgcn_raw_buffer_load_b128(rs_x1, (int)off, 0, 0);
+      for (int i = 0; i < XROWS; ++i) {
+        const uint32_t ok = chunk_ok & (xmask[i] >> tap) & 1u;
+        const uint32_t off = ok ? xbase[0][i] + delta : kInvalidOff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(xt + i * RPP * 128), 16, (int)off, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) {
+        const uint32_t ok = chunk_ok & (xmask[i] >> tap) & 1u;
+        const uint32_t off = ok ? xbase[NSRC - 1][i] + delta : kInvalidOff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(xt + i * RPP * 128), 16, (int)off, 0, 0, 0);
+      }
     }
-  };
-
-  auto store_slice = [&](int stage) {
-    char* wt = smem + stage * STAGE;
-    char* xt = wt + BCO * 128;
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i) *reinterpret_cast<u32x4*>(wt + swz(r0 + i * RPP, c)) = wreg[i];
-#pragma unroll
-    for (int i = 0; i < XROWS; ++i) *reinterpret_cast<u32x4*>(xt + swz(r0 + i * RPP, c)) = xreg[i];
   };
 
   const int fr = lane & 31, fh = lane >> 5;
@@ -205,18 +230,24 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     }
   };
 
-  // ---- main loop: register-staged double buffer, one barrier per K-slice -------------------
+  // ---- main loop: two LDS stages filled by LDS-DMA, one barrier per K-slice ---------------------------
+  // iteration s:  [wait own DMA of slice s] barrier  ->  issue DMA of slice s+1 into the other stage
+  //               (free: every wave is past compute(s-1))  ->  MFMAs on slice s while the DMA flies.
   const int S = p.n_slices;
-  load_slice(0);
-  store_slice(0);
-  __syncthreads();
+  __syncthreads();                               // slice constants visible
+  SliceMeta m = meta[0];
+  issue_slice(0, m, 0);
+  m = meta[S > 1 ? 1 : 0];
   for (int s = 0; s < S; ++s) {
     const int stage = s & 1;
-    if (s + 1 < S) load_slice(s + 1);      // global loads fly under the MFMAs of slice s
+    __syncthreads();                             // hipcc drains vmcnt(0) here because LDS-DMA is in flight
+    if (s + 1 < S) {
+      issue_slice(s + 1, m, stage ^ 1);
+      m = meta[s + 2 < S ? s + 2 : s + 1];       // constants for the next issue, read a full iteration early
+    }
     compute(stage);
-    if (s + 1 < S) store_slice(stage ^ 1);
-    __syncthreads();
   }
+  __syncthreads();                               // all waves done with the last stage before it is reused
 
   // ---- epilogue: bias in registers, transpose through LDS, coalesced NHWC rows ----------------
 #pragma unroll
