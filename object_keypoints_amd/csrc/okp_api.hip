@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "okp_internal.h"
@@ -195,10 +196,13 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.weights = plan->weights_dev; p.w_bytes = plan->w_bytes; p.cout_pad = plan->cout_pad; p.bias = plan->bias_dev;
   p.slices = plan->slices_dev; p.n_slices = plan->n_slices; p.n_taps = plan->n_taps;
   p.N = a->n; p.Ho = a->ho; p.Wo = a->wo;
+  p.div_howo = okp_fastdiv((uint32_t)(a->ho * a->wo)); p.div_wo = okp_fastdiv((uint32_t)a->wo);
   p.out = a->out.data; p.OH = a->out.h; p.OW = a->out.w; p.out_step = a->out_step; p.out_oy = a->out_oy; p.out_ox = a->out_ox;
   p.out_pix_stride = a->out.pix_stride; p.cout = plan->cout;
   p.res = a->res.data; p.res_pix_stride = a->res.pix_stride; p.act = plan->act;
   for (int t = 0; t < plan->n_taps; ++t) p.taps[t] = plan->taps[t];
+  static const int dbg = getenv("OKP_DEBUG") ? atoi(getenv("OKP_DEBUG")) : 0;
+  p.debug = dbg;
   return okp_launch_igemm(plan, p, a->tile, (hipStream_t)stream);
 }
 

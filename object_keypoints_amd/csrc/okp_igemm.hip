@@ -70,6 +70,10 @@ template <> struct Io<__bf16> {
   }
 };
 
+__device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
+  return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
+}
+
 __device__ __forceinline__ uint32_t swz(int row, int chunk) {   // byte offset of a 16-B chunk in a [row][128 B] tile
   return (uint32_t)row * 128u + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
 }
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     const int pix = px0 + r0 + i * RPP;
     const bool valid = pix < P;
     const int pp = valid ? pix : 0;
-    const int n = pp / HoWo;
+    const int n = fastdiv(pp, p.div_howo);
     const int rem = pp - n * HoWo;
-    const int ho = rem / p.Wo;
+    const int ho = fastdiv(rem, p.div_wo);
     const int wo = rem - ho * p.Wo;
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
@@ -180,21 +184,24 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // Issue the LDS-DMA gather of slice `s` (constants `m`) into `stage`.  Masked lanes (padding halo, rows
-  // beyond the problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then
-  // writes zeros to LDS (verified by scripts/hwtests/dma_oob.hip).
-  auto issue_slice = [&](int s, const SliceMeta& m, int stage) {
+  // LDS-DMA gather of slice `s` (constants `m`) into `stage`, in two parts so that the issue slots can be
+  // interleaved with the MFMAs of the slice being computed.  Masked lanes (padding halo, rows beyond the
+  // problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then writes zeros
+  // to LDS (verified by scripts/hwtests/dma_oob.hip).
+  auto issue_w = [&](int s, int stage) {
+    const uint32_t wslice = (uint32_t)s * (uint32_t)p.cout_pad * 128u;
+    char* const wt = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * 128), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+  };
+  auto issue_x = [&](const SliceMeta& m, int stage) {
     const bool hi_half = c >= 4;
     const uint32_t delta = (uint32_t)(hi_half ? m.d_hi : m.d_lo);
     const uint32_t tap = hi_half ? ((m.packed >> 8) & 0xffu) : (m.packed & 0xffu);
     const uint32_t chunk_ok = ((uint32_t)c < ((m.packed >> 16) & 0xffu)) ? 1u : 0u;
     const int src = (NSRC == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(m.packed >> 24));
-    const uint32_t wslice = (uint32_t)s * (uint32_t)p.cout_pad * 128u;
-    char* const wt = smem + stage * STAGE + wave * 1024;
-    char* const xt = wt + BCO * 128;
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * 128), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+    char* const xt = smem + stage * STAGE + BCO * 128 + wave * 1024;
     if (NSRC == 1 || src == 0) {
 #pragma unroll
       for (int i = 0; i < XROWS; ++i) {
@@ -213,43 +220,56 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   };
 
   const int fr = lane & 31, fh = lane >> 5;
-  auto compute = [&](int stage) {
+  auto load_frag = [&](int stage, int kk, u32x4 (&a)[TCO], u32x4 (&b)[TPX]) {
     const char* wt = smem + stage * STAGE;
     const char* xt = wt + BCO * 128;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      u32x4 a[TCO], b[TPX];
+    for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz((wco * TCO + i) * 32 + fr, 2 * kk + fh));
 #pragma unroll
-      for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz((wco * TCO + i) * 32 + fr, 2 * kk + fh));
+    for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz((wpx * TPX + j) * 32 + fr, 2 * kk + fh));
+  };
+  auto mma_step = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX]) {
 #pragma unroll
-      for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz((wpx * TPX + j) * 32 + fr, 2 * kk + fh));
+    for (int i = 0; i < TCO; ++i)
 #pragma unroll
-      for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPX; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
-    }
+      for (int j = 0; j < TPX; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
   };
 
   // ---- main loop: two LDS stages filled by LDS-DMA, one barrier per K-slice ---------------------------
-  // iteration s:  [wait own DMA of slice s] barrier  ->  issue DMA of slice s+1 into the other stage
-  //               (free: every wave is past compute(s-1))  ->  MFMAs on slice s while the DMA flies.
+  // iteration s:  [own DMA of slice s drained] barrier -> fragments of k-steps 0/1 -> DMA of slice s+1 into the
+  // other stage (free: every wave is past slice s-1), issued in the shadow of the first MFMA groups -> remaining
+  // k-steps.  Fragment registers are double-buffered so LDS latency hides behind the previous k-step's MFMAs.
   const int S = p.n_slices;
   __syncthreads();                               // slice constants visible
   SliceMeta m = meta[0];
-  issue_slice(0, m, 0);
+  issue_w(0, 0);
+  issue_x(m, 0);
   m = meta[S > 1 ? 1 : 0];
   for (int s = 0; s < S; ++s) {
     const int stage = s & 1;
+    const bool more = (s + 1 < S) && !(p.debug & 1);
     __syncthreads();                             // hipcc drains vmcnt(0) here because LDS-DMA is in flight
-    if (s + 1 < S) {
-      issue_slice(s + 1, m, stage ^ 1);
-      m = meta[s + 2 < S ? s + 2 : s + 1];       // constants for the next issue, read a full iteration early
+    if (p.debug & 2) {
+      if (more) { issue_w(s + 1, stage ^ 1); issue_x(m, stage ^ 1); m = meta[s + 2 < S ? s + 2 : s + 1]; }
+      continue;
     }
-    compute(stage);
+    u32x4 a0[TCO], b0[TPX], a1[TCO], b1[TPX];
+    load_frag(stage, 0, a0, b0);
+    load_frag(stage, 1, a1, b1);
+    if (more) issue_w(s + 1, stage ^ 1);
+    mma_step(a0, b0);
+    load_frag(stage, 2, a0, b0);
+    if (more) issue_x(m, stage ^ 1);
+    mma_step(a1, b1);
+    load_frag(stage, 3, a1, b1);
+    if (more) m = meta[s + 2 < S ? s + 2 : s + 1];   // constants for the next issue, read a full iteration early
+    mma_step(a0, b0);
+    mma_step(a1, b1);
   }
   __syncthreads();                               // all waves done with the last stage before it is reused
 
   // ---- epilogue: bias in registers, transpose through LDS, coalesced NHWC rows ----------------
+  if (p.debug & 4) return;
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wpx == pass) {
@@ -282,9 +302,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q) ^ (prow & 7)) << 4));
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q + 1) ^ (prow & 7)) << 4));
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int n = pix / HoWo;
+        const int n = fastdiv(pix, p.div_howo);
         const int rem = pix - n * HoWo;
-        const int ho = rem / p.Wo;
+        const int ho = fastdiv(rem, p.div_wo);
         const int wo = rem - ho * p.Wo;
         const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + p.out_oy)) * p.OW + (size_t)(wo * p.out_step + p.out_ox);
         if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);

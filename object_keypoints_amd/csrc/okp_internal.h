@@ -25,6 +25,20 @@ struct OkpTapDev {
   int32_t dy, dx, src, pad;
 };
 
+// x / d for 0 <= x < 2^31 and a divisor fixed per launch: q = umulhi(x, mul) >> shift (mul == 0: d == 1).
+struct OkpFastDiv {
+  uint32_t mul, shift;
+};
+inline OkpFastDiv okp_fastdiv(uint32_t d) {
+  OkpFastDiv f{0u, 0u};
+  if (d <= 1) return f;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;                   // ceil(log2 d) >= 1
+  f.mul = (uint32_t)((1ull << (31 + s)) / d + 1); // < 2^32 because d > 2^(s-1)
+  f.shift = s - 1;
+  return f;
+}
+
 struct OkpIgemmParams {
   const void* src[2];
   uint32_t src_bytes[2];
@@ -37,6 +51,7 @@ struct OkpIgemmParams {
   int32_t n_slices;
   int32_t n_taps;
   int32_t N, Ho, Wo;
+  OkpFastDiv div_howo, div_wo;
   void* out;
   int32_t OH, OW, out_step, out_oy, out_ox, out_pix_stride;
   int32_t cout;
@@ -44,6 +59,7 @@ struct OkpIgemmParams {
   int32_t res_pix_stride;
   int32_t act;
   int32_t n_co_tiles;
+  int32_t debug;           // timing experiments only (OKP_DEBUG): 1 = no DMA after slice 0, 2 = no MFMA
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 
