@@ -89,7 +89,16 @@ typedef struct okp_conv_args {
   okp_tensor out;                  /* out.h/out.w are the FULL output tensor's spatial size */
   int32_t out_step, out_oy, out_ox;/* sub-pixel placement (1,0,0 for ordinary convs) */
   okp_tensor res;                  /* optional residual, same spatial mapping as out; data==NULL if none */
-  int32_t tile;                    /* 0 = auto, else 1 (64x64), 2 (128x128), 3 (256x256) */
+  int32_t tile;                    /* 0 = auto, else 1 (64x64), 2 (128x128), 3 (256x256), 4 (128x256, 2 workgroups/CU) */
+  /* Optional fused depth-wise branch (the fire-module tail, CornerNet_Squeeze.py:15-17,25-30): the same launch
+   * also computes  dw_out[..., c] = act(dw_bias[c] + dw_res[..., c] + sum_{3x3 taps} dw_w[tap][c] * src[0][..., c])
+   * for c in [0, cout) with the plan's conv_stride[0] and pad 1, so that `expand 1x1 || depth-wise 3x3` of one
+   * squeeze tensor is ONE kernel.  dw_w_dev: DEVICE fp32 [9][cout]; dw_bias_dev: DEVICE fp32 [cout];
+   * dw_out / dw_res: views with the spatial mapping of out / res.  dw_w_dev == NULL disables the branch. */
+  const float* dw_w_dev;
+  const float* dw_bias_dev;
+  okp_tensor dw_out;
+  okp_tensor dw_res;
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
@@ -97,6 +106,23 @@ int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stre
 int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* args);
 /* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
 int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
+
+/* ------------------------------------------------------------------------------------
+ * Whole fire module in ONE launch (bf16): squeeze 1x1 (+bn1) -> [expand 1x1 || depth-wise 3x3] (+bn2) -> (+x) -> ReLU,
+ * the squeeze tensor staying in LDS (fire_module.forward, corner_net_lite/core/models/CornerNet_Squeeze.py:22-30).
+ * squeeze: 1-tap plan cin -> mid (bias = folded bn1, no activation); expand: 1-tap plan mid -> half (bias = first half
+ * of folded bn2); dw_w_dev [9][half] / dw_bias_dev [half]: depth-wise weights with the second half of bn2 folded.
+ * cin and mid multiples of 64, mid == half <= 256.  out has 2*half channels: [expand | depth-wise].
+ * ---------------------------------------------------------------------------------- */
+typedef struct okp_fire_args {
+  int32_t n;
+  okp_tensor x;        /* input, cin channels */
+  okp_tensor out;      /* output, 2*half channels, spatial size ceil(h/stride) x ceil(w/stride) */
+  int32_t stride;      /* 1 or 2 (applies to both branches) */
+  int32_t skip;        /* 1: add x (needs stride 1 and cin == 2*half) */
+} okp_fire_args;
+int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const float* dw_w_dev, const float* dw_bias_dev,
+                     const okp_fire_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Depth-wise 3x3 convolution (pad 1, stride 1|2) + bias + optional residual + activation.

@@ -31,7 +31,12 @@ class okp_conv_args(Structure):
     _fields_ = [("n", c_int32), ("ho", c_int32), ("wo", c_int32),
                 ("src", okp_tensor * 2), ("out", okp_tensor),
                 ("out_step", c_int32), ("out_oy", c_int32), ("out_ox", c_int32),
-                ("res", okp_tensor), ("tile", c_int32)]
+                ("res", okp_tensor), ("tile", c_int32),
+                ("dw_w_dev", c_void_p), ("dw_bias_dev", c_void_p), ("dw_out", okp_tensor), ("dw_res", okp_tensor)]
+
+
+class okp_fire_args(Structure):
+    _fields_ = [("n", c_int32), ("x", okp_tensor), ("out", okp_tensor), ("stride", c_int32), ("skip", c_int32)]
 
 
 class okp_head_out_args(Structure):
@@ -56,6 +61,7 @@ SIGNATURES = [
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),
+    ("okp_fire_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(okp_fire_args), c_void_p]),
     ("okp_dwconv3x3_forward", c_int, [c_int, c_int32, c_int32, c_int32, POINTER(okp_tensor), c_void_p, c_void_p, POINTER(okp_tensor), POINTER(okp_tensor), c_int, c_void_p]),
     ("okp_pack_frames", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     ("okp_head_out_forward", c_int, [c_int, POINTER(okp_head_out_args), c_void_p]),

@@ -19,7 +19,10 @@ OBJ_DIR = os.path.join(REPO, "build", "okp")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
-          "-Wall", "-Wno-unused-function"]
+          "-Wall", "-Wno-unused-function",
+          # keep MFMA accumulators in arch VGPRs: with 256-thread workgroups hipcc otherwise allocates them as
+          # AGPRs and copies all of them to and from VGPRs around every K-step (v_accvgpr_write/read x 128)
+          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _sources():

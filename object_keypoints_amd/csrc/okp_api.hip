@@ -183,7 +183,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   }
   if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
   if (a->res.data && (a->res.h != a->out.h || a->res.w != a->out.w)) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
-  if (a->tile < 0 || a->tile > 3) { okp_set_error("okp_conv_forward: tile %d", a->tile); return OKP_EINVAL; }
+  if (a->tile < 0 || a->tile > 4) { okp_set_error("okp_conv_forward: tile %d", a->tile); return OKP_EINVAL; }
 
   OkpIgemmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -201,8 +201,15 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.out_pix_stride = a->out.pix_stride; p.cout = plan->cout;
   p.res = a->res.data; p.res_pix_stride = a->res.pix_stride; p.act = plan->act;
   for (int t = 0; t < plan->n_taps; ++t) p.taps[t] = plan->taps[t];
-  static const int dbg = getenv("OKP_DEBUG") ? atoi(getenv("OKP_DEBUG")) : 0;
-  p.debug = dbg;
+  if (a->dw_w_dev) {
+    if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
+    if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }
+    if (int e = check_view("dw_out", a->dw_out, esz, true)) return e;
+    if (int e = check_view("dw_res", a->dw_res, esz, false)) return e;
+    if (a->dw_out.h != a->out.h || a->dw_out.w != a->out.w || a->dw_out.pix_stride < plan->cout) { okp_set_error("okp_conv_forward: dw_out does not match out"); return OKP_EINVAL; }
+    p.dw_w = a->dw_w_dev; p.dw_bias = a->dw_bias_dev; p.dw_out = a->dw_out.data; p.dw_res = a->dw_res.data;
+    p.dw_out_pix_stride = a->dw_out.pix_stride; p.dw_res_pix_stride = a->dw_res.pix_stride;
+  }
   return okp_launch_igemm(plan, p, a->tile, (hipStream_t)stream);
 }
 

@@ -15,6 +15,8 @@
 //
 // Reference semantics being computed: torch conv2d/conv_transpose2d + eval-mode batch_norm
 // (folded into W/bias) + add + relu — see include/okp.h for the file:line list.
+#include <cstdlib>
+
 #include "okp_internal.h"
 
 namespace {
@@ -74,8 +76,13 @@ __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
 }
 
-__device__ __forceinline__ uint32_t swz(int row, int chunk) {   // byte offset of a 16-B chunk in a [row][128 B] tile
-  return (uint32_t)row * 128u + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
+// Byte offset of a 16-B chunk in a [row][KB bytes] LDS tile.  The chunk index is XOR-swizzled with row bits so
+// that the 16 rows a ds_read_b128 lane group touches fall on 16 different 16-B slots of the 256-B bank row:
+// 128-B rows (2 per bank row) use (row>>1)&7, 64-B rows (4 per bank row) use (row>>2)&3.
+template <int KB>
+__device__ __forceinline__ uint32_t swz(int row, int chunk) {
+  if constexpr (KB == 128) return (uint32_t)row * 128u + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
+  else return (uint32_t)row * 64u + (uint32_t)((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
 struct SliceMeta {            // per-slice gather constants, built once per workgroup in LDS
@@ -86,17 +93,22 @@ struct SliceMeta {            // per-slice gather constants, built once per work
 constexpr int kMetaMax = 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, int BCO, int BPX, int WCO, int WPX, int NSRC>
+template <typename T, int BCO, int BPX, int WCO, int WPX, int NS, int KB, int NSRC>
 __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgemmParams p) {
   constexpr int NT = 64 * WCO * WPX;
   constexpr int ESZ = (int)sizeof(T);
-  constexpr int RPP = NT / 8;                 // tile rows covered by one loader pass (8 chunks per row)
+  static_assert(KB == 128 || KB == 64, "LDS row = one 128-byte K-slice or half of one");
+  constexpr int CPR = KB / 16;                // 16-B chunks per LDS row
+  constexpr int HPS = 128 / KB;               // ring steps per 128-byte K-slice
+  constexpr int KSTEPS = KB / 32;             // 32x32 MFMA k-steps per ring step (16 bf16 / 8 fp32 of K each)
+  constexpr int RPP = NT / CPR;               // tile rows covered by one loader pass
   constexpr int WROWS = BCO / RPP;
   constexpr int XROWS = BPX / RPP;
   constexpr int TCO = BCO / WCO / 32;
   constexpr int TPX = BPX / WPX / 32;
-  constexpr int STAGE = (BCO + BPX) * 128;
-  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int STAGE = (BCO + BPX) * KB;
+  constexpr int LDS_BYTES = NS * STAGE;        // NS-deep ring of stages
+  static_assert(NS >= 2, "ring depth");
   constexpr int PASSES = (BPX * BCO * 4 > LDS_BYTES) ? 2 : 1;
   static_assert(RPP % 16 == 0, "loader swizzle assumes the pass height keeps (row>>1)&7");
   static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
@@ -112,17 +124,14 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave / WPX, wpx = wave % WPX;
-  const int co_tile = blockIdx.x % p.n_co_tiles;
-  const int px_tile = blockIdx.x / p.n_co_tiles;
-  const int co0 = co_tile * BCO, px0 = px_tile * BPX;
   const int HoWo = p.Ho * p.Wo;
   const int P = p.N * HoWo;
 
   // Loader geometry.  One `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B = 8 tile rows linearly into LDS,
   // so lane (row r0 = tid>>3, position tid&7) must FETCH the logical chunk that the read-side swizzle expects
   // at that position: c = pos ^ ((row>>1)&7)  (swizzle on the source address, linear destination).
-  const int r0 = tid >> 3;
-  const int c = (tid & 7) ^ ((r0 >> 1) & 7);
+  const int r0 = tid / CPR;
+  const int c = (KB == 128) ? ((tid & 7) ^ ((r0 >> 1) & 7)) : ((tid & 3) ^ ((r0 >> 2) & 3));
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[0]), 0, (int)p.src_bytes[0], 0x00020000);
@@ -141,6 +150,19 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     m.pad = 0;
     meta[s] = m;
   }
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int S = p.n_slices;
+  __syncthreads();                               // slice constants visible
+
+  // ---- persistent tile loop: the grid is sized to the resident workgroups; a workgroup walks tiles
+  // blockIdx.x, +gridDim.x, ...  The epilogue's stores are fire-and-forget, so they drain to HBM while the
+  // next tile's gather and MFMAs run (a one-tile-per-workgroup grid leaves the matrix cores idle during the
+  // chip-wide write burst, and pays prologue + first-DMA latency once per tile).
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+  const int co_tile = tile % p.n_co_tiles;
+  const int px_tile = tile / p.n_co_tiles;
+  const int co0 = co_tile * BCO, px0 = px_tile * BPX;
 
   // ---- per-thread row state -------------------------------------------------------------
   uint32_t wbase[WROWS];
@@ -163,7 +185,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
     for (int s = 0; s < NSRC; ++s) {
       const int hi0 = ho * p.conv_stride[s], wi0 = wo * p.conv_stride[s];
-      xbase[s][i] = (uint32_t)(((n * p.srcH[s] + hi0) * p.srcW[s] + wi0) * p.src_pix_stride[s]) * (uint32_t)ESZ + (uint32_t)(c & 3) * 16u;
+      xbase[s][i] = (uint32_t)(((n * p.srcH[s] + hi0) * p.srcW[s] + wi0) * p.src_pix_stride[s]) * (uint32_t)ESZ + (uint32_t)(c & 3) * 16u;   // KB == 64: c < 4
     }
     uint32_t m = 0;
     for (int t = 0; t < p.n_taps; ++t) {
@@ -188,45 +210,46 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // interleaved with the MFMAs of the slice being computed.  Masked lanes (padding halo, rows beyond the
   // problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then writes zeros
   // to LDS (verified by scripts/hwtests/dma_oob.hip).
-  auto issue_w = [&](int s, int stage) {
-    const uint32_t wslice = (uint32_t)s * (uint32_t)p.cout_pad * 128u;
+  auto issue_w = [&](int t, int stage) {       // t = ring step = slice * HPS + half
+    const uint32_t wslice = (uint32_t)(t / HPS) * (uint32_t)p.cout_pad * 128u + (uint32_t)(t % HPS) * 64u;
     char* const wt = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * 128), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * KB), 16, (int)(wbase[i] + wslice), 0, 0, 0);
   };
-  auto issue_x = [&](const SliceMeta& m, int stage) {
-    const bool hi_half = c >= 4;
+  auto issue_x = [&](int t, const SliceMeta& m, int stage) {
+    const int half = t % HPS;                                    // KB == 64: which 64-byte half of the slice
+    const bool hi_half = (KB == 128) ? (c >= 4) : (half != 0);
     const uint32_t delta = (uint32_t)(hi_half ? m.d_hi : m.d_lo);
     const uint32_t tap = hi_half ? ((m.packed >> 8) & 0xffu) : (m.packed & 0xffu);
-    const uint32_t chunk_ok = ((uint32_t)c < ((m.packed >> 16) & 0xffu)) ? 1u : 0u;
+    const uint32_t cidx = (KB == 128) ? (uint32_t)c : (uint32_t)(half * 4 + c);
+    const uint32_t chunk_ok = (cidx < ((m.packed >> 16) & 0xffu)) ? 1u : 0u;
     const int src = (NSRC == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(m.packed >> 24));
-    char* const xt = smem + stage * STAGE + BCO * 128 + wave * 1024;
+    char* const xt = smem + stage * STAGE + BCO * KB + wave * 1024;
     if (NSRC == 1 || src == 0) {
 #pragma unroll
       for (int i = 0; i < XROWS; ++i) {
         const uint32_t ok = chunk_ok & (xmask[i] >> tap) & 1u;
         const uint32_t off = ok ? xbase[0][i] + delta : kInvalidOff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(xt + i * RPP * 128), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)(xt + i * RPP * KB), 16, (int)off, 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < XROWS; ++i) {
         const uint32_t ok = chunk_ok & (xmask[i] >> tap) & 1u;
         const uint32_t off = ok ? xbase[NSRC - 1][i] + delta : kInvalidOff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(xt + i * RPP * 128), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)(xt + i * RPP * KB), 16, (int)off, 0, 0, 0);
       }
     }
   };
 
-  const int fr = lane & 31, fh = lane >> 5;
   auto load_frag = [&](int stage, int kk, u32x4 (&a)[TCO], u32x4 (&b)[TPX]) {
     const char* wt = smem + stage * STAGE;
-    const char* xt = wt + BCO * 128;
+    const char* xt = wt + BCO * KB;
 #pragma unroll
-    for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz((wco * TCO + i) * 32 + fr, 2 * kk + fh));
+    for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>((wco * TCO + i) * 32 + fr, 2 * kk + fh));
 #pragma unroll
-    for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz((wpx * TPX + j) * 32 + fr, 2 * kk + fh));
+    for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz<KB>((wpx * TPX + j) * 32 + fr, 2 * kk + fh));
   };
   auto mma_step = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX]) {
 #pragma unroll
@@ -235,41 +258,50 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       for (int j = 0; j < TPX; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
   };
 
-  // ---- main loop: two LDS stages filled by LDS-DMA, one barrier per K-slice ---------------------------
-  // iteration s:  [own DMA of slice s drained] barrier -> fragments of k-steps 0/1 -> DMA of slice s+1 into the
-  // other stage (free: every wave is past slice s-1), issued in the shadow of the first MFMA groups -> remaining
-  // k-steps.  Fragment registers are double-buffered so LDS latency hides behind the previous k-step's MFMAs.
-  const int S = p.n_slices;
-  __syncthreads();                               // slice constants visible
-  SliceMeta m = meta[0];
-  issue_w(0, 0);
-  issue_x(m, 0);
-  m = meta[S > 1 ? 1 : 0];
-  for (int s = 0; s < S; ++s) {
-    const int stage = s & 1;
-    const bool more = (s + 1 < S) && !(p.debug & 1);
-    __syncthreads();                             // hipcc drains vmcnt(0) here because LDS-DMA is in flight
-    if (p.debug & 2) {
-      if (more) { issue_w(s + 1, stage ^ 1); issue_x(m, stage ^ 1); m = meta[s + 2 < S ? s + 2 : s + 1]; }
-      continue;
+  // ---- main loop: NS-deep LDS ring filled by LDS-DMA, one barrier per ring step -------------------------
+  // A ring step is KB bytes of K per row (a whole 128-byte slice, or one 64-byte half).  NS-1 steps are in flight
+  // ahead of the MFMAs.  Step t: wait (counted vmcnt) until this wave's DMA of step t has landed, barrier (=> every
+  // wave's part has landed AND every wave is past step t-1, so its stage is free), issue step t+NS-1 into that
+  // stage in the shadow of the first MFMA groups, compute step t.  Fragment registers are double-buffered.
+  constexpr int NDMA = WROWS + XROWS;            // LDS-DMA instructions per ring step per wave
+  const int T_ = S * HPS;
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) {
+    if (j < T_) {
+      const SliceMeta mj = meta[j / HPS];
+      issue_w(j, j);
+      issue_x(j, mj, j);
     }
+  }
+  int st_c = 0, st_i = NS - 1;                   // stage being computed / stage being filled
+  SliceMeta m = meta[(NS - 1 < T_ ? NS - 1 : 0) / HPS];
+  for (int t = 0; t < T_; ++t) {
+    const int nxt = t + NS - 1;
+    const bool more = nxt < T_;
+    // steps t+1 .. t+NS-2 may stay in flight; in the tail fewer were issued, so drain completely
+    if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     u32x4 a0[TCO], b0[TPX], a1[TCO], b1[TPX];
-    load_frag(stage, 0, a0, b0);
-    load_frag(stage, 1, a1, b1);
-    if (more) issue_w(s + 1, stage ^ 1);
+    load_frag(st_c, 0, a0, b0);
+    load_frag(st_c, 1, a1, b1);
+    if (more) issue_w(nxt, st_i);
     mma_step(a0, b0);
-    load_frag(stage, 2, a0, b0);
-    if (more) issue_x(m, stage ^ 1);
+    if constexpr (KSTEPS > 2) load_frag(st_c, 2, a0, b0);
+    if (more) issue_x(nxt, m, st_i);
     mma_step(a1, b1);
-    load_frag(stage, 3, a1, b1);
-    if (more) m = meta[s + 2 < S ? s + 2 : s + 1];   // constants for the next issue, read a full iteration early
-    mma_step(a0, b0);
-    mma_step(a1, b1);
+    if constexpr (KSTEPS > 2) {
+      load_frag(st_c, 3, a1, b1);
+      mma_step(a0, b0);
+      mma_step(a1, b1);
+    }
+    m = meta[(nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];   // constants for the next issue, read a step early
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
   }
   __syncthreads();                               // all waves done with the last stage before it is reused
 
   // ---- epilogue: bias in registers, transpose through LDS, coalesced NHWC rows ----------------
-  if (p.debug & 4) return;
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wpx == pass) {
@@ -315,30 +347,107 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         Io<T>::store8(v, static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ);
       }
     }
-    if (pass + 1 < PASSES) __syncthreads();
+    __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
+
+  // ---- optional fused depth-wise 3x3 branch over the same pixels / channel range (fire-module tail) -------
+  // Branch-free: the nine 16-byte taps of an item are buffer loads whose offset is pushed out of range when the
+  // tap falls in the zero padding, so all nine are in flight together (L2-hot: the GEMM just streamed this tensor).
+  if (p.dw_w) {
+    constexpr int VN = 16 / ESZ;
+    constexpr int CG = BCO / VN;
+    for (int it = tid; it < BPX * CG; it += NT) {
+      const int cq = it % CG;
+      const int pix = px0 + it / CG;
+      const int ch = co0 + cq * VN;
+      if (pix < P && ch < p.cout) {
+        const int n = fastdiv(pix, p.div_howo);
+        const int rem = pix - n * HoWo;
+        const int ho = fastdiv(rem, p.div_wo);
+        const int wo = rem - ho * p.Wo;
+        const int cs = p.conv_stride[0], H = p.srcH[0], W = p.srcW[0], ps = p.src_pix_stride[0];
+        u32x4 tapv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int hi = ho * cs + k / 3 - 1, wi = wo * cs + k % 3 - 1;
+          const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+          const uint32_t off = ok ? (uint32_t)(((n * H + hi) * W + wi) * ps + ch) * (uint32_t)ESZ : kInvalidOff;
+          tapv[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x0, (int)off, 0, 0);
+        }
+        float v[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = p.dw_bias[ch + e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float* wk = p.dw_w + k * p.cout + ch;
+          if constexpr (ESZ == 2) {
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, tapv[k]);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = fmaf((float)xv[e], wk[e], v[e]);
+          } else {
+            const f32x4 xv = __builtin_bit_cast(f32x4, tapv[k]);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = fmaf(xv[e], wk[e], v[e]);
+          }
+        }
+        const size_t opix = ((size_t)n * p.OH + (size_t)(ho + p.out_oy)) * p.OW + (size_t)(wo + p.out_ox);
+        if (p.dw_res) {
+          const char* rp = static_cast<const char*>(p.dw_res) + (opix * p.dw_res_pix_stride + ch) * ESZ;
+          if constexpr (ESZ == 2) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += (float)r[e];
+          } else {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += r[e];
+          }
+        }
+        if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        char* op = static_cast<char*>(p.dw_out) + (opix * p.dw_out_pix_stride + ch) * ESZ;
+        if constexpr (ESZ == 2) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < VN; ++e) o[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x8*>(op) = o;
+        } else {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op) = o;
+        }
+      }
+    }
+  }
+  }  // tile loop
 }
 
-template <typename T, int BCO, int BPX, int WCO, int WPX>
+template <typename T, int BCO, int BPX, int WCO, int WPX, int NS, int KB>
 int launch_cfg(const okp_conv* plan, OkpIgemmParams p, hipStream_t stream) {
   const int P = p.N * p.Ho * p.Wo;
   p.n_co_tiles = (p.cout_pad + BCO - 1) / BCO;
   const int n_px_tiles = (P + BPX - 1) / BPX;
-  const dim3 grid((unsigned)(p.n_co_tiles * n_px_tiles));
+  p.n_tiles = p.n_co_tiles * n_px_tiles;
+  constexpr int kLds = NS * (BCO + BPX) * KB + kMetaMax * (int)sizeof(SliceMeta);
+  constexpr int kPerCu = (160 * 1024 / kLds) < 1 ? 1 : (160 * 1024 / kLds > 4 ? 4 : 160 * 1024 / kLds);
+  const int resident = 256 * kPerCu;              // MI355X: 256 CUs
+  const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident));
   const dim3 block(64 * WCO * WPX);
   if (plan->n_src == 1)
-    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, 1>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, NS, KB, 1>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, 2>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((okp_igemm_kernel<T, BCO, BPX, WCO, WPX, NS, KB, 2>), grid, block, 0, stream, p);
   return okp_check_hip(hipGetLastError(), "okp_igemm launch");
 }
 
 template <typename T>
 int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
-    case 3: return launch_cfg<T, 256, 256, 4, 2>(plan, p, stream);
-    case 2: return launch_cfg<T, 128, 128, 2, 2>(plan, p, stream);
-    default: return launch_cfg<T, 64, 64, 2, 2>(plan, p, stream);
+    case 4: return launch_cfg<T, 128, 256, 2, 2, 3, 64>(plan, p, stream);     // 2 workgroups per CU, half-slice ring
+    case 3: return launch_cfg<T, 256, 256, 4, 2, 2, 128>(plan, p, stream);
+    case 2: return launch_cfg<T, 128, 128, 2, 2, 2, 128>(plan, p, stream);
+    default: return launch_cfg<T, 64, 64, 2, 2, 4, 128>(plan, p, stream);
   }
 }
 

@@ -59,8 +59,23 @@ struct OkpIgemmParams {
   int32_t res_pix_stride;
   int32_t act;
   int32_t n_co_tiles;
-  int32_t debug;           // timing experiments only (OKP_DEBUG): 1 = no DMA after slice 0, 2 = no MFMA
+  const float* dw_w;       // fused depth-wise branch (NULL = off)
+  const float* dw_bias;
+  void* dw_out;
+  const void* dw_res;
+  int32_t dw_out_pix_stride, dw_res_pix_stride;
+  int32_t n_tiles;
   OkpTapDev taps[OKP_MAX_TAPS];
+};
+
+struct OkpFireParams {
+  const void* x; uint32_t x_bytes; int32_t H, W, x_ps;
+  void* out; int32_t Ho, Wo, out_ps;
+  int32_t N, stride, skip, cin, mid, half;
+  const void* w1; uint32_t w1_bytes; int32_t w1_cout_pad; const float* b1;
+  const void* wa; uint32_t wa_bytes; int32_t wa_cout_pad; const float* ba;
+  const float* wd; const float* bd;
+  int32_t SH, SW, IH, IW, FR, tiles_y, tiles_x;
 };
 
 struct okp_conv {

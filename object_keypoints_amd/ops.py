@@ -118,7 +118,8 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
-    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0):
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None):
+        """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch."""
         a = _lib.okp_conv_args()
         a.n, a.ho, a.wo = out.n, ho, wo
         for i, s in enumerate(srcs):
@@ -131,6 +132,14 @@ class ConvPlan:
         a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
         a.res = res.view() if res is not None else _NULL_TENSOR
         a.tile = tile or FORCE_TILE
+        if dw is not None:
+            dw_w, dw_b, dw_out, dw_res = dw
+            a.dw_w_dev, a.dw_bias_dev = dw_w.data_ptr(), dw_b.data_ptr()
+            a.dw_out = dw_out.view()
+            a.dw_res = dw_res.view() if dw_res is not None else _NULL_TENSOR
+            macs_dw = out.n * ho * wo * self.cout * 9
+        else:
+            macs_dw = 0
         macs = out.n * ho * wo * self.cout * self.alg_k
         hook = LAUNCH_HOOK
         if hook is not None:
@@ -139,13 +148,30 @@ class ConvPlan:
         _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
         if hook is not None:
             hook.after(token)
-        COUNTERS["macs"] += macs
+        COUNTERS["macs"] += macs + macs_dw
         COUNTERS["launches"] += 1
 
 
 COUNTERS = {"macs": 0, "launches": 0}
 LAUNCH_HOOK = None      # bench.py: object with before(plan, tile, macs) / after(token) bracketing conv launches
 FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256), 0 = heuristic
+
+
+def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
+    """One-launch fire module (bf16): see okp_fire_forward in include/okp.h."""
+    a = _lib.okp_fire_args()
+    a.n = x.n
+    a.x, a.out = x.view(), out.view()
+    a.stride, a.skip = stride, 1 if skip else 0
+    _lib.check(_lib.lib().okp_fire_forward(squeeze._h, expand._h, wd_dev.data_ptr(), bd_dev.data_ptr(), ctypes.byref(a), stream_handle()),
+               "okp_fire_forward")
+    half = expand.cout
+    COUNTERS["macs"] += x.n * x.h * x.w * squeeze.cout * squeeze.cins[0] + out.n * out.h * out.w * half * (expand.cins[0] + 9)
+    COUNTERS["launches"] += 1
+
+
+FUSE_FIRE = False       # one-launch fire module (okp_fire_forward): correct, but measured slower than squeeze + fused tail
+                        # at every hourglass level in round 1 (231 vs 193 us at 64x64, N=64) - kept as an experiment
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):

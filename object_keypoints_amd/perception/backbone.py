@@ -182,13 +182,19 @@ class fire_module(_HipModule):
     def forward(self, x):
         squeeze, expand, wd, bd = self._plan(("p", x.dtype), lambda: self._build(x.dtype, x.t.device))
         half = self.out_dim // 2
+        ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
+        if (ops.FUSE_FIRE and x.dtype == torch.bfloat16 and self.inp_dim % 64 == 0 and self.mid % 64 == 0 and self.mid <= 256):
+            out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+            ops.fire_fused(squeeze, expand, wd, bd, x, out, self.stride, self.skip)
+            return out
         s = Act.empty(x.n, x.h, x.w, self.mid, x.dtype, x.t.device)
         squeeze([x], s, x.h, x.w)
         ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
         out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
-        # concat is free: both branches write their channel window of the same NHWC tensor
-        expand([s], out.slice(0, half), ho, wo, res=x.slice(0, half) if self.skip else None)
-        ops.dwconv3x3(s, wd, bd, out.slice(half, half), self.stride, res=x.slice(half, half) if self.skip else None, relu=True)
+        # concat is free: both branches write their channel window of the same NHWC tensor, and both run in ONE
+        # launch (expand GEMM + depth-wise taps of the same squeeze tile)
+        expand([s], out.slice(0, half), ho, wo, res=x.slice(0, half) if self.skip else None,
+               dw=(wd, bd, out.slice(half, half), x.slice(half, half) if self.skip else None))
         return out
 
 

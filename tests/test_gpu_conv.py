@@ -25,7 +25,7 @@ def _rand(shape, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
     (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
     (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
@@ -124,3 +124,42 @@ def test_bad_arguments_are_reported():
         ops.ConvPlan(torch.float32, [6], [1], 8, [(0, 0, 0, np.zeros((8, 6), np.float32))])   # cin not 16-byte multiple
     with pytest.raises(ops.OkpError):
         ops.Act(torch.zeros(1, 2, 2, 8))                                                        # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,n", [
+    (256, 256, 16, 16, 1, 3),      # skip, strips of full rows
+    (256, 256, 64, 64, 1, 1),      # skip, 2-D tiles with halo
+    (256, 384, 32, 32, 2, 2),      # stride 2, mid 192 (partial 128-channel chunk)
+    (384, 512, 8, 8, 2, 3),        # stride 2 to 4x4, mid 256
+    (512, 512, 4, 4, 1, 7),        # several whole frames per workgroup
+    (384, 384, 13, 9, 1, 2),       # odd sizes
+    (384, 256, 16, 16, 1, 2),      # no skip (cin != cout)
+])
+def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
+    """One-launch bf16 fire module vs the oracle's fire_module (fp32) on the same bf16-rounded input, and vs the
+    three-launch HIP path, which it must reproduce up to the bf16 rounding of the squeeze tensor."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    dev = _dev()
+    o = onet.load_synthetic(onet.fire_module(cin, cout, stride=stride), seed=21)
+    m = bb.fire_module(cin, cout, stride=stride)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    x = _rand((n, cin, h, w), 31).bfloat16().float()
+    with torch.no_grad():
+        ref = o(x)
+    xa = ops.Act.from_nchw(x.to(dev), torch.bfloat16)
+    ops.FUSE_FIRE = True
+    try:
+        l0 = ops.COUNTERS["launches"]
+        got = m(xa).to_nchw().cpu()
+        assert ops.COUNTERS["launches"] - l0 == 1
+    finally:
+        ops.FUSE_FIRE = False
+    unfused = m(xa).to_nchw().cpu()
+    scale = float(ref.abs().max())
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    assert float(err.max()) <= 0.03 * scale + 0.02, f"max err {float(err.max())} scale {scale}"
+    assert float((got - unfused).abs().max()) <= 0.02 * scale + 0.02
