@@ -170,6 +170,7 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
     COUNTERS["launches"] += 1
 
 
+SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
 FUSE_FIRE = False       # one-launch fire module (okp_fire_forward): correct, but measured slower than squeeze + fused tail
                         # at every hourglass level in round 1 (231 vs 193 us at 64x64, N=64) - kept as an experiment
 

@@ -281,9 +281,30 @@ class hg_module(nn.Module):
         self.up2 = make_unpool_layer(curr_dim)
 
     def forward(self, x):
-        up1 = self.up1(x)
-        low3 = self.low3(self.low2(self.low1(x)))      # max1 is the identity (CornerNet_Squeeze.py:32-33)
+        """up1(x) and the whole low path are independent until the merge.  The low path is a long chain of small,
+        latency-bound launches that leave most of the 256 CUs idle, so up1 runs on a side HIP stream and fills
+        them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph)."""
+        if not ops.SIDE_STREAMS:
+            up1 = self.up1(x)
+            low3 = self.low3(self.low2(self.low1(x)))  # max1 is the identity (CornerNet_Squeeze.py:32-33)
+            return self.up2(low3, up1)
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.t.device)
+        side.wait_stream(main)                          # x is ready on the side stream
+        with torch.cuda.stream(side):
+            up1 = self.up1(x)
+        x.t.record_stream(side)
+        low3 = self.low3(self.low2(self.low1(x)))
+        main.wait_stream(side)                          # join before the merge
+        up1.t.record_stream(main)
         return self.up2(low3, up1)
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
 
 
 class _MergeMod(nn.Sequential):
