@@ -72,6 +72,22 @@ class KernelTimer:
         return len(self.records), ms, flops
 
 
+def pmc_traffic(kernel_sig):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  bench.py cannot run the profiler on itself, so the number comes from profiles/ and is null if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for name, row in data.items():
+        if kernel_sig in name:
+            return (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6, os.path.basename(files[-1])
+    return None, None
+
+
 def build_net(dtype):
     from object_keypoints_amd import synth
     from object_keypoints_amd.perception.models import KeypointNet
@@ -178,6 +194,8 @@ def main():
     n_launch, k_ms, k_flops = timer.summary()
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
+    traffic, traffic_src = pmc_traffic("okp_igemm_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E" if args.dtype == "bf16"
+                                       else "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E")
     result = {
         "metric": "frames/sec keypoint inference (511x511 -> heatmaps+3D)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,7 +207,7 @@ def main():
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
         "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
         "roofline": {"bound": "mfma", "kernel": f"okp_igemm_kernel<{args.dtype},256x256,src1>", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
                      "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
                      "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None},
     }

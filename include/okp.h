@@ -142,6 +142,12 @@ int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride,
 int okp_pack_frames(int dtype, const float* frames_nchw_dev, int32_t n, int32_t h, int32_t w,
                     void* out_dev, int32_t out_w, void* stream);
 
+/* Same packing fused with the reference's frame normalisation (perception/datasets/video.py:55-56,215):
+ * uint8 RGB frames, NHWC (n,h,w,3), already resized/cropped  ->  ((u8 / 255) - mean[c]) / std[c]  in fp32 with the
+ * reference's operation order (bit-exact with NumPy float32), then packed as above.  A quarter of the fp32 H2D bytes. */
+int okp_pack_frames_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int32_t h, int32_t w,
+                       const float* mean3, const float* std3, void* out_dev, int32_t out_w, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Final 1x1 convolutions of the three heads, NHWC -> NCHW fp32, optional sigmoid per output.
  * Replaces prediction_module[-1] (perception/models.py:17) for heat/depth/centre heads and

@@ -115,6 +115,30 @@ __global__ __launch_bounds__(256) void okp_pack_frames_kernel(const float* __res
   }
 }
 
+struct NormParams { float mean[3], stdv[3]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void okp_pack_frames_u8_kernel(const uint8_t* __restrict__ in, int N, int H, int W, NormParams np,
+                                                                  T* __restrict__ out, int OHt, int OWt) {
+  const long total = (long)N * OHt * OWt;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % OWt);
+    const long t = idx / OWt;
+    const int y = (int)(t % OHt);
+    const int n = (int)(t / OHt);
+    const int sy = y - 3, sx = x - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+      const uint8_t* px = in + (((size_t)n * H + sy) * W + sx) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)      // (u8 / 255 - mean) / std, one IEEE rounding per operation as NumPy float32 does
+        v[c] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[c], 255.0f), np.mean[c]), np.stdv[c]);
+    }
+    T* o = out + idx * 4;
+    o[0] = (T)v[0]; o[1] = (T)v[1]; o[2] = (T)v[2]; o[3] = (T)0.f;
+  }
+}
+
 struct HeadParams {
   const void* src; int32_t src_ps;
   int32_t N, HW, n_out;
@@ -209,6 +233,20 @@ extern "C" int okp_pack_frames(int dtype, const float* frames, int32_t n, int32_
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (__bf16*)out, h + 6, out_w);
   else hipLaunchKernelGGL(okp_pack_frames_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (float*)out, h + 6, out_w);
   return okp_check_hip(hipGetLastError(), "okp_pack_frames launch");
+}
+
+extern "C" int okp_pack_frames_u8(int dtype, const uint8_t* frames, int32_t n, int32_t h, int32_t w, const float* mean3, const float* std3,
+                                  void* out, int32_t out_w, void* stream) {
+  if (!frames || !out || !mean3 || !std3) { okp_set_error("okp_pack_frames_u8: null argument"); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_pack_frames_u8: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (out_w < w + 6) { okp_set_error("okp_pack_frames_u8: out_w %d < w+6", out_w); return OKP_EINVAL; }
+  NormParams np;
+  for (int c = 0; c < 3; ++c) { np.mean[c] = mean3[c]; np.stdv[c] = std3[c]; }
+  const long total = (long)n * (h + 6) * out_w;
+  const int grid = grid_for(total, 256);
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (__bf16*)out, h + 6, out_w);
+  else hipLaunchKernelGGL(okp_pack_frames_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (float*)out, h + 6, out_w);
+  return okp_check_hip(hipGetLastError(), "okp_pack_frames_u8 launch");
 }
 
 extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void* stream) {

@@ -208,6 +208,29 @@ def pack_frames(frames, dtype):
     return act
 
 
+# normalisation constants of the reference's data loader (perception/datasets/video.py:55-56)
+RGB_MEAN = (0.40789654, 0.44719302, 0.47026115)
+RGB_STD = (0.28863828, 0.27408164, 0.27809835)
+
+
+def pack_frames_u8(frames, dtype, mean=RGB_MEAN, std=RGB_STD):
+    """uint8 RGB frames [N,H,W,3] (device) -> normalised, packed stem input (see okp_pack_frames_u8)."""
+    require_cuda(frames, "frames")
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise OkpError("frames must be uint8 [N,H,W,3]")
+    frames = frames.contiguous()
+    n, h, w, _ = frames.shape
+    wp = stem_packed_width(w)
+    out = torch.empty((n, h + 6, wp, 4), dtype=dtype, device=frames.device)
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    _lib.check(_lib.lib().okp_pack_frames_u8(okp_dtype(dtype), frames.data_ptr(), n, h, w, m, sd, out.data_ptr(), wp, stream_handle()), "okp_pack_frames_u8")
+    COUNTERS["launches"] += 1
+    act = Act(out)
+    act.orig_hw = (h, w)
+    return act
+
+
 def head_out(src, outputs, w_dev, bias_dev):
     """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
     a = _lib.okp_head_out_args()

@@ -130,17 +130,36 @@ class KeypointNet(_HipModule):
         ops.require_cuda(x, "frames")
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
+        if x.dtype == torch.uint8:      # raw RGB crop [N,H,W,3]: normalisation fused into the packing kernel
+            return self.backbone(ops.pack_frames_u8(x, self.compute_dtype))
         return self.backbone(ops.pack_frames(x.float(), self.compute_dtype))
+
+    def max_frames_per_pass(self, h, w):
+        """Frames per launch sequence such that the largest activation (the stem output, 128 channels at half
+        resolution) stays under the 2 GiB view limit of the 32-bit buffer offsets (include/okp.h)."""
+        esz = 2 if self.compute_dtype == torch.bfloat16 else 4
+        per_frame = ((h + 1) // 2) * ((w + 1) // 2) * 128 * esz
+        return max(1, (0x7FFF0000 - 1) // per_frame)
+
+    def _chunks(self, x):
+        h, w = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
+        step = self.max_frames_per_pass(h, w)
+        return [x[i:i + step] for i in range(0, x.shape[0], step)]
 
     def forward(self, x):
         """frames [N,3,H,W] fp32 -> ((hm1,hm2),(d1,d2),(c1,c2)), raw logits for the heat maps."""
-        feats = self._features(x)
-        h1, d1, c1 = self._run_heads(0, feats[0], sigmoid=False)
-        h2, d2, c2 = self._run_heads(1, feats[1], sigmoid=False)
+        outs = []
+        for xc in self._chunks(x):
+            feats = self._features(xc)
+            outs.append(self._run_heads(0, feats[0], sigmoid=False) + self._run_heads(1, feats[1], sigmoid=False))
+        h1, d1, c1, h2, d2, c2 = [torch.cat(t) if len(outs) > 1 else t[0] for t in zip(*outs)]
         return (h1, h2), (d1, d2), (c1, c2)
 
     def deployed(self, x):
         """What the packaged model returns (scripts/package_model.py:26-28):
         sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed."""
-        feats = self._features(x)
-        return self._run_heads(1, feats[1], sigmoid=True)
+        outs = []
+        for xc in self._chunks(x):
+            feats = self._features(xc)
+            outs.append(self._run_heads(1, feats[1], sigmoid=True))
+        return tuple(torch.cat(t) if len(outs) > 1 else t[0] for t in zip(*outs))

@@ -251,6 +251,20 @@ class BatchedKeypointPipeline:
         heat, depth, centers = self.net.deployed(frames)
         return self.postprocess_device(heat, depth, centers)
 
+    def capture(self, frames):
+        """Capture forward_device for this frame shape into a hipGraph (HIP stream capture through torch): the ~160
+        launches of a step become one graph launch, which removes the host launch cost that dominates small
+        batches (batch 8: 2.7 -> 2.2 ms per step).  Returns (graph, static_input, static_outputs); replay with
+        static_input.copy_(new_frames); graph.replay()."""
+        static_in = frames.clone()
+        for _ in range(2):                                   # warm-up: plans, allocator pools, kernel attributes
+            self.forward_device(static_in)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self.forward_device(static_in)
+        return graph, static_in, static_out
+
     def postprocess_device(self, heat, depth, centers):
         """Peaks + per-peak 3D points from (post-sigmoid) heat, depth and centre maps on the device."""
         count, yx, xyc = ops.peak_nms(heat, cap=self.capacity)

@@ -18,6 +18,16 @@ import numpy as np
 from . import geometry
 
 
+RGB_MEAN = np.array([0.40789654, 0.44719302, 0.47026115], dtype=np.float32)   # perception/datasets/video.py:55
+RGB_STD = np.array([0.28863828, 0.27408164, 0.27809835], dtype=np.float32)    # perception/datasets/video.py:56
+
+
+def normalize_frames(u8_nhwc):
+    """uint8 RGB [N,H,W,3] -> float32 [N,3,H,W], exactly the expression of perception/datasets/video.py:215."""
+    x = u8_nhwc.astype(np.float32).transpose([0, 3, 1, 2])
+    return ((x / 255.0 - RGB_MEAN[None, :, None, None]) / RGB_STD[None, :, None, None]).astype(np.float32)
+
+
 def box_sum5(p):
     """5x5 ones convolution with zero padding, accumulated in fp32 in row-major tap order — the
     association the reference's conv2d produces bit-for-bit."""
