@@ -99,6 +99,10 @@ typedef struct okp_conv_args {
   const float* dw_bias_dev;
   okp_tensor dw_out;
   okp_tensor dw_res;
+  /* Sub-pixel classes in ONE launch (transposed convolution 4x4/s2 = four 2x2 convolutions, one per output
+   * parity): with n_classes == 4 the plan's taps are four equal consecutive groups; class k uses group k only and
+   * writes to (out_oy + k/2, out_ox + k%2) with out_step 2.  0 or 1 = off. */
+  int32_t n_classes;
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);

@@ -201,6 +201,14 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.out_pix_stride = a->out.pix_stride; p.cout = plan->cout;
   p.res = a->res.data; p.res_pix_stride = a->res.pix_stride; p.act = plan->act;
   for (int t = 0; t < plan->n_taps; ++t) p.taps[t] = plan->taps[t];
+  p.n_classes = a->n_classes > 1 ? a->n_classes : 1;
+  if (p.n_classes > 1) {
+    if (p.n_classes != 4 || a->out_step != 2 || plan->n_slices % 4 || plan->n_taps % 4 || a->dw_w_dev) {
+      okp_set_error("okp_conv_forward: n_classes must be 4 with out_step 2 and four equal tap groups"); return OKP_EINVAL;
+    }
+    if ((a->ho - 1) * 2 + a->out_oy + 1 >= a->out.h || (a->wo - 1) * 2 + a->out_ox + 1 >= a->out.w) { okp_set_error("okp_conv_forward: sub-pixel classes do not fit out"); return OKP_EINVAL; }
+  }
+  p.slices_per_class = plan->n_slices / p.n_classes;
   if (a->dw_w_dev) {
     if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
     if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }

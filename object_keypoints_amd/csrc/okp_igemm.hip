@@ -192,9 +192,13 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // each other's halo rows (and the same weight slices) out of that XCD's L2.  Bijective for any tile count.
   const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
-  const int co_tile = tile % p.n_co_tiles;
-  const int px_tile = tile / p.n_co_tiles;
+  const int cls = tile / p.tiles_per_class;                  // sub-pixel class (0 unless n_classes == 4)
+  const int tile_c = tile - cls * p.tiles_per_class;
+  const int sbase = cls * p.slices_per_class;                // this class's K-slices
+  const int co_tile = tile_c % p.n_co_tiles;
+  const int px_tile = tile_c / p.n_co_tiles;
   const int co0 = co_tile * BCO, px0 = px_tile * BPX;
+  const int out_oy = p.out_oy + (cls >> 1), out_ox = p.out_ox + (cls & 1);
 
   // ---- per-thread row state -------------------------------------------------------------
   uint32_t wbase[WROWS];
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then writes zeros
   // to LDS (verified by scripts/hwtests/dma_oob.hip).
   auto issue_w = [&](int t, int stage) {       // t = ring step = slice * HPS + half
-    const uint32_t wslice = (uint32_t)(t / HPS) * (uint32_t)p.cout_pad * 128u + (uint32_t)(t % HPS) * 64u;
+    const uint32_t wslice = (uint32_t)(sbase + t / HPS) * (uint32_t)p.cout_pad * 128u + (uint32_t)(t % HPS) * 64u;
     char* const wt = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
@@ -296,17 +300,17 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // wave's part has landed AND every wave is past step t-1, so its stage is free), issue step t+NS-1 into that
   // stage in the shadow of the first MFMA groups, compute step t.  Fragment registers are double-buffered.
   constexpr int NDMA = WROWS + XROWS;            // LDS-DMA instructions per ring step per wave
-  const int T_ = S * HPS;
+  const int T_ = p.slices_per_class * HPS;
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j) {
     if (j < T_) {
-      const SliceMeta mj = meta[j / HPS];
+      const SliceMeta mj = meta[sbase + j / HPS];
       issue_w(j, j);
       issue_x(j, mj, j);
     }
   }
   int st_c = 0, st_i = NS - 1;                   // stage being computed / stage being filled
-  SliceMeta m = meta[(NS - 1 < T_ ? NS - 1 : 0) / HPS];
+  SliceMeta m = meta[sbase + (NS - 1 < T_ ? NS - 1 : 0) / HPS];
   for (int t = 0; t < T_; ++t) {
     const int nxt = t + NS - 1;
     const bool more = nxt < T_;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       mma_step(a0, b0);
       mma_step(a1, b1);
     }
-    m = meta[(nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];   // constants for the next issue, read a step early
+    m = meta[sbase + (nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];   // constants for the next issue, read a step early
     st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
   }
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         const int rem = pix - n * HoWo;
         const int ho = fastdiv(rem, p.div_wo);
         const int wo = rem - ho * p.Wo;
-        const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + p.out_oy)) * p.OW + (size_t)(wo * p.out_step + p.out_ox);
+        const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
         if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
         if (p.act == OKP_ACT_RELU) {
 #pragma unroll
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         }
       };
       auto finish = [&](float (&v)[VN], int n, int ho, int wo) {
-        const size_t opix = ((size_t)n * p.OH + (size_t)(ho + p.out_oy)) * p.OW + (size_t)(wo + p.out_ox);
+        const size_t opix = ((size_t)n * p.OH + (size_t)(ho + out_oy)) * p.OW + (size_t)(wo + out_ox);
         if (p.dw_res) {
           float r[VN];
           to_f(*reinterpret_cast<const u32x4*>(static_cast<const char*>(p.dw_res) + (opix * p.dw_res_pix_stride + ch) * ESZ), r);
@@ -513,7 +517,8 @@ int launch_cfg(const okp_conv* plan, OkpIgemmParams p, hipStream_t stream) {
   const int P = p.N * p.Ho * p.Wo;
   p.n_co_tiles = (p.cout_pad + BCO - 1) / BCO;
   const int n_px_tiles = (P + BPX - 1) / BPX;
-  p.n_tiles = p.n_co_tiles * n_px_tiles;
+  p.tiles_per_class = p.n_co_tiles * n_px_tiles;
+  p.n_tiles = p.tiles_per_class * p.n_classes;
   constexpr int kLds = NS * (BCO + BPX) * KB + kMetaMax * (int)sizeof(SliceMeta);
   constexpr int kPerCu = (160 * 1024 / kLds) < 1 ? 1 : (160 * 1024 / kLds > 4 ? 4 : 160 * 1024 / kLds);
   const int resident = 256 * kPerCu;              // MI355X: 256 CUs

@@ -65,6 +65,7 @@ struct OkpIgemmParams {
   const void* dw_res;
   int32_t dw_out_pix_stride, dw_res_pix_stride;
   int32_t n_tiles;
+  int32_t n_classes, tiles_per_class, slices_per_class;
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 

@@ -118,7 +118,7 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
-    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None):
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1):
         """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch."""
         a = _lib.okp_conv_args()
         a.n, a.ho, a.wo = out.n, ho, wo
@@ -132,6 +132,7 @@ class ConvPlan:
         a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
         a.res = res.view() if res is not None else _NULL_TENSOR
         a.tile = tile or FORCE_TILE
+        a.n_classes = n_classes
         if dw is not None:
             dw_w, dw_b, dw_out, dw_res = dw
             a.dw_w_dev, a.dw_bias_dev = dw_w.data_ptr(), dw_b.data_ptr()

@@ -212,8 +212,8 @@ class unpool_merge(_HipModule):
     Holds the transposed-conv parameters as `weight` / `bias` so that, assigned to `hg_module.up2`,
     the state_dict keys are the reference's `...up2.weight` / `...up2.bias`
     (CornerNet_Squeeze.py:35-36; merge: py_utils/utils.py:139-141, modules.py:64-65).
-    Lowered to four sub-pixel 2x2 convolutions (one per output parity), each writing its quarter
-    of the output with the `up1` tensor added in the epilogue.
+    Lowered to four sub-pixel 2x2 convolutions (one per output parity) that run as the four classes of ONE
+    launch, each writing its quarter of the output with the `up1` tensor added in the epilogue.
     """
 
     def __init__(self, dim):
@@ -228,20 +228,17 @@ class unpool_merge(_HipModule):
         b = _np(self.bias)
         # output row 2i+a gathers input rows i+dy with kernel row ky:  a=0: (0,1), (-1,3);  a=1: (1,0), (0,2)
         sel = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
-        plans = {}
-        for a in (0, 1):
-            for bb in (0, 1):
-                taps = [(0, dy, dx, np.ascontiguousarray(w[:, :, ky, kx].T)) for dy, ky in sel[a] for dx, kx in sel[bb]]
-                plans[(a, bb)] = ConvPlan(dtype, [self.dim], [1], self.dim, taps, b, relu=False)
-        return plans
+        # ONE plan, 16 taps = four groups of four; group k = 2a + bb is the sub-pixel class written at (a, bb)
+        taps = [(0, dy, dx, np.ascontiguousarray(w[:, :, ky, kx].T))
+                for a in (0, 1) for bb in (0, 1) for dy, ky in sel[a] for dx, kx in sel[bb]]
+        return ConvPlan(dtype, [self.dim], [1], self.dim, taps, b, relu=False)
 
     def forward(self, low, up1):
-        plans = self._plan(("p", low.dtype), lambda: self._build(low.dtype))
+        plan = self._plan(("p", low.dtype), lambda: self._build(low.dtype))
         if up1.h != 2 * low.h or up1.w != 2 * low.w:
             raise OkpError("unpool_merge: up1 must be twice the size of low")
         out = Act.empty(low.n, 2 * low.h, 2 * low.w, self.dim, low.dtype, low.t.device)
-        for (a, b), plan in plans.items():
-            plan([low], out, low.h, low.w, res=up1, out_step=2, oy=a, ox=b)
+        plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4)     # four output parities, one launch
         return out
 
 
