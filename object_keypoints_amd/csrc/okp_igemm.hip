@@ -144,8 +144,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   constexpr int PITCH = BCO * 4;
 
   // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta)];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta) + 1024];
   SliceMeta* const meta = reinterpret_cast<SliceMeta*>(smem + LDS_BYTES);
+  char* const bias_lds = smem + LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta);     // this tile's BCO biases (fp32)
+  static_assert(BCO <= 256, "bias staging is one 1 KiB LDS-DMA");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[0]), 0, (int)p.src_bytes[0], 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[NSRC - 1]), 0, (int)p.src_bytes[NSRC - 1], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * BCO * 4, 0x00020000);
 
   // ---- slice constants -> LDS (one thread per slice) -------------------------------------------
   for (int s = tid; s < p.n_slices; s += NT) {
@@ -200,6 +203,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   const int co0 = co_tile * BCO, px0 = px_tile * BPX;
   const int out_oy = p.out_oy + (cls >> 1), out_ox = p.out_ox + (cls & 1);
 
+  // this tile's biases -> LDS by one LDS-DMA (wave 0), consumed only in the epilogue: the load is never waited for
+  if (wave == 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16,
+                                             (int)(lane * 4 < BCO ? (uint32_t)(co0 + lane * 4) * 4u : kInvalidOff), 0, 0, 0);
+
   // ---- per-thread row state -------------------------------------------------------------
   uint32_t wbase[WROWS];
 #pragma unroll
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   }
   uint32_t xbase[NSRC][XROWS];
   uint32_t xmask[XROWS];
+  int row_ho[XROWS], row_wo[XROWS];
 #pragma unroll
   for (int i = 0; i < XROWS; ++i) {
     const int pix = px0 + r0 + i * RPP;
@@ -223,15 +232,22 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       const int hi0 = ho * p.conv_stride[s], wi0 = wo * p.conv_stride[s];
       xbase[s][i] = (uint32_t)(((n * p.srcH[s] + hi0) * p.srcW[s] + wi0) * p.src_pix_stride[s]) * (uint32_t)ESZ + (uint32_t)(c & 3) * 16u;   // KB == 64: c < 4
     }
-    uint32_t m = 0;
-    for (int t = 0; t < p.n_taps; ++t) {
-      const int s = (NSRC == 1) ? 0 : p.taps[t].src;
-      const int hi = ho * p.conv_stride[s] + p.taps[t].dy;
-      const int wi = wo * p.conv_stride[s] + p.taps[t].dx;
-      const bool ok = valid && hi >= 0 && hi < p.srcH[s] && wi >= 0 && wi < p.srcW[s];
-      m |= (ok ? 1u : 0u) << t;
+    xmask[i] = 0;
+    row_ho[i] = valid ? ho : -0x40000000;        // rows beyond the problem fail every bounds test below
+    row_wo[i] = wo;
+  }
+  // tap loop outermost: one scalar load of the tap per iteration, the rows unrolled underneath it
+  for (int t = 0; t < p.n_taps; ++t) {
+    const int s = (NSRC == 1) ? 0 : p.taps[t].src;
+    const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+    const int cs = s ? p.conv_stride[NSRC - 1] : p.conv_stride[0];       // selects, not indexing: no scratch copy
+    const int H = s ? p.srcH[NSRC - 1] : p.srcH[0], W = s ? p.srcW[NSRC - 1] : p.srcW[0];
+#pragma unroll
+    for (int i = 0; i < XROWS; ++i) {
+      const int hi = row_ho[i] * cs + dy, wi = row_wo[i] * cs + dx;
+      const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+      xmask[i] |= (ok ? 1u : 0u) << t;
     }
-    xmask[i] = m;
   }
 
   acc_t acc[TCO][TPX];
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         for (int g = 0; g < AREGS / 4; ++g) {
           // accumulator rows: 32x32 -> 8g + 4*(lane>>5) + e ; 16x16 -> 4*(lane>>4) + e  (4 consecutive channels per lane)
           const int co_l = (wco * TCO + i) * MT + (MT == 32 ? 8 * g + 4 * fh : 4 * fh);
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co0 + co_l);   // bias is padded to n_co_tiles*BCO
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + co_l * 4);
 #pragma unroll
           for (int j = 0; j < TPX; ++j) {
             const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * MT + fr;
@@ -362,26 +378,38 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     __syncthreads();
     constexpr int GROUPS = BCO / 8;
     constexpr int ITEMS = PX_PER_PASS * GROUPS;
-    for (int it = tid; it < ITEMS; it += NT) {
-      const int q = it % GROUPS;
-      const int prow = it / GROUPS;
-      const int pix = px0 + pass * PX_PER_PASS + prow;
-      const int co = co0 + q * 8;
-      if (pix < P && co < p.cout) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q) ^ (prow & 7)) << 4));
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q + 1) ^ (prow & 7)) << 4));
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int n = fastdiv(pix, p.div_howo);
-        const int rem = pix - n * HoWo;
-        const int ho = fastdiv(rem, p.div_wo);
-        const int wo = rem - ho * p.Wo;
-        const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
-        if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
-        if (p.act == OKP_ACT_RELU) {
+    constexpr int U = ITEMS / NT;                  // 16-byte output items per thread and pass
+    constexpr int UB = U >= 2 ? 2 : 1;             // items per batch: their LDS reads are in flight together
+    static_assert(ITEMS % NT == 0 && U % UB == 0, "epilogue work split");
+    for (int u0 = 0; u0 < U; u0 += UB) {
+      f32x4 v0[UB], v1[UB];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int u = 0; u < UB; ++u) {
+        const int it = tid + (u0 + u) * NT;
+        const int q = it % GROUPS, prow = it / GROUPS;
+        v0[u] = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q) ^ (prow & 7)) << 4));
+        v1[u] = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q + 1) ^ (prow & 7)) << 4));
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int it = tid + (u0 + u) * NT;
+        const int q = it % GROUPS, prow = it / GROUPS;
+        const int pix = px0 + pass * PX_PER_PASS + prow;
+        const int co = co0 + q * 8;
+        if (pix < P && co < p.cout) {
+          float v[8] = {v0[u][0], v0[u][1], v0[u][2], v0[u][3], v1[u][0], v1[u][1], v1[u][2], v1[u][3]};
+          const int n = fastdiv(pix, p.div_howo);
+          const int rem = pix - n * HoWo;
+          const int ho = fastdiv(rem, p.div_wo);
+          const int wo = rem - ho * p.Wo;
+          const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
+          if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
+          if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          Io<T>::store8(v, static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ);
         }
-        Io<T>::store8(v, static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ);
       }
     }
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
@@ -519,7 +547,7 @@ int launch_cfg(const okp_conv* plan, OkpIgemmParams p, hipStream_t stream) {
   const int n_px_tiles = (P + BPX - 1) / BPX;
   p.tiles_per_class = p.n_co_tiles * n_px_tiles;
   p.n_tiles = p.tiles_per_class * p.n_classes;
-  constexpr int kLds = NS * (BCO + BPX) * KB + kMetaMax * (int)sizeof(SliceMeta);
+  constexpr int kLds = NS * (BCO + BPX) * KB + kMetaMax * (int)sizeof(SliceMeta) + 1024;
   constexpr int kPerCu = (160 * 1024 / kLds) < 1 ? 1 : (160 * 1024 / kLds > 4 ? 4 : 160 * 1024 / kLds);
   const int resident = 256 * kPerCu;              // MI355X: 256 CUs
   const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident));
