@@ -136,12 +136,12 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   constexpr int STAGE = (BCO + BPX) * KB;
   constexpr int LDS_BYTES = NS * STAGE;        // NS-deep ring of stages
   static_assert(NS >= 2, "ring depth");
-  constexpr int PASSES = (BPX * BCO * 4 > LDS_BYTES) ? 2 : 1;
+  constexpr int PASSES = (BPX * BCO * ESZ > LDS_BYTES) ? 2 : 1;   // epilogue staging holds the tile in the output type
   static_assert(RPP % 16 == 0, "loader swizzle assumes the pass height keeps (row>>1)&7");
   static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
-  static_assert(BPX * BCO * 4 / PASSES <= LDS_BYTES, "epilogue staging must fit");
+  static_assert(BPX * BCO * ESZ / PASSES <= LDS_BYTES, "epilogue staging must fit");
   constexpr int PX_PER_PASS = BPX / PASSES;
-  constexpr int PITCH = BCO * 4;
+  constexpr int PITCH = BCO * ESZ;
 
   // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta) + 1024];
@@ -353,7 +353,12 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   }
   __syncthreads();                               // all waves done with the last stage before it is reused
 
-  // ---- epilogue: bias in registers, transpose through LDS, coalesced NHWC rows ----------------
+  // ---- epilogue: bias in registers, transpose through LDS in the OUTPUT type, coalesced NHWC rows -----------
+  // Every lane owns 4 consecutive channels of one pixel per register group; it adds the bias, rounds to T and
+  // writes them to a [pixel][channel] LDS image (16-B chunks XOR-swizzled by the pixel row).  With bf16 the whole
+  // 256x256 tile fits the ring's LDS, so all waves stage at once and the tile leaves in ONE pass; the residual is
+  // added after the read-back (bf16 + residual in fp32, ReLU, one more rounding).
+  const bool dense_out = p.out_step == 1 && p.OH == p.Ho && p.OW == p.Wo;   // output pixel index == GEMM pixel index
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wpx == pass) {
@@ -367,10 +372,18 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
           for (int j = 0; j < TPX; ++j) {
             const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * MT + fr;
-            f32x4 v;
+            char* dst = smem + prow * PITCH + ((((co_l * ESZ) >> 4) ^ (prow & 7)) << 4) + ((co_l * ESZ) & 15);
+            if constexpr (ESZ == 2) {
+              bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-            *reinterpret_cast<f32x4*>(smem + prow * PITCH + (((co_l >> 2) ^ (prow & 7)) << 4)) = v;
+              for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][j][4 * g + e] + bv[e]);
+              *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+              *reinterpret_cast<f32x4*>(dst) = v;
+            }
           }
         }
       }
@@ -378,17 +391,19 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     __syncthreads();
     constexpr int GROUPS = BCO / 8;
     constexpr int ITEMS = PX_PER_PASS * GROUPS;
-    constexpr int U = ITEMS / NT;                  // 16-byte output items per thread and pass
+    constexpr int U = ITEMS / NT;                  // 8-channel output items per thread and pass
     constexpr int UB = U >= 2 ? 2 : 1;             // items per batch: their LDS reads are in flight together
+    constexpr int CH8 = 8 * ESZ / 16;              // 16-B chunks per item (1 for bf16, 2 for fp32)
     static_assert(ITEMS % NT == 0 && U % UB == 0, "epilogue work split");
     for (int u0 = 0; u0 < U; u0 += UB) {
-      f32x4 v0[UB], v1[UB];
+      u32x4 raw[UB][CH8];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int it = tid + (u0 + u) * NT;
         const int q = it % GROUPS, prow = it / GROUPS;
-        v0[u] = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q) ^ (prow & 7)) << 4));
-        v1[u] = *reinterpret_cast<const f32x4*>(smem + prow * PITCH + (((2 * q + 1) ^ (prow & 7)) << 4));
+#pragma unroll
+        for (int h = 0; h < CH8; ++h)
+          raw[u][h] = *reinterpret_cast<const u32x4*>(smem + prow * PITCH + (((CH8 * q + h) ^ (prow & 7)) << 4));
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -397,18 +412,45 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         const int pix = px0 + pass * PX_PER_PASS + prow;
         const int co = co0 + q * 8;
         if (pix < P && co < p.cout) {
-          float v[8] = {v0[u][0], v0[u][1], v0[u][2], v0[u][3], v1[u][0], v1[u][1], v1[u][2], v1[u][3]};
-          const int n = fastdiv(pix, p.div_howo);
-          const int rem = pix - n * HoWo;
-          const int ho = fastdiv(rem, p.div_wo);
-          const int wo = rem - ho * p.Wo;
-          const size_t opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
-          if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
-          if (p.act == OKP_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          size_t opix = (size_t)pix;
+          if (!dense_out) {
+            const int n = fastdiv(pix, p.div_howo);
+            const int rem = pix - n * HoWo;
+            const int ho = fastdiv(rem, p.div_wo);
+            const int wo = rem - ho * p.Wo;
+            opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
           }
-          Io<T>::store8(v, static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ);
+          char* op = static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ;
+          if (!p.res && ESZ == 2) {                // no residual: ReLU on the packed bf16 words, store as read
+            u32x4 w = raw[u][0];
+            if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {        // bf16 pair: clear halves whose sign bit is set (NaN keeps its payload sign)
+                const uint32_t x = w[e];
+                const uint32_t lo = (x & 0x8000u) ? 0u : (x & 0xFFFFu);
+                const uint32_t hi = (x & 0x80000000u) ? 0u : (x & 0xFFFF0000u);
+                w[e] = lo | hi;
+              }
+            }
+            *reinterpret_cast<u32x4*>(op) = w;
+          } else {
+            float v[8];
+            if constexpr (ESZ == 2) {
+              const bf16x8 s8 = __builtin_bit_cast(bf16x8, raw[u][0]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (float)s8[e];
+            } else {
+              const f32x4 a4 = __builtin_bit_cast(f32x4, raw[u][0]), b4 = __builtin_bit_cast(f32x4, raw[u][CH8 - 1]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = a4[e]; v[4 + e] = b4[e]; }
+            }
+            if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
+            if (p.act == OKP_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            Io<T>::store8(v, op);
+          }
         }
       }
     }
