@@ -7,8 +7,8 @@ packs = [i for i, r in enumerate(rows) if "okp_pack_frames" in r["Kernel_Name"]]
 sel = rows[packs[-1]:]
 def short(n):
     if "okp_igemm" in n:
-        m = re.search(r"okp_igemm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)ELi(\d+)E", n)
-        return f"igemm<{ 'bf16' if 'DF16b' in m.group(1) else 'f32'},{m.group(2)}x{m.group(3)},ring{m.group(4)}x{m.group(5)}B,src{m.group(6)}>"
+        m = re.search(r"okp_igemm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
+        return f"igemm<{ 'bf16' if 'DF16b' in m.group(1) else 'f32'},{m.group(2)}x{m.group(3)},ring{m.group(4)}x{m.group(5)}B,mfma{m.group(6)},src{m.group(7)}>"
     for k in ("okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_peak_nms"):
         if k in n: return k
     return n[:40]
