@@ -424,13 +424,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
           if (!p.res && ESZ == 2) {                // no residual: ReLU on the packed bf16 words, store as read
             u32x4 w = raw[u][0];
             if (p.act == OKP_ACT_RELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {        // bf16 pair: clear halves whose sign bit is set (NaN keeps its payload sign)
-                const uint32_t x = w[e];
-                const uint32_t lo = (x & 0x8000u) ? 0u : (x & 0xFFFFu);
-                const uint32_t hi = (x & 0x80000000u) ? 0u : (x & 0xFFFF0000u);
-                w[e] = lo | hi;
-              }
+              // bf16 read as int16 keeps the sign and the order of positive values: max(x, 0) clears negatives
+              // (one v_pk_max_i16 per register instead of unpack / compare / select)
+              typedef short s16x8 __attribute__((ext_vector_type(8)));
+              const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+              w = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w), z));
             }
             *reinterpret_cast<u32x4*>(op) = w;
           } else {
