@@ -34,59 +34,125 @@ template <> struct Vec<__bf16> {
 };
 
 struct DwParams {
-  const void* src; int32_t H, W, src_ps;
+  const void* src; uint32_t src_bytes; int32_t H, W, src_ps;
   const float* w; const float* bias;
   const void* res; int32_t res_ps;
   void* out; int32_t Ho, Wo, out_ps;
   int32_t N, C, stride, act;
 };
 
-// One lane = one output pixel x 16 bytes of channels.  Lanes of a wave walk the channel
-// dimension first, so every tap read and the final store are contiguous across the wave.
+// A thread owns one 16-byte channel group (its 9 x VN weights stay in registers) and SEG = 8 consecutive output
+// pixels, processed in groups of G = 4: with stride 1 and a group inside one image row the 3 x (G+2) taps are loaded
+// once and slid across the G outputs.  Zero padding is branch-free (out-of-range buffer offsets return 0), so all taps
+// of a group are in flight together.  No MFMA accumulators here, so the kernel runs at 3-4 waves per SIMD; the
+// host runs it on a side stream next to the expand GEMM of the same fire module.
 template <typename T>
 __global__ __launch_bounds__(256) void okp_dwconv3x3_kernel(const DwParams p) {
   constexpr int VN = Vec<T>::N;
   constexpr int ESZ = (int)sizeof(T);
-  const int cgroups = p.C / VN;
-  const long total = (long)p.N * p.Ho * p.Wo * cgroups;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(idx % cgroups);
-    const long pix = idx / cgroups;
-    const int wo = (int)(pix % p.Wo);
-    const long t = pix / p.Wo;
-    const int ho = (int)(t % p.Ho);
-    const int n = (int)(t / p.Ho);
-    const int c0 = cg * VN;
-    float acc[VN];
+  constexpr int SEG = 8, G = 4;
+  constexpr uint32_t kInvalidOff = 0x80000000u;
+  // the 9 x C weights live in LDS (36 B per channel): registers are kept for the tap window, 3+ waves per SIMD
+  extern __shared__ __attribute__((aligned(16))) float sw[];
+  for (int i = threadIdx.x; i < 9 * p.C; i += 256) sw[i] = p.w[i];
+  __syncthreads();
+  const int CG = p.C / VN;
+  const int PL = 256 / CG;
+  const int cq = threadIdx.x % CG, pl = threadIdx.x / CG;
+  if (pl >= PL) return;
+  const int ch = cq * VN;
+  const long P = (long)p.N * p.Ho * p.Wo;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+  float breg[VN];
 #pragma unroll
-    for (int e = 0; e < VN; ++e) acc[e] = p.bias[c0 + e];
+  for (int e = 0; e < VN; ++e) breg[e] = p.bias[ch + e];
+  const int cs = p.stride, H = p.H, W = p.W, ps = p.src_ps;
+  const bool slide = cs == 1 && (p.Wo % G) == 0;
+  auto tap_off = [&](int n, int hi, int wi) -> uint32_t {
+    const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+    return ok ? (uint32_t)(((n * H + hi) * W + wi) * ps + ch) * (uint32_t)ESZ : kInvalidOff;
+  };
+  auto to_f = [&](const u32x4& raw, float (&x)[VN]) {
+    if constexpr (ESZ == 2) {
+      const bf16x8 xv = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int hi = ho * p.stride + dy - 1;
-      if (hi < 0 || hi >= p.H) continue;
+      for (int e = 0; e < VN; ++e) x[e] = (float)xv[e];
+    } else {
+      const f32x4 xv = __builtin_bit_cast(f32x4, raw);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int wi = wo * p.stride + dx - 1;
-        if (wi < 0 || wi >= p.W) continue;
-        float x[VN];
-        Vec<T>::load(static_cast<const char*>(p.src) + (((size_t)n * p.H + hi) * p.W + wi) * (size_t)p.src_ps * ESZ + (size_t)c0 * ESZ, x);
-        const float* wt = p.w + (dy * 3 + dx) * p.C + c0;
-#pragma unroll
-        for (int e = 0; e < VN; ++e) acc[e] = fmaf(x[e], wt[e], acc[e]);
-      }
+      for (int e = 0; e < VN; ++e) x[e] = xv[e];
     }
+  };
+  auto finish = [&](float (&v)[VN], int n, int ho, int wo) {
     const size_t opix = ((size_t)n * p.Ho + ho) * p.Wo + wo;
     if (p.res) {
       float r[VN];
-      Vec<T>::load(static_cast<const char*>(p.res) + (opix * p.res_ps + c0) * ESZ, r);
+      Vec<T>::load(static_cast<const char*>(p.res) + (opix * p.res_ps + ch) * ESZ, r);
 #pragma unroll
-      for (int e = 0; e < VN; ++e) acc[e] += r[e];
+      for (int e = 0; e < VN; ++e) v[e] += r[e];
     }
     if (p.act == OKP_ACT_RELU) {
 #pragma unroll
-      for (int e = 0; e < VN; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    Vec<T>::store(static_cast<char*>(p.out) + (opix * p.out_ps + c0) * ESZ, acc);
+    Vec<T>::store(static_cast<char*>(p.out) + (opix * p.out_ps + ch) * ESZ, v);
+  };
+  for (long base = ((long)blockIdx.x * PL + pl) * SEG; base < P; base += (long)gridDim.x * PL * SEG) {
+#pragma unroll
+    for (int g0 = 0; g0 < SEG; g0 += G) {
+      const long pix0 = base + g0;
+      if (pix0 >= P) break;
+      if (slide) {                                  // Wo % G == 0  =>  the whole group is in range and in one row
+        const int wo0 = (int)(pix0 % p.Wo);
+        const long t = pix0 / p.Wo;
+        const int ho = (int)(t % p.Ho), n = (int)(t / p.Ho);
+        u32x4 win[3][G + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < G + 2; ++cc)
+            win[r][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tap_off(n, ho + r - 1, wo0 + cc - 1), 0, 0);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          float v[VN];
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = breg[e];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+              float x[VN];
+              to_f(win[r][k + c3], x);
+#pragma unroll
+              for (int e = 0; e < VN; ++e) v[e] = fmaf(x[e], sw[(r * 3 + c3) * p.C + ch + e], v[e]);
+            }
+          finish(v, n, ho, wo0 + k);
+        }
+      } else {
+        for (int k = 0; k < G; ++k) {
+          const long pix = pix0 + k;
+          if (pix >= P) break;
+          const int wo = (int)(pix % p.Wo);
+          const long t = pix / p.Wo;
+          const int ho = (int)(t % p.Ho), n = (int)(t / p.Ho);
+          u32x4 tapv[9];
+#pragma unroll
+          for (int q = 0; q < 9; ++q)
+            tapv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)tap_off(n, ho * cs + q / 3 - 1, wo * cs + q % 3 - 1), 0, 0);
+          float v[VN];
+#pragma unroll
+          for (int e = 0; e < VN; ++e) v[e] = breg[e];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            float x[VN];
+            to_f(tapv[q], x);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = fmaf(x[e], sw[q * p.C + ch + e], v[e]);
+          }
+          finish(v, n, ho, wo);
+        }
+      }
+    }
   }
 }
 
@@ -212,15 +278,18 @@ extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t co
   const int ho = (src->h + 2 - 3) / conv_stride + 1, wo = (src->w + 2 - 3) / conv_stride + 1;
   if (out->h != ho || out->w != wo) { okp_set_error("okp_dwconv3x3_forward: out is %dx%d, expected %dx%d", out->h, out->w, ho, wo); return OKP_EINVAL; }
   DwParams p;
-  p.src = src->data; p.H = src->h; p.W = src->w; p.src_ps = src->pix_stride;
+  if (src->bytes <= 0 || src->bytes >= 0x7FFF0000ll) { okp_set_error("okp_dwconv3x3_forward: src spans %lld bytes; views must be < 2 GiB", (long long)src->bytes); return OKP_EINVAL; }
+  if (c / vn > 256) { okp_set_error("okp_dwconv3x3_forward: at most %d channels", 256 * vn); return OKP_EINVAL; }
+  p.src = src->data; p.src_bytes = (uint32_t)src->bytes; p.H = src->h; p.W = src->w; p.src_ps = src->pix_stride;
   p.w = w_dev; p.bias = bias_dev;
   p.res = (res && res->data) ? res->data : nullptr; p.res_ps = res ? res->pix_stride : 0;
   p.out = out->data; p.Ho = ho; p.Wo = wo; p.out_ps = out->pix_stride;
   p.N = n; p.C = c; p.stride = conv_stride; p.act = act;
-  const long total = (long)n * ho * wo * (c / vn);
-  const int grid = grid_for(total, 256);
-  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(okp_dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  const int pl = 256 / (c / vn);
+  const long groups = ((long)n * ho * wo + (long)pl * 8 - 1) / ((long)pl * 8);
+  const int grid = (int)(groups < 1 ? 1 : (groups > 256L * 16 ? 256L * 16 : groups));
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<__bf16>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(okp_dwconv3x3_kernel<float>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_dwconv3x3 launch");
 }
 
