@@ -221,6 +221,26 @@ int okp_lift_peaks(const okp_camera* cam, const int32_t* count_dev, const float*
                    const float* depth_dev, int32_t h, int32_t w, int32_t max_x, int32_t max_y,
                    double* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Object grouping on the device (batched form of ObjectExtraction.__call__, perception/pipeline.py:104-153):
+ * the peaks of map 0 are object centres; every peak of map k >= 1 votes for the centre nearest to
+ * (pixel centre + centre-offset map value at its rounded position), votes farther than `max_dist` (20 px in the
+ * reference) are dropped; per object and keypoint type at most `type_count[k-1]` peaks are kept: for a type with
+ * count 1 the most confident one, otherwise the first `type_count` in peak order with `overflow` set so the caller
+ * can run the reference's k-means on them (its unseeded KMeans is not reproducible bit for bit anyway).
+ *   count [n][K] int32, xyc [n][K][cap][3] fp32 (okp_peak_nms outputs), centers [n][K-1][2][h][w] fp32
+ *   n_obj   [n] int32                         objects per frame (= min(count[n][0], max_obj))
+ *   sel     [n][max_obj][K-1][max_sel] int32  selected peak indices into map k, -1 = empty slot
+ *   n_votes [n][max_obj][K-1] int32           votes the object received for that type (before the cut)
+ *   assign  [n][K][cap] int32                 object index each peak voted for (-1: none / dropped / map 0)
+ *   pred    [n][K][cap][2] fp64               the predicted centre (x, y) each peak voted with
+ * One lane per frame; K <= 8, max_sel <= 8.
+ * ---------------------------------------------------------------------------------- */
+int okp_group_objects(const int32_t* count_dev, const float* xyc_dev, const float* centers_dev, int32_t n, int32_t K,
+                      int32_t cap, int32_t h, int32_t w, const int32_t* type_count /* HOST [K-1] */, float max_dist,
+                      int32_t max_obj, int32_t max_sel, int32_t* n_obj_dev, int32_t* sel_dev, int32_t* n_votes_dev,
+                      int32_t* assign_dev, double* pred_dev, void* stream);
+
 /* Replaces StereoCamera.triangulate (utils/camera_utils.py:92-110) and the labelling tool's
  * 2-view DLT (scripts/label.py:285-305): undistort both views (P=K) -> optional Hartley-Sturm
  * correction against F (cv2.correctMatches) -> DLT null vector of the 4x4 system built from

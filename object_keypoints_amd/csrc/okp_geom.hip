@@ -93,6 +93,66 @@ __global__ void okp_lift_peaks_kernel(okp_camera cam, const int* __restrict__ co
   o[3] = (double)pk[2];
 }
 
+struct GroupParams {
+  const int* count; const float* xyc; const float* centers;
+  int n, K, cap, H, W, max_obj, max_sel;
+  int type_count[8];
+  float max_dist;
+  int* n_obj; int* sel; int* n_votes; int* assign; double* pred;
+};
+
+// One lane per frame: tens of peaks per frame, the loops are tiny; what matters is that the batch never leaves the
+// device between peak extraction and the all-gather.  Distances are evaluated in fp64 like the reference (NumPy
+// promotes float32 centres + float64 pixel grid to float64).
+__global__ void okp_group_objects_kernel(const GroupParams p) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= p.n) return;
+  const int* cnt = p.count + (size_t)f * p.K;
+  const float* pk = p.xyc + (size_t)f * p.K * p.cap * 3;
+  const int nobj = min(min(cnt[0], p.cap), p.max_obj);
+  p.n_obj[f] = nobj;
+  int* sel = p.sel + (size_t)f * p.max_obj * (p.K - 1) * p.max_sel;
+  int* votes = p.n_votes + (size_t)f * p.max_obj * (p.K - 1);
+  for (int i = 0; i < p.max_obj * (p.K - 1) * p.max_sel; ++i) sel[i] = -1;
+  for (int i = 0; i < p.max_obj * (p.K - 1); ++i) votes[i] = 0;
+  int* assign = p.assign + (size_t)f * p.K * p.cap;
+  double* pred = p.pred + (size_t)f * p.K * p.cap * 2;
+  for (int i = 0; i < p.K * p.cap; ++i) assign[i] = -1;
+  if (nobj == 0) return;
+  for (int k = 1; k < p.K; ++k) {
+    const int want = p.type_count[k - 1];
+    const float* cmap = p.centers + ((size_t)f * (p.K - 1) + (k - 1)) * 2 * p.H * p.W;
+    const int npk = min(cnt[k], p.cap);
+    for (int j = 0; j < npk; ++j) {
+      const float* q = pk + ((size_t)k * p.cap + j) * 3;
+      int xi = (int)rintf(q[0]), yi = (int)rintf(q[1]);
+      xi = min(max(xi, 0), p.W - 1);
+      yi = min(max(yi, 0), p.H - 1);
+      const double cx = ((double)xi + 0.5) + (double)cmap[(size_t)yi * p.W + xi];
+      const double cy = ((double)yi + 0.5) + (double)cmap[(size_t)p.H * p.W + (size_t)yi * p.W + xi];
+      int best = 0;
+      double bestd = 1e300;
+      for (int o = 0; o < nobj; ++o) {
+        const double dx = (double)pk[o * 3 + 0] - cx, dy = (double)pk[o * 3 + 1] - cy;
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < bestd) { bestd = d; best = o; }
+      }
+      pred[((size_t)k * p.cap + j) * 2 + 0] = cx;
+      pred[((size_t)k * p.cap + j) * 2 + 1] = cy;
+      if (bestd > (double)p.max_dist) continue;
+      assign[k * p.cap + j] = best;
+      int* vs = votes + best * (p.K - 1) + (k - 1);
+      int* ss = sel + ((size_t)best * (p.K - 1) + (k - 1)) * p.max_sel;
+      const int v = (*vs)++;
+      if (want == 1) {                                   // keep the most confident vote (first one wins ties, as argmax does)
+        if (v == 0 || q[2] > pk[((size_t)k * p.cap + ss[0]) * 3 + 2]) ss[0] = j;
+      } else if (v < p.max_sel) {
+        ss[v] = j;                                        // peak order; the caller resolves v > want (k-means) itself
+      }
+    }
+  }
+}
+
 // One-sided (Hestenes) Jacobi on the columns of a 4x4 matrix; returns the column of V that
 // belongs to the smallest singular value, i.e. argmin |A v| over unit v.
 __device__ void null_vector4(double (&A)[4][4], double (&v)[4]) {
@@ -346,6 +406,20 @@ extern "C" int okp_lift_peaks(const okp_camera* cam, const int32_t* count, const
   const int total = n_maps * cap;
   hipLaunchKernelGGL(okp_lift_peaks_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *cam, count, xyc, n_maps, cap, depth, h, w, max_x, max_y, out);
   return okp_check_hip(hipGetLastError(), "okp_lift_peaks launch");
+}
+
+extern "C" int okp_group_objects(const int32_t* count, const float* xyc, const float* centers, int32_t n, int32_t K, int32_t cap,
+                                 int32_t h, int32_t w, const int32_t* type_count, float max_dist, int32_t max_obj, int32_t max_sel,
+                                 int32_t* n_obj, int32_t* sel, int32_t* n_votes, int32_t* assign, double* pred, void* stream) {
+  if (!count || !xyc || !centers || !type_count || !n_obj || !sel || !n_votes || !assign || !pred) { okp_set_error("okp_group_objects: null argument"); return OKP_EINVAL; }
+  if (K < 2 || K > 8 || max_sel < 1 || max_sel > 8 || max_obj < 1 || cap < 1) { okp_set_error("okp_group_objects: K in [2,8], max_sel in [1,8] required"); return OKP_EINVAL; }
+  if (n <= 0) return OKP_OK;
+  GroupParams p;
+  p.count = count; p.xyc = xyc; p.centers = centers; p.n = n; p.K = K; p.cap = cap; p.H = h; p.W = w;
+  p.max_obj = max_obj; p.max_sel = max_sel; p.max_dist = max_dist; p.n_obj = n_obj; p.sel = sel; p.n_votes = n_votes; p.assign = assign; p.pred = pred;
+  for (int k = 0; k < 8; ++k) p.type_count[k] = k < K - 1 ? type_count[k] : 0;
+  hipLaunchKernelGGL(okp_group_objects_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_group_objects launch");
 }
 
 extern "C" int okp_triangulate_dlt(const okp_camera* left, const okp_camera* right, const double* T_RL, const double* F,

@@ -321,6 +321,28 @@ def lift_peaks(cam, count, xyc, depth, max_x, max_y):
     return out
 
 
+def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_dist=20.0):
+    """Device-side object grouping (okp_group_objects).  count [N,K] int32, xyc [N,K,cap,3] fp32, centers
+    [N,K-1,2,H,W] fp32 -> dict of device tensors: n_obj [N], sel [N,max_obj,K-1,max_sel], n_votes [N,max_obj,K-1],
+    assign [N,K,cap] (int32) and pred [N,K,cap,2] (fp64 predicted centres)."""
+    require_cuda(xyc, "xyc")
+    n, k, cap, _ = xyc.shape
+    centers = centers.contiguous()
+    if centers.dtype != torch.float32 or tuple(centers.shape[:3]) != (n, k - 1, 2):
+        raise OkpError("centers must be float32 [N,K-1,2,H,W]")
+    dev = xyc.device
+    n_obj = torch.empty((n,), dtype=torch.int32, device=dev)
+    sel = torch.empty((n, max_obj, k - 1, max_sel), dtype=torch.int32, device=dev)
+    votes = torch.empty((n, max_obj, k - 1), dtype=torch.int32, device=dev)
+    assign = torch.empty((n, k, cap), dtype=torch.int32, device=dev)
+    pred = torch.zeros((n, k, cap, 2), dtype=torch.float64, device=dev)
+    tc = (ctypes.c_int32 * (k - 1))(*[int(c) for c in type_count])
+    _lib.check(_lib.lib().okp_group_objects(count.data_ptr(), xyc.data_ptr(), centers.data_ptr(), n, k, cap, centers.shape[3], centers.shape[4],
+                                            tc, float(max_dist), max_obj, max_sel, n_obj.data_ptr(), sel.data_ptr(), votes.data_ptr(),
+                                            assign.data_ptr(), pred.data_ptr(), stream_handle()), "okp_group_objects")
+    return {"n_obj": n_obj, "sel": sel, "n_votes": votes, "assign": assign, "pred": pred}
+
+
 def triangulate_dlt(cam_l, cam_r, T_RL, left_xy, right_xy, F=None):
     require_cuda(left_xy, "left_xy")
     left_xy = left_xy.to(torch.float32).contiguous()

@@ -237,8 +237,11 @@ class BatchedKeypointPipeline:
     objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points.
     """
 
-    def __init__(self, net, keypoint_config, camera, prediction_size=(64, 64), capacity=DEFAULT_PEAK_CAPACITY):
+    def __init__(self, net, keypoint_config, camera, prediction_size=(64, 64), capacity=DEFAULT_PEAK_CAPACITY,
+                 max_objects=16, max_per_type=4):
         self.net = net
+        self.max_objects = max_objects
+        self.max_per_type = max_per_type
         self.config = keypoint_config
         self.capacity = capacity
         self.prediction_size = list(prediction_size)
@@ -266,19 +269,53 @@ class BatchedKeypointPipeline:
         return graph, static_in, static_out
 
     def postprocess_device(self, heat, depth, centers):
-        """Peaks + per-peak 3D points from (post-sigmoid) heat, depth and centre maps on the device."""
+        """Peaks, per-peak 3D points and the object grouping from (post-sigmoid) heat, depth and centre maps, all on
+        the device: three small launches, nothing crosses PCIe."""
         count, yx, xyc = ops.peak_nms(heat, cap=self.capacity)
         points = ops.lift_peaks(self.cam, count, xyc, depth, int(self.max_index[0]), int(self.max_index[1]))
-        return {"heat": heat, "depth": depth, "centers": centers, "count": count, "yx": yx, "xyc": xyc, "points": points}
+        out = {"heat": heat, "depth": depth, "centers": centers, "count": count, "yx": yx, "xyc": xyc, "points": points}
+        out.update(ops.group_objects(count, xyc, centers, self.config['keypoint_config'], max_obj=self.max_objects,
+                                     max_sel=self.max_per_type))
+        return out
 
     def objects(self, out, n):
-        """Host-side grouping of frame n of a forward_device() result (one D2H copy per tensor)."""
+        """Frame n of a forward_device() result as the reference's list of object dicts
+        ({'p_centers', 'keypoints', 'p_C'}, pipeline.py:190-200), assembled from the device-side grouping.  Falls back
+        to the host ObjectExtraction for the k-means branch (more detections of a multi-instance type than configured)
+        or when a capacity was exceeded."""
+        cfg = self.config['keypoint_config']
         count = out["count"][n].cpu().numpy()
         xyc = out["xyc"][n].cpu().numpy()
         pts3 = out["points"][n].cpu().numpy()
+        n_obj = int(out["n_obj"][n])
+        votes = out["n_votes"][n].cpu().numpy()
+        if int(count.max(initial=0)) > self.capacity or int(count[0]) > self.max_objects:
+            raise OkpError("peak / object capacity exceeded; raise `capacity` / `max_objects`")
+        overflow = any(votes[o, i] > cfg[i] and cfg[i] > 1 for o in range(n_obj) for i in range(len(cfg))) or \
+            any(votes[o, i] > self.max_per_type and cfg[i] > 1 for o in range(n_obj) for i in range(len(cfg)))
+        if overflow:
+            return self._objects_host(out, n, count, xyc, pts3)
+        sel = out["sel"][n].cpu().numpy()
+        assign = out["assign"][n].cpu().numpy()
+        pred = out["pred"][n].cpu().numpy()
+        objects = []
+        for o in range(n_obj):
+            keypoints = [xyc[0, o, :2].copy()[None]]
+            world = [pts3[0, o, :3][None]]
+            for i in range(len(cfg)):
+                idx = [int(j) for j in sel[o, i] if j >= 0][:max(cfg[i], 1)]
+                if idx:
+                    keypoints.append(xyc[i + 1, idx, :2].copy())
+                    world.append(pts3[i + 1, idx, :3])
+                else:
+                    keypoints.append(np.array([]))
+                    world.append(None)
+            p_centers = [pred[k, j] for k in range(1, count.shape[0]) for j in range(int(count[k])) if assign[k, j] == o]
+            objects.append({'p_centers': p_centers, 'keypoints': keypoints, 'p_C': world})
+        return objects
+
+    def _objects_host(self, out, n, count, xyc, pts3):
         centers = out["centers"][n].cpu().numpy()
-        if int(count.max(initial=0)) > self.capacity:
-            raise OkpError("peak capacity exceeded")
         keypoints = [[xyc[k, j, :2].copy() for j in range(int(count[k]))] for k in range(count.shape[0])]
         confidence = [[xyc[k, j, 2] for j in range(int(count[k]))] for k in range(count.shape[0])]
         lifted = {}

@@ -111,13 +111,19 @@ def test_object_pipeline_matches_reference_golden(golden, name):
     batched = pp.BatchedKeypointPipeline(None, cfg, camera_small)
     out = batched.postprocess_device(torch.from_numpy(c["heat"][None]).cuda(), torch.from_numpy(c["depth"][None]).cuda(),
                                      torch.from_numpy(c["centers"][None]).cuda())
-    objs = batched.objects(out, 0)
+    objs = batched.objects(out, 0)           # device-side grouping (okp_group_objects)
     assert len(objs) == len(res)
     for o, r in zip(objs, res):
         for a, b in zip(o["p_C"], r["p_C"]):
             assert (a is None) == (b is None)
             if a is not None:
                 np.testing.assert_array_equal(a, b)
+        for a, b in zip(o["keypoints"], r["keypoints"]):
+            assert np.asarray(a).shape == np.asarray(b).shape
+            np.testing.assert_array_equal(a, b)
+        assert len(o["p_centers"]) == len(r["p_centers"])
+        for a, b in zip(o["p_centers"], r["p_centers"]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
 
 
 def test_triangulation_known_answer_and_oracle(known):
@@ -189,3 +195,39 @@ def test_batch64_properties():
             if len(idx):
                 want = d2p(xyc[n, k, :len(idx), :2], scenes[n]["depth"][k])
                 assert np.abs(pts[n, k, :len(idx), :3] - want).max() < 1e-6
+
+
+def test_device_grouping_matches_oracle_on_a_batch():
+    """okp_group_objects on 64 multi-object frames vs the oracle's ObjectExtraction, frame by frame; the k-means
+    branch (more votes than configured for a multi-instance type) falls back to the host and is compared as a set."""
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    cfg = {"keypoint_config": [1, 3]}
+    scenes = [synth.bump_scene([1, 3], n_objects=1 + (i % 3), seed=23, index=i) for i in range(64)]
+    heat = torch.from_numpy(np.stack([s["heat"] for s in scenes])).cuda()
+    depth = torch.from_numpy(np.stack([s["depth"] for s in scenes])).cuda()
+    centers = torch.from_numpy(np.stack([s["centers"] for s in scenes])).cuda()
+    cam_o = op.eval_camera(CALIB)
+    batched = pp.BatchedKeypointPipeline(None, cfg, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size))
+    out = batched.postprocess_device(heat, depth, centers)
+    opipe = op.ObjectKeypointPipeline([64, 64], None, cfg)
+    opipe.reset(cam_o)
+    checked = 0
+    for n in range(64):
+        want = opipe(scenes[n]["heat"][None], scenes[n]["depth"][None], scenes[n]["centers"][None])
+        got = batched.objects(out, n)
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            for a, b in zip(g["keypoints"], w_["keypoints"]):
+                a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+                assert a.shape == b.shape
+                if a.size:                 # same SET of points (the k-means branch has no defined order)
+                    d = np.linalg.norm(a[:, None, :] - b[None, :, :], axis=2)
+                    assert d.min(axis=1).max() < 1e-4 and d.min(axis=0).max() < 1e-4
+            for a, b in zip(g["p_C"], w_["p_C"]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert np.abs(np.sort(a, axis=0) - np.sort(b, axis=0)).max() < 1e-4
+            checked += 1
+    assert checked > 64
