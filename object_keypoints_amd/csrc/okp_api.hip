@@ -224,7 +224,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
 extern "C" int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* a) {
   if (!plan || !a) return 0;
   if (a->tile) return a->tile;
-  return okp_select_tile(plan->cout_pad, (long)a->n * a->ho * a->wo);
+  return okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
 }
 
 extern "C" int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* a) {

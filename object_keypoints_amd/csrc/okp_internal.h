@@ -99,5 +99,5 @@ void okp_set_error(const char* fmt, ...);
 int okp_check_hip(hipError_t e, const char* what);
 
 // launchers implemented in the .hip files
-int okp_select_tile(int cout_pad, long pixels);
+int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
