@@ -19,10 +19,12 @@ OBJ_DIR = os.path.join(REPO, "build", "okp")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
-          "-Wall", "-Wno-unused-function",
-          # keep MFMA accumulators in arch VGPRs: with 256-thread workgroups hipcc otherwise allocates them as
-          # AGPRs and copies all of them to and from VGPRs around every K-step (v_accvgpr_write/read x 128)
-          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+          "-Wall", "-Wno-unused-function"]
+# keep MFMA accumulators in arch VGPRs: with 256-thread workgroups hipcc otherwise allocates them as
+# AGPRs and copies all of them to and from VGPRs around every K-step (v_accvgpr_write/read x 128).
+# okp_igemm_w4.hip is the exception: its 256 accumulators per lane only fit the AGPR file.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+AGPR_FILES = {"okp_igemm_w4.hip"}
 
 
 def _sources():
@@ -30,7 +32,8 @@ def _sources():
 
 
 def _deps():
-    return [os.path.join(REPO, "include", "okp.h"), os.path.join(CSRC, "okp_internal.h"), os.path.abspath(__file__)]
+    return [os.path.join(REPO, "include", "okp.h"), os.path.join(CSRC, "okp_internal.h"),
+            os.path.join(CSRC, "okp_igemm_kernel.h"), os.path.abspath(__file__)]
 
 
 def _stale(target, deps):
@@ -43,7 +46,8 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
     if _stale(obj, [src] + _deps()):
-        cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+        extra = [] if os.path.basename(src) in AGPR_FILES else VGPR_FORM
+        cmd = [HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -101,3 +101,4 @@ int okp_check_hip(hipError_t e, const char* what);
 // launchers implemented in the .hip files
 int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
+int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip

@@ -2,7 +2,8 @@
 import re, subprocess, sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "object_keypoints_amd/csrc/okp_igemm.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+form = [] if src.endswith("_w4.hip") else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950"] + form + [
        "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "object_keypoints_amd/csrc"), "-c", src, "-o", "/tmp/_kres.o",
        "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
@@ -16,4 +17,4 @@ for line in out.splitlines():
 for k, v in rows.items():
     if "DF16b" in k or "okp_fire" in k or len(sys.argv) > 2:
         name = re.sub(r"_ZN12_GLOBAL__N_116okp_igemm_kernelI|EEv14OkpIgemmParams", "", k)
-        print(f"{name:48s} VGPR {v.get('VGPRs', -1):4d} spill {v.get('VGPRs Spill', -1):3d} scratch {v.get('ScratchSize [bytes/lane]', -1):4d} LDS {v.get('LDS Size [bytes/block]', -1):7d} occ {v.get('Occupancy [waves/SIMD]', -1)}")
+        print(f"{name:48s} VGPR {v.get('VGPRs', -1):4d} AGPR {v.get('AGPRs', -1):4d} spill {v.get('VGPRs Spill', -1):3d} scratch {v.get('ScratchSize [bytes/lane]', -1):4d} LDS {v.get('LDS Size [bytes/block]', -1):7d} occ {v.get('Occupancy [waves/SIMD]', -1)}")

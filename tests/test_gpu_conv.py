@@ -25,7 +25,7 @@ def _rand(shape, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
     (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
     (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
@@ -34,6 +34,8 @@ def _rand(shape, seed):
     (3, 1, 8, 16, 1, 5, 5),         # one partial slice per tap
 ])
 def test_conv_matches_torch(dtype, tile, k, stride, cin, cout, n, h, w):
+    if tile >= 9 and dtype == torch.float32:
+        pytest.skip("4-wave AGPR tiles are bf16 only")
     from object_keypoints_amd import ops
     from object_keypoints_amd.perception.backbone import conv_taps, conv_out_size
     dev = _dev()
