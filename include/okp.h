@@ -153,6 +153,19 @@ int okp_pack_frames_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int
                        const float* mean3, const float* std3, void* out_dev, int32_t out_w, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The 7x7 / stride-2 / pad-3 stem convolution 3 -> 128 + folded BatchNorm + ReLU in bf16 as its own kernel
+ * (write-bound layer: whole 64-byte NHWC lines are stored straight from the MFMA accumulators).
+ * Replaces hg.pre[0] = convolution(7, 3, 128, stride=2) (corner_net_lite/core/models/py_utils/utils.py:143-156,
+ * CornerNet_Squeeze.py:84).  w: HOST fp32 [128][3][7][7] with BatchNorm folded, bias: HOST fp32 [128].
+ * packed: the bf16 output of okp_pack_frames(_u8) for (n,h,w) frames: {data, h+6, out_w, pix_stride 4, bytes}.
+ * out: NHWC bf16 view of size ((h-1)/2+1) x ((w-1)/2+1), >= 128 channels, 64-byte aligned pixels.
+ * ---------------------------------------------------------------------------------- */
+typedef struct okp_stem okp_stem;
+okp_stem* okp_stem_create(const float* w_host, const float* bias_host);
+void okp_stem_destroy(okp_stem* stem);
+int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Final 1x1 convolutions of the three heads, NHWC -> NCHW fp32, optional sigmoid per output.
  * Replaces prediction_module[-1] (perception/models.py:17) for heat/depth/centre heads and
  * the deployed wrapper's sigmoid (scripts/package_model.py:28).

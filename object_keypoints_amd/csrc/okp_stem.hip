@@ -1,0 +1,258 @@
+// 7x7 / stride-2 stem convolution (3 -> 128 channels) + folded BatchNorm + ReLU, bf16, for gfx950.
+//
+// Replaces `convolution(7, 3, 128, stride=2)` = hg.pre[0] (corner_net_lite/core/models/py_utils/utils.py:143-156,
+// built at corner_net_lite/core/models/CornerNet_Squeeze.py:84).  The generic tap-list kernel spends more time in
+// its per-tile prologue and epilogue than in the 7 K-slices of this layer; this kernel is shaped for it instead:
+//
+//  * The layer is WRITE bound: 2 B x 128 channels per output pixel (1.07 GB at 64 frames) against 224 padded MACs
+//    per output value.  Everything is organised so that the stores leave as whole 64-byte lines straight from the
+//    accumulator registers, without a transposition through LDS.
+//  * Input: the packed frame of okp_pack_frames (NHWC4 bf16 with a zero halo, image at (3,3)).  A workgroup owns an
+//    8 x 32 tile of output pixels and keeps the 21 x 70 pixel input patch of that tile in LDS (11.8 KB, fetched by
+//    LDS-DMA one tile ahead, double-buffered).  No im2col: with 4 channels per pixel and stride 2, the 8 K-values
+//    lane (pixel j, half h) feeds to a 32x32x16 MFMA are the two packed pixels at patch column 2j + kx0 + 2h, one
+//    aligned ds_read_b128.  K order: k-step s = (ky = s/2, kx0 = 4*(s%2)), k = 8h + e <-> (kx = kx0 + 2h + e/4, c = e%4);
+//    channel 3 and kx = 7 carry zero weights.
+//  * Pixels are the MFMA ROWS (A operand), output channels the COLUMNS (B operand): D then has lane j of a half-wave
+//    on channel column j and accumulator register r on pixel 8 (r/4) + 4 h + r%4.  Weights: 14 k-steps x 2 column
+//    blocks of B fragments stay in registers for the whole kernel (112 VGPRs); wave (wc, wp) owns output channels
+//    [64 wc, 64 wc + 64) and tile rows [4 wp, 4 wp + 4).
+//  * Column j of block b is channel 64 wc + 2 j + b (fixed at pack time), so a lane's two blocks are two ADJACENT
+//    channels of the same pixel: bias is the accumulator's initial value, ReLU and the bf16 rounding happen in
+//    registers, the pair is one dword and a half-wave's store is 128 contiguous bytes of one NHWC pixel (whole
+//    64-byte lines, two pixels per instruction) - no transposition through LDS.
+#include <cstring>
+#include <vector>
+
+#include "okp_internal.h"
+
+namespace {
+
+constexpr int kCout = 128;
+constexpr int TH = 8, TW = 32;                 // output pixels per tile
+constexpr int PR = 2 * (TH - 1) + 7;           // 21 patch rows
+constexpr int PC = 2 * (TW - 1) + 8;           // 70 patch columns (the 8th kernel column is zero padding of K)
+constexpr int PITCH = PC * 8;                  // 560 bytes per patch row (bf16 x 4 channels per pixel)
+constexpr int CHUNKS_ROW = PITCH / 16;         // 35 16-byte chunks per row
+constexpr int CHUNKS = PR * CHUNKS_ROW;        // 735 per patch
+constexpr int PATCH_BYTES = ((CHUNKS + 63) / 64) * 1024;   // whole LDS-DMA instructions: 12 KiB
+constexpr int KSTEPS = 14;
+constexpr uint32_t kInvalidOff = 0x80000000u;
+
+struct StemParams {
+  const void* src;          // packed frames [N][Hp][Wp][4] bf16
+  uint32_t src_bytes;
+  int32_t Hp, Wp;
+  const void* wfrag;        // [wc 2][block 2][k-step 14][lane 64][16 B]  B-operand fragments
+  const float* bias;        // [128], natural channel order
+  void* out;
+  uint32_t out_bytes;
+  int32_t N, Ho, Wo, out_pix_stride;
+  int32_t tiles_x, tiles_y, n_tiles;
+  OkpFastDiv div_tiles_frame, div_tiles_x;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
+  return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
+}
+
+__global__ __launch_bounds__(256) void okp_stem_kernel(const StemParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+
+  // weight (B operand) fragments: resident for the whole kernel
+  u32x4 wa[2][KSTEPS];
+  {
+    const u32x4* wf = reinterpret_cast<const u32x4*>(p.wfrag) + (size_t)wc * 2 * KSTEPS * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) wa[b][s] = wf[(b * KSTEPS + s) * 64];
+  }
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const uint32_t ps2 = (uint32_t)p.out_pix_stride * 2u;                       // bytes per output pixel
+  const uint32_t st_lane = (uint32_t)(4 * h) * ps2 + (uint32_t)(64 * wc + 2 * j) * 2u;
+  // this lane's two channels (64 wc + 2 j, + 1): their biases are the initial accumulator values
+  const float bias0 = p.bias[64 * wc + 2 * j], bias1 = p.bias[64 * wc + 2 * j + 1];
+
+  // patch loader: LDS-DMA instruction q of this wave covers chunks [64 (3 wave + q), +64) of the linear patch image
+  constexpr int DMA_PER_WAVE = PATCH_BYTES / 1024 / 4;      // 3
+  uint32_t ld_off[DMA_PER_WAVE];                            // offset inside the patch's first row/column origin
+#pragma unroll
+  for (int q = 0; q < DMA_PER_WAVE; ++q) {
+    const int ci = 64 * (DMA_PER_WAVE * wave + q) + lane;
+    const int row = ci / CHUNKS_ROW, col = ci - row * CHUNKS_ROW;
+    ld_off[q] = ci < CHUNKS ? (uint32_t)row * (uint32_t)p.Wp * 8u + (uint32_t)col * 16u : kInvalidOff;
+  }
+  auto tile_coords = [&](int tile, int& n, int& oy0, int& ox0) {
+    n = fastdiv(tile, p.div_tiles_frame);
+    const int r = tile - n * p.tiles_x * p.tiles_y;
+    const int ty = fastdiv(r, p.div_tiles_x);
+    oy0 = ty * TH;
+    ox0 = (r - ty * p.tiles_x) * TW;
+  };
+  auto issue_patch = [&](int tile, int buf) {
+    int n, oy0, ox0;
+    tile_coords(tile, n, oy0, ox0);
+    // patch origin = packed pixel (2 oy0, 2 ox0); rows beyond the packed frame end past the buffer -> zeros
+    const uint32_t base = (uint32_t)(((long)n * p.Hp + 2 * oy0) * p.Wp + 2 * ox0) * 8u;
+    char* dst = smem + buf * PATCH_BYTES + (DMA_PER_WAVE * wave) * 1024;
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q) {
+      const uint32_t off = ld_off[q] == kInvalidOff ? kInvalidOff : base + ld_off[q];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(dst + q * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.n_tiles) return;
+  issue_patch(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int buf = 0;
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < p.n_tiles) issue_patch(next, buf ^ 1);
+    int n, oy0, ox0;
+    tile_coords(tile, n, oy0, ox0);
+    const char* patch = smem + buf * PATCH_BYTES;
+    // byte address of this lane's B chunk for (row ry of the tile, ky, kx0): ((2 ry + ky) * PC + 2 j + kx0 + 2 h) * 8
+    const int lane_off = (2 * j + 2 * h) * 8;
+#pragma unroll 1
+    for (int g = 0; g < 2; ++g) {                 // two groups of two output rows
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[0][0][e] = bias0; acc[1][0][e] = bias0; acc[0][1][e] = bias1; acc[1][1][e] = bias1; }
+      const int ry0 = 4 * wp + 2 * g;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int ky = s >> 1, kx0 = 4 * (s & 1);
+        u32x4 pf[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          pf[r] = *reinterpret_cast<const u32x4*>(patch + (2 * (ry0 + r) + ky) * PITCH + kx0 * 8 + lane_off);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[r][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pf[r]), __builtin_bit_cast(bf16x8, wa[b][s]),
+                                                                acc[r][b], 0, 0, 0);
+      }
+      if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next patch has landed, older stores have drained
+      // ReLU, round to bf16, channel pair -> one dword; a half-wave writes 128 contiguous bytes of one pixel.
+      // Buffer stores: the lane part of the address is one VGPR, the register-dependent part a scalar offset.
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + ry0 + r;
+        if (oy < p.Ho) {
+          const uint32_t row_off = (uint32_t)(((long)n * p.Ho + oy) * p.Wo + ox0) * ps2;       // scalar
+          const bool full = ox0 + TW <= p.Wo;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
+            bf16x2 v;
+            v[0] = (__bf16)fmaxf(acc[r][0][e], 0.f);
+            v[1] = (__bf16)fmaxf(acc[r][1][e], 0.f);
+            if (full || ox0 + i0 + 4 * h < p.Wo)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps2), 0);
+          }
+        }
+      }
+    }
+    __syncthreads();            // every wave's part of the next patch is in LDS; this patch is free
+    buf ^= 1;
+  }
+}
+
+}  // namespace
+
+struct okp_stem {
+  void* wfrag_dev;
+  float* bias_dev;
+};
+
+// w: HOST fp32 [128][3][7][7] (BatchNorm folded), bias: HOST fp32 [128]
+extern "C" okp_stem* okp_stem_create(const float* w, const float* bias) {
+  if (!w || !bias) { okp_set_error("okp_stem_create: null argument"); return nullptr; }
+  std::vector<uint16_t> frag((size_t)2 * 2 * KSTEPS * 64 * 8, 0);
+  auto bf16_rne = [](float f) -> uint16_t {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  for (int wc = 0; wc < 2; ++wc)
+    for (int b = 0; b < 2; ++b)
+      for (int s = 0; s < KSTEPS; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int jc = lane & 31, h = lane >> 5;                // MFMA column jc, k half h
+          const int co = 64 * wc + 2 * jc + b;
+          const int ky = s >> 1, kx0 = 4 * (s & 1);
+          uint16_t* dst = &frag[((((size_t)wc * 2 + b) * KSTEPS + s) * 64 + lane) * 8];
+          for (int e = 0; e < 8; ++e) {
+            const int kx = kx0 + 2 * h + e / 4, c = e % 4;
+            dst[e] = (kx < 7 && c < 3) ? bf16_rne(w[((co * 3 + c) * 7 + ky) * 7 + kx]) : 0;
+          }
+        }
+  okp_stem* st = new okp_stem{nullptr, nullptr};
+  if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
+      okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
+      okp_check_hip(hipMemcpy(st->wfrag_dev, frag.data(), frag.size() * 2, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
+      okp_check_hip(hipMemcpy(st->bias_dev, bias, kCout * 4, hipMemcpyHostToDevice), "okp_stem_create: copy")) {
+    if (st->wfrag_dev) (void)hipFree(st->wfrag_dev);
+    if (st->bias_dev) (void)hipFree(st->bias_dev);
+    delete st;
+    return nullptr;
+  }
+  return st;
+}
+
+extern "C" void okp_stem_destroy(okp_stem* st) {
+  if (!st) return;
+  (void)hipFree(st->wfrag_dev);
+  (void)hipFree(st->bias_dev);
+  delete st;
+}
+
+extern "C" int okp_stem_forward(const okp_stem* st, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream) {
+  if (!st || !packed || !out || !packed->data || !out->data) { okp_set_error("okp_stem_forward: null argument"); return OKP_EINVAL; }
+  if (n < 1 || h < 1 || w < 1) { okp_set_error("okp_stem_forward: empty problem"); return OKP_EINVAL; }
+  const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
+  if (packed->pix_stride != 4 || packed->h != h + 6 || packed->w < 2 * (wo - 1) + 8 || packed->w < w + 6 || packed->w % 2 ||
+      ((uintptr_t)packed->data) % 16) {
+    okp_set_error("okp_stem_forward: packed frame must be the okp_pack_frames layout (h+6 rows, even width >= w+6, 4 channels)");
+    return OKP_EINVAL;
+  }
+  if (packed->bytes <= 0 || packed->bytes >= 0x7FFF0000ll || out->bytes <= 0 || out->bytes >= 0x7FFF0000ll) { okp_set_error("okp_stem_forward: views must be < 2 GiB"); return OKP_EINVAL; }
+  if (out->h != ho || out->w != wo || out->pix_stride < kCout || (out->pix_stride * 2) % 64 || ((uintptr_t)out->data) % 64) {
+    okp_set_error("okp_stem_forward: out must be %dx%d with 64-byte aligned pixels of >= 128 channels", ho, wo);
+    return OKP_EINVAL;
+  }
+  if ((int64_t)n * ho * wo * out->pix_stride * 2 > out->bytes + (int64_t)(out->pix_stride - kCout) * 2) { okp_set_error("okp_stem_forward: out view too small"); return OKP_EINVAL; }
+  StemParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.src = packed->data; p.src_bytes = (uint32_t)packed->bytes; p.Hp = packed->h; p.Wp = packed->w;
+  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev;
+  p.out = out->data; p.out_bytes = (uint32_t)out->bytes; p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
+  p.tiles_x = (wo + TW - 1) / TW; p.tiles_y = (ho + TH - 1) / TH;
+  const long tiles = (long)n * p.tiles_x * p.tiles_y;
+  if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_stem_forward: too many tiles"); return OKP_EINVAL; }
+  p.n_tiles = (int)tiles;
+  p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_x * p.tiles_y));
+  p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
+  const int resident = 256 * 2;        // two workgroups per CU: one computes while the other's stores drain
+  const int grid = p.n_tiles < resident ? p.n_tiles : resident;
+  hipLaunchKernelGGL(okp_stem_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_stem launch");
+}

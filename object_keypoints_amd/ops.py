@@ -210,6 +210,37 @@ def pack_frames(frames, dtype):
     return act
 
 
+class StemPlan:
+    """The bf16 7x7/s2 stem (okp_stem_*): w [128,3,7,7] and bias [128] with BatchNorm folded (host fp32)."""
+
+    def __init__(self, w, bias):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32)
+        if w.shape != (128, 3, 7, 7) or b.shape != (128,):
+            raise OkpError("the stem kernel is 7x7, 3 -> 128 channels")
+        L = _lib.lib()
+        self._h = L.okp_stem_create(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        if not self._h:
+            raise OkpError("okp_stem_create: " + L.okp_last_error().decode())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        try:
+            if h and _lib is not None and _lib._lib is not None:
+                _lib._lib.okp_stem_destroy(h)
+        except Exception:
+            pass
+
+    def __call__(self, packed, out):
+        if packed.orig_hw is None or packed.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+            raise OkpError("stem input must be the bf16 output of ops.pack_frames")
+        h, w = packed.orig_hw
+        pv, ov = packed.view(), out.view()
+        _lib.check(_lib.lib().okp_stem_forward(self._h, packed.n, h, w, ctypes.byref(pv), ctypes.byref(ov), stream_handle()), "okp_stem_forward")
+        COUNTERS["macs"] += out.n * out.h * out.w * 128 * 147
+        COUNTERS["launches"] += 1
+
+
 # normalisation constants of the reference's data loader (perception/datasets/video.py:55-56)
 RGB_MEAN = (0.40789654, 0.44719302, 0.47026115)
 RGB_STD = (0.28863828, 0.27408164, 0.27809835)

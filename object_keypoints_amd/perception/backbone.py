@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..ops import Act, ConvPlan, OkpError
+from ..ops import Act, ConvPlan, OkpError, StemPlan
 
 
 # ------------------------------------------------------------------------------------------
@@ -25,6 +25,7 @@ from ..ops import Act, ConvPlan, OkpError
 # ------------------------------------------------------------------------------------------
 
 import os
+STEM_KERNEL = os.environ.get("OKP_STEM_KERNEL", "1") != "0"     # bf16: dedicated stem kernel (okp_stem.hip); 0 = generic tap-list kernel
 STEM_TILE = int(os.environ.get("OKP_STEM_TILE", "4"))      # 7x7/s2 stem: 128 co x 256 px tile measured fastest (603 vs 728 us)
 
 
@@ -93,6 +94,8 @@ class convolution(_HipModule):
         if self.inp_dim == 3:
             if self.k != 7 or self.stride != 2:
                 raise OkpError("3-channel input is supported for the 7x7/s2 stem only")
+            if dtype == torch.bfloat16 and self.out_dim == 128 and STEM_KERNEL:
+                return StemPlan(w, b)
             # one tap per kernel row: 8 pixels x 4 channels of the packed frame = 32 contiguous elements
             taps = []
             for r in range(7):
@@ -112,7 +115,10 @@ class convolution(_HipModule):
         else:
             ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
         out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
-        plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0)
+        if isinstance(plan, StemPlan):
+            plan(x, out)
+        else:
+            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0)
         return out
 
 

@@ -185,3 +185,39 @@ def test_standalone_depthwise_kernel(dtype, c, h, w, stride, n):
     ops.dwconv3x3(ops.Act.from_nchw(x.to(dev), dtype), wd, b.to(dev), out, stride, res=ops.Act.from_nchw(r.to(dev), dtype), relu=True)
     got = out.to_nchw().cpu()
     assert float((got - ref).abs().max()) <= _tol(dtype, ref)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 37, 45), (3, 511, 511), (2, 15, 130)])
+def test_stem_kernel_matches_torch(n, h, w):
+    """okp_stem_forward (dedicated bf16 7x7/s2 kernel) vs conv2d + bias + relu on the same bf16-rounded operands,
+    including partial tiles (output sizes that are not multiples of 8 x 32)."""
+    from object_keypoints_amd import ops
+    dev = _dev()
+    x = _rand((n, 3, h, w), 11).bfloat16().float()
+    wt = (_rand((128, 3, 7, 7), 12) * (1.0 / np.sqrt(147.0))).bfloat16().float()
+    b = _rand((128,), 13) * 0.1
+    ref = F.relu(F.conv2d(x, wt, b, stride=2, padding=3))
+    plan = ops.StemPlan(wt.numpy(), b.numpy())
+    packed = ops.pack_frames(x.to(dev), torch.bfloat16)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = ops.Act.empty(n, ho, wo, 128, torch.bfloat16, dev)
+    out.t.fill_(float("nan"))
+    plan(packed, out)
+    got = out.to_nchw().float().cpu()
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= _tol(torch.bfloat16, ref), f"max err {err}"
+
+
+def test_stem_kernel_rejects_bad_views():
+    from object_keypoints_amd import ops
+    dev = _dev()
+    plan = ops.StemPlan(np.zeros((128, 3, 7, 7), np.float32), np.zeros(128, np.float32))
+    packed = ops.pack_frames(torch.zeros(1, 3, 33, 33, device=dev), torch.bfloat16)
+    with pytest.raises(ops.OkpError):
+        plan(packed, ops.Act.empty(1, 16, 17, 128, torch.bfloat16, dev))       # wrong output size
+    with pytest.raises(ops.OkpError):
+        plan(packed, ops.Act.empty(1, 17, 17, 64, torch.bfloat16, dev))        # too few channels
+    with pytest.raises(ops.OkpError):
+        ops.StemPlan(np.zeros((64, 3, 7, 7), np.float32), np.zeros(64, np.float32))
