@@ -14,6 +14,7 @@
 // Out-of-frame halo pixels are zero in `s` (the reference zero-pads the squeeze output), which the gather
 // gives for free: masked LDS-DMA lanes write zeros and the bias is multiplied by the validity flag.
 // HBM traffic per module: x once (+halo overlap, mostly L2 hits) and the output once.
+#include <cstdlib>
 #include <cstring>
 
 #include "okp_internal.h"
@@ -323,6 +324,18 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
   if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||
       ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) { okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL; }
   if (a->x.bytes <= 0 || a->x.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: x spans %lld bytes; views must be < 2 GiB", (long long)a->x.bytes); return OKP_EINVAL; }
+  if (okp_fire2_supported(cin, mid, half, a->stride) && !getenv("OKP_FIRE_V1")) {
+    if (a->out.bytes <= 0 || a->out.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: out spans %lld bytes; views must be < 2 GiB", (long long)a->out.bytes); return OKP_EINVAL; }
+    OkpFire2Params q;
+    memset(&q, 0, sizeof(q));
+    q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
+    q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.out_ps = a->out.pix_stride;
+    q.N = a->n; q.skip = a->skip;
+    q.w1 = squeeze->weights_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
+    q.wa = expand->weights_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
+    q.wd = dw_w_dev; q.bd = dw_bias_dev;
+    return okp_launch_fire2(q, (hipStream_t)stream);
+  }
   OkpFireParams p;
   memset(&p, 0, sizeof(p));
   p.x = a->x.data; p.x_bytes = (uint32_t)a->x.bytes; p.H = a->x.h; p.W = a->x.w; p.x_ps = a->x.pix_stride;

@@ -1,0 +1,421 @@
+// Streaming one-launch fire module for the 256 -> 128 -> 256, stride-1 configuration (bf16, gfx950): the two
+// high-resolution hourglass levels, where the unfused module (squeeze launch + expand/depth-wise launch) is bound by
+// HBM traffic: x read twice (GEMM input + skip), the squeeze tensor written and re-read.  Here x is read once (+halo,
+// mostly L2 hits) and the output written once; the squeeze tile never leaves LDS.
+//
+//     s   = W1 x + b1                                   squeeze 1x1 (+bn1, no ReLU)      256 -> 128
+//     y_a = relu(Wa s + ba (+ x[:, :128]))              expand 1x1 (+bn2 half, skip)     128 -> 128
+//     y_b = relu(dw3x3(s) * wd + bd (+ x[:, 128:]))     depth-wise 3x3 (+bn2 half, skip) 128 -> 128
+// (reference: fire_module, corner_net_lite/core/models/CornerNet_Squeeze.py:10-30)
+//
+// Shape of the kernel (256 threads, ~71 KB LDS -> two workgroups per CU, persistent grid):
+//  * A workgroup owns an IH x IW rectangle of output pixels; the squeeze tile is that rectangle plus a one-pixel
+//    halo (SH x SW <= 128 pixels).  Halo pixels outside the frame are zero in s (the reference zero-pads s).
+//  * Both GEMMs run on 16x16x32 MFMAs with PIXELS as rows (A operand, read from LDS) and CHANNELS as columns
+//    (B operand = weights).  Wave w owns 32 channels; column j of block b is channel 32 w + 2 j + b, so a lane's two
+//    accumulator blocks are two ADJACENT channels: one dword per pixel, 16 lanes = one 64-byte line.  The squeeze
+//    result goes to LDS with ds_write_b32, the expand result straight to HBM in whole lines - no transposition.
+//  * Squeeze weights stay in registers for the whole kernel (64 VGPRs per lane, gathered once from the packed
+//    [slice][cout][128 B] plan layout); expand weights are re-fetched per tile (L2 hits, 8 loads per lane).
+//  * x streams through a 4-stage LDS ring of 64-byte K-chunks (one MFMA k-step per stage) filled by LDS-DMA; the
+//    16-byte chunk position inside a row is rotated by 2*(row>>2) so that the 16x16 fragment reads are conflict-free.
+//  * The depth-wise branch reads its 3x3 neighbourhoods from the LDS squeeze tile (runs of 4 pixels share a
+//    3 x 6 window), weights in registers for the duration of the phase.
+#include <cstring>
+
+#include "okp_internal.h"
+
+namespace {
+
+constexpr uint32_t kInvalid = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CIN = 256, MID = 128, HALF = 128;
+constexpr int KS1 = CIN / 32;                    // squeeze k-steps (8)
+constexpr int KS2 = MID / 32;                    // expand k-steps (4)
+constexpr int SP = 128;                          // squeeze-tile rows in LDS
+constexpr int PBI = 6;                           // interior pixel blocks of 16 (IP <= 96)
+constexpr int NST = 4;                           // x ring stages
+constexpr int MAXIH = 6;                         // interior rows per tile (depth-wise phase keeps a column's residuals in registers)
+constexpr int XST = SP * 64;                     // bytes per stage
+constexpr int OFF_S = 0;                         // [128][256 B] squeeze tile, 16-B chunks XOR-swizzled by row & 15
+constexpr int OFF_X = OFF_S + SP * MID * 2;      // x ring
+constexpr int OFF_WD = OFF_X + NST * XST;        // [9][128] fp32 depth-wise weights, then [128] bias
+constexpr int OFF_TAB = OFF_WD + 10 * HALF * 4;  // interior pixel ip -> byte offset relative to the tile's first pixel, in x ([96]) and in out ([96])
+constexpr int OFF_MASK = OFF_TAB + 2 * 96 * 4;       // 4 x u32 validity bits of the squeeze pixels (OFF_TAB: [96] x-relative, [96] out-relative pixel byte offsets)
+constexpr int LDS_BYTES = OFF_MASK + 16;
+
+__device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
+  return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
+}
+
+__global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params p) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, q = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+
+  // ---- once per workgroup: resident squeeze weights, depth-wise constants -> LDS -----------------------------
+  // B fragment (column = channel c, k-step ks, k-group q) = 16 bytes at [slice ks/2][row c][64 (ks&1) + 16 q]
+  const int ch0 = 32 * w + 2 * l16;                         // this lane's channel pair (ch0, ch0 + 1) in both GEMMs
+  u32x4 w1f[2][KS1];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      w1f[b][ks] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w1) + (size_t)(ks >> 1) * p.w1_cout_pad * 128 +
+                                                   (size_t)(ch0 + b) * 128 + (ks & 1) * 64 + q * 16);
+  const char* const wa_lane = static_cast<const char*>(p.wa) + (size_t)ch0 * 128 + q * 16;
+  const float b1v0 = p.b1[ch0], b1v1 = p.b1[ch0 + 1];
+  const float bav0 = p.ba[ch0], bav1 = p.ba[ch0 + 1];
+  for (int i = tid; i < 10 * HALF; i += 256)
+    reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
+  if (tid < 16 * PBI) {
+    const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
+    const uint32_t rel = (uint32_t)(iy * p.W + ix);
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? rel * (uint32_t)(p.x_ps * 2) : kInvalid;
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? rel * (uint32_t)(p.out_ps * 2) : kInvalid;
+  }
+
+  // interior pixel block pb, row l16 -> squeeze-tile row (constant over tiles: depends on the tile geometry only)
+  uint32_t a_row[PBI], a_key[PBI];
+#pragma unroll
+  for (int pb = 0; pb < PBI; ++pb) {
+    int ip = 16 * pb + l16;
+    if (ip >= p.IP) ip = 0;
+    const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
+    const int sp = (iy + 1) * p.SW + ix + 1;
+    a_row[pb] = (uint32_t)sp * (MID * 2);
+    a_key[pb] = (uint32_t)(sp & 15);
+  }
+  // x-ring fragment read: row 16 pb + l16, chunk q sits at position (q + 2 (row >> 2)) & 3 = (q + 2 (l16 >> 2)) & 3
+  const uint32_t xfrag_off = (uint32_t)l16 * 64u + (uint32_t)((q + 2 * (l16 >> 2)) & 3) * 16u;
+  // squeeze result -> LDS: register r of block pb is tile row 16 pb + 4 q + r; the pair (ch0, ch0 + 1) is one dword
+  uint32_t s_dst[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rl = 4 * q + r;
+    s_dst[r] = (uint32_t)(OFF_S + rl * (MID * 2) + (((4 * w + (l16 >> 2)) ^ rl) << 4) + (l16 & 3) * 4);
+  }
+  // LDS-DMA geometry: instruction i of this wave fills rows [32 w + 16 i, +16); lane -> (row, position).  The lane
+  // FETCHES the 16-byte k-chunk that the read-side rotation expects at its position.
+  int d_sy[2], d_sx[2];
+  uint32_t d_chunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 32 * w + 16 * i + (lane >> 2);
+    d_sy[i] = fastdiv(row, p.div_sw);
+    d_sx[i] = row - d_sy[i] * p.SW;
+    if (row >= p.SH * p.SW) d_sy[i] = 1 << 20;              // rows beyond the tile: always out of frame
+    d_chunk[i] = (uint32_t)(((lane & 3) - 2 * (row >> 2)) & 3) * 16u;
+  }
+  // validity of squeeze row `tid` (threads 0..127): same arithmetic, one row per thread
+  const int m_sy = tid < p.SH * p.SW ? fastdiv(tid, p.div_sw) : (1 << 20);
+  const int m_sx = tid - fastdiv(tid, p.div_sw) * p.SW;
+
+  auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+    n = fastdiv(tile, p.div_tiles_frame);
+    const int trem = tile - n * p.tiles_y * p.tiles_x;
+    const int ty = fastdiv(trem, p.div_tiles_x);
+    y0 = ty * p.IH;                                          // frame coordinates of interior pixel (0, 0)
+    x0 = (trem - ty * p.tiles_x) * p.IW;
+  };
+  uint32_t d_off[2];
+  auto tile_setup = [&](int tile) {                          // DMA source offsets + validity bits of `tile`
+    int n, y0, x0;
+    tile_origin(tile, n, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = y0 - 1 + d_sy[i], x = x0 - 1 + d_sx[i];
+      const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+      d_off[i] = ok ? (uint32_t)(((long)n * p.H + y) * p.W + x) * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
+    }
+    if (tid < SP) {
+      const int y = y0 - 1 + m_sy, x = x0 - 1 + m_sx;
+      const unsigned long long m = __ballot(y >= 0 && y < p.H && x >= 0 && x < p.W);
+      if (lane == 0) {
+        uint32_t* mk = reinterpret_cast<uint32_t*>(smem + OFF_MASK);
+        mk[2 * w] = (uint32_t)m;
+        mk[2 * w + 1] = (uint32_t)(m >> 32);
+      }
+    }
+  };
+  auto issue_x = [&](int ks, int stage) {
+    char* dst = smem + OFF_X + stage * XST + (32 * w) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(dst + i * 1024), 16,
+                                               (int)(d_off[i] == kInvalid ? kInvalid : d_off[i] + (uint32_t)ks * 64u), 0, 0, 0);
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.n_tiles) return;
+  __syncthreads();                                           // depth-wise constants are in LDS
+  tile_setup(tile);
+#pragma unroll
+  for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    int n, y0, x0;
+    tile_origin(tile, n, y0, x0);
+    // opaque copies: the per-(block, register) pixel arithmetic below is tile-invariant, and hoisting ~100 such
+    // values out of the tile loop costs more registers than recomputing them (a multiply-high each)
+    int qt = q, tidt = tid;
+    asm volatile("" : "+v"(qt), "+v"(tidt));
+    // phase 2b residuals of column `ix` (thread = 8-channel group cg, column slot): one 16-byte load per output row
+    auto load_col_residuals = [&](int ix, u32x4 (&rr)[MAXIH], uint32_t (&oo)[MAXIH]) {
+      const int cg = tidt & 15;
+      const int ox = x0 + ix;
+      const uint32_t pix = (uint32_t)(((long)n * p.H + y0) * p.W + ox);
+      uint32_t xo = pix * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u, oof = pix * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u;
+      const bool col_ok = ix < p.IW && ox < p.W;
+#pragma unroll
+      for (int iy = 0; iy < MAXIH; ++iy) {
+        const bool ok = col_ok && iy < p.IH && y0 + iy < p.H;
+        oo[iy] = ok ? oof : kInvalid;
+        rr[iy] = u32x4{0u, 0u, 0u, 0u};
+        if (p.skip) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
+        xo += (uint32_t)(p.W * p.x_ps * 2);
+        oof += (uint32_t)(p.W * p.out_ps * 2);
+      }
+    };
+    uint32_t o_off[PBI][4], r_raw[PBI][4];                  // phase 2a: output offsets and residual pairs of this lane's pixels
+    u32x4 rr[MAXIH];                                        // phase 2b: residuals / output offsets of this thread's first column
+    uint32_t oo[MAXIH];
+
+    // ---- phase 1: s = W1 x + b1 on the halo'd tile, x through the LDS ring -------------------------------------
+    // The first NST-1 ring steps of this tile were issued during the previous tile's phase 2 (or above).
+    f32x4 acc[SP / 16][2];
+#pragma unroll
+    for (int pb = 0; pb < SP / 16; ++pb) {
+      acc[pb][0] = f32x4{b1v0, b1v0, b1v0, b1v0};
+      acc[pb][1] = f32x4{b1v1, b1v1, b1v1, b1v1};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      // ks == 0: everything older (the previous tile's stores, the prefetched steps) must be done, because loads
+      // and stores share the counter; afterwards steps ks+1, ks+2 may stay in flight (2 LDS-DMA each per wave)
+      if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (ks >= NST - 1 && ks + 2 < KS1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (ks >= NST - 1 && ks + 1 < KS1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (ks >= NST - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
+      const char* st = smem + OFF_X + (ks % NST) * XST + xfrag_off;
+      u32x4 a[SP / 16];
+#pragma unroll
+      for (int pb = 0; pb < SP / 16; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
+#pragma unroll
+      for (int pb = 0; pb < SP / 16; ++pb)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[b][ks]),
+                                                               acc[pb][b], 0, 0, 0);
+    }
+    // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
+    u32x4 waf[2][KS2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks)
+        waf[b][ks] = *reinterpret_cast<const u32x4*>(wa_lane + (size_t)(ks >> 1) * p.wa_cout_pad * 128 + b * 128 + (ks & 1) * 64);
+    // s -> LDS (zero outside the frame: the reference zero-pads the squeeze output)
+    {
+      const uint32_t* mk = reinterpret_cast<const uint32_t*>(smem + OFF_MASK);
+      uint32_t mq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mq[i] = mk[i] >> (4 * qt);
+#pragma unroll
+      for (int pb = 0; pb < SP / 16; ++pb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (mq[pb >> 1] >> (16 * (pb & 1) + r)) & 1u;
+          bf16x2 v;
+          v[0] = (__bf16)(ok ? acc[pb][0][r] : 0.f);
+          v[1] = (__bf16)(ok ? acc[pb][1][r] : 0.f);
+          *reinterpret_cast<bf16x2*>(smem + s_dst[r] + pb * 16 * (MID * 2)) = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
+    {
+      // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
+      // pixels from the per-workgroup table (one 16-byte LDS read per block); edge tiles do the arithmetic.
+      const bool full = y0 + p.IH <= p.H && x0 + p.IW <= p.W;
+      const uint32_t pix0 = (uint32_t)(((long)n * p.H + y0) * p.W + x0);
+      const uint32_t xb = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)ch0 * 2u, ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)ch0 * 2u;
+#pragma unroll
+      for (int pb = 0; pb < PBI; ++pb) {
+        u32x4 xr = {kInvalid, kInvalid, kInvalid, kInvalid}, orr = {kInvalid, kInvalid, kInvalid, kInvalid};
+        if (16 * pb < p.IP) {
+          xr = *reinterpret_cast<const u32x4*>(smem + OFF_TAB + (16 * pb + 4 * qt) * 4);
+          orr = *reinterpret_cast<const u32x4*>(smem + OFF_TAB + (96 + 16 * pb + 4 * qt) * 4);
+          if (!full) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ip = 16 * pb + 4 * qt + r;
+              const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
+              if (y0 + iy >= p.H || x0 + ix >= p.W) { xr[r] = kInvalid; orr[r] = kInvalid; }
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o_off[pb][r] = orr[r] == kInvalid ? kInvalid : ob + orr[r];
+          r_raw[pb][r] = 0;
+          if (p.skip && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
+        }
+      }
+      f32x4 ac2[PBI][2];
+#pragma unroll
+      for (int pb = 0; pb < PBI; ++pb) {
+        ac2[pb][0] = f32x4{bav0, bav0, bav0, bav0};
+        ac2[pb][1] = f32x4{bav1, bav1, bav1, bav1};
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+#pragma unroll
+        for (int pb = 0; pb < PBI; ++pb) {
+          if (16 * pb < p.IP) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_S + a_row[pb] + (((uint32_t)(4 * ks + qt) ^ a_key[pb]) << 4));
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              ac2[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, waf[b][ks]),
+                                                                   ac2[pb][b], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int pb = 0; pb < PBI; ++pb) {
+        if (16 * pb < p.IP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bf16x2 rv = __builtin_bit_cast(bf16x2, r_raw[pb][r]);
+            bf16x2 v;
+            v[0] = (__bf16)fmaxf(ac2[pb][0][r] + (float)rv[0], 0.f);
+            v[1] = (__bf16)fmaxf(ac2[pb][1][r] + (float)rv[1], 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)o_off[pb][r], 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");             // keep the stores here (the scheduler otherwise sinks them below phase 2b)
+
+    // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
+    // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
+    // output rows that see it as tap row 2, 1, 0; depth-wise weights in registers for the phase.
+    {
+      const int cg = tidt & 15;
+      const float* const wl = reinterpret_cast<const float*>(smem + OFF_WD) + cg * 8;     // [tap][128] fp32, bias at tap 9
+      float breg[8];
+      {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(wl + 9 * HALF), u1 = *reinterpret_cast<const f32x4*>(wl + 9 * HALF + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { breg[e] = u0[e]; breg[4 + e] = u1[e]; }
+      }
+      bool prefetched = false;
+      for (int ix = tidt >> 4; ix < ((p.IW + 15) & ~15); ix += 16) {       // uniform trip count: the prefetch sits inside
+        // residuals of the whole column first, then the next tile's first ring steps (HBM): those land behind the
+        // residuals, while the taps run
+        load_col_residuals(ix, rr, oo);
+        if (!prefetched) {
+          prefetched = true;
+          const int next = tile + gridDim.x;
+          if (next < p.n_tiles) {
+            tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
+#pragma unroll
+            for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+          }
+        }
+        const int ixc = ix < p.IW ? ix : 0;
+        f32x2 v[MAXIH][4];                                   // one accumulator row per output row of the column
+#pragma unroll
+        for (int iy = 0; iy < MAXIH; ++iy)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[iy][e] = f32x2{breg[2 * e], breg[2 * e + 1]};
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          f32x2 wt[3][4];                                    // the three taps of this column position
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * HALF), u1 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * HALF + 4);
+            wt[dy][0] = f32x2{u0[0], u0[1]}; wt[dy][1] = f32x2{u0[2], u0[3]}; wt[dy][2] = f32x2{u1[0], u1[1]}; wt[dy][3] = f32x2{u1[2], u1[3]};
+          }
+#pragma unroll
+          for (int sr = 0; sr < MAXIH + 2; ++sr) {           // squeeze row sr is tap row dy of output row sr - dy
+            if (sr < p.IH + 2) {
+              const int sp = sr * p.SW + ixc + dx;
+              const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & 15)) << 4));
+              f32x2 s2[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s2[e] = f32x2{__builtin_bit_cast(float, sv[e] << 16), __builtin_bit_cast(float, sv[e] & 0xffff0000u)};
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int iy = sr - dy;
+                if (iy >= 0 && iy < MAXIH) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_elementwise_fma(s2[e], wt[dy][e], v[iy][e]);
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int iy = 0; iy < MAXIH; ++iy) {
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = fmaxf(v[iy][e][0] + __builtin_bit_cast(float, rr[iy][e] << 16), 0.f);
+            const float hi = fmaxf(v[iy][e][1] + __builtin_bit_cast(float, rr[iy][e] & 0xffff0000u), 0.f);
+            bf16x2 pk;
+            pk[0] = (__bf16)lo; pk[1] = (__bf16)hi;
+            o[e] = __builtin_bit_cast(uint32_t, pk);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
+        }
+      }
+    }
+    // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
+  }
+}
+
+}  // namespace
+
+bool okp_fire2_supported(int cin, int mid, int half, int stride) {
+  return cin == CIN && mid == MID && half == HALF && stride == 1;
+}
+
+int okp_launch_fire2(OkpFire2Params p, hipStream_t stream) {
+  // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
+  // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
+  long best = -1;
+  for (int ih = 1; ih <= p.H && ih <= MAXIH; ++ih)
+    for (int iw = 1; iw <= p.W && iw <= 96; ++iw) {
+      const int sh = ih + 2, sw = iw + 2;
+      if (sh * sw > SP || ih * iw > 16 * PBI) continue;
+      const long ty = (p.H + ih - 1) / ih, tx = (p.W + iw - 1) / iw;
+      const long score = ty * tx * 4096 - iw;
+      if (best < 0 || score < best) { best = score; p.IH = ih; p.IW = iw; p.SH = sh; p.SW = sw; p.tiles_y = (int)ty; p.tiles_x = (int)tx; }
+    }
+  p.IP = p.IH * p.IW;
+  p.RPR = (p.IW + 3) / 4;
+  const long tiles = (long)p.N * p.tiles_y * p.tiles_x;
+  if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_fire_forward: too many tiles"); return OKP_EINVAL; }
+  p.n_tiles = (int)tiles;
+  p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x));
+  p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
+  p.div_sw = okp_fastdiv((uint32_t)p.SW);
+  p.div_iw = okp_fastdiv((uint32_t)p.IW);
+  p.div_rpr = okp_fastdiv((uint32_t)p.RPR);
+  const int resident = 256 * 2;
+  const int grid = p.n_tiles < resident ? p.n_tiles : resident;
+  hipLaunchKernelGGL(okp_fire2_kernel, dim3(grid), dim3(256), 0, stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_fire2 launch");
+}

@@ -4,6 +4,7 @@ torch is used for device memory and streams only: every computation below is a c
 libokp_hip.so on `torch.cuda.current_stream()`.  Nothing here has a CPU path.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -173,8 +174,17 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
 
 
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
-FUSE_FIRE = False       # one-launch fire module (okp_fire_forward): correct, but measured slower than squeeze + fused tail
-                        # at every hourglass level in round 1 (231 vs 193 us at 64x64, N=64) - kept as an experiment
+FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
+                        # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64
+FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "32"))   # smaller maps: two launches are as fast
+FUSE_FIRE_ALL = False   # tests: also route the other configurations through the first-generation one-launch kernel
+                        # (okp_fire.hip: correct, but slower than squeeze + fused tail at every level)
+
+
+def fire_fusable(inp_dim, mid, stride, h, w):
+    if FUSE_FIRE_ALL:
+        return inp_dim % 64 == 0 and mid % 64 == 0 and mid <= 256
+    return FUSE_FIRE and inp_dim == 256 and mid == 128 and stride == 1 and min(h, w) >= FUSE_FIRE_MIN_HW
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):

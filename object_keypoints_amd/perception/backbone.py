@@ -193,7 +193,7 @@ class fire_module(_HipModule):
         squeeze, expand, wd, bd = self._plan(("p", x.dtype), lambda: self._build(x.dtype, x.t.device))
         half = self.out_dim // 2
         ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
-        if (ops.FUSE_FIRE and x.dtype == torch.bfloat16 and self.inp_dim % 64 == 0 and self.mid % 64 == 0 and self.mid <= 256):
+        if x.dtype == torch.bfloat16 and ops.fire_fusable(self.inp_dim, self.mid, self.stride, x.h, x.w):
             out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
             ops.fire_fused(squeeze, expand, wd, bd, x, out, self.stride, self.skip)
             return out

@@ -136,6 +136,9 @@ def test_bad_arguments_are_reported():
     (512, 512, 4, 4, 1, 7),        # several whole frames per workgroup
     (384, 384, 13, 9, 1, 2),       # odd sizes
     (384, 256, 16, 16, 1, 2),      # no skip (cin != cout)
+    (256, 256, 33, 21, 1, 2),      # streaming kernel (okp_fire2): odd sizes, partial tiles on both axes
+    (256, 256, 7, 5, 1, 3),        # streaming kernel: one small tile per frame
+    (256, 256, 32, 32, 1, 4),      # streaming kernel: the 32x32 hourglass level
 ])
 def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
     """One-launch bf16 fire module vs the oracle's fire_module (fp32) on the same bf16-rounded input, and vs the
@@ -152,19 +155,50 @@ def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
     with torch.no_grad():
         ref = o(x)
     xa = ops.Act.from_nchw(x.to(dev), torch.bfloat16)
-    ops.FUSE_FIRE = True
+    ops.FUSE_FIRE_ALL = True
     try:
         l0 = ops.COUNTERS["launches"]
         got = m(xa).to_nchw().cpu()
         assert ops.COUNTERS["launches"] - l0 == 1
     finally:
-        ops.FUSE_FIRE = False
-    unfused = m(xa).to_nchw().cpu()
+        ops.FUSE_FIRE_ALL = False
+    keep, ops.FUSE_FIRE = ops.FUSE_FIRE, False
+    try:
+        l0 = ops.COUNTERS["launches"]
+        unfused = m(xa).to_nchw().cpu()
+        assert ops.COUNTERS["launches"] - l0 == 2
+    finally:
+        ops.FUSE_FIRE = keep
     scale = float(ref.abs().max())
     assert got.shape == ref.shape
     err = (got - ref).abs()
     assert float(err.max()) <= 0.03 * scale + 0.02, f"max err {float(err.max())} scale {scale}"
     assert float((got - unfused).abs().max()) <= 0.02 * scale + 0.02
+
+
+def test_streaming_fire_without_skip():
+    """okp_fire2 with the skip connection switched off (the reference module always has it at 256 -> 256; the C ABI
+    takes it as an argument)."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    dev = _dev()
+    o = onet.load_synthetic(onet.fire_module(256, 256), seed=22)
+    m = bb.fire_module(256, 256)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    o.skip = False
+    m.skip = False
+    x = _rand((2, 256, 19, 23), 32).bfloat16().float()
+    with torch.no_grad():
+        ref = o(x)
+    ops.FUSE_FIRE_ALL = True
+    try:
+        got = m(ops.Act.from_nchw(x.to(dev), torch.bfloat16)).to_nchw().cpu()
+    finally:
+        ops.FUSE_FIRE_ALL = False
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 0.03 * scale + 0.02
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
