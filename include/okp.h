@@ -242,7 +242,7 @@ int okp_lift_peaks(const okp_camera* cam, const int32_t* count_dev, const float*
  * count 1 the most confident one, otherwise the first `type_count` in peak order with `overflow` set so the caller
  * can run the reference's k-means on them (its unseeded KMeans is not reproducible bit for bit anyway).
  *   count [n][K] int32, xyc [n][K][cap][3] fp32 (okp_peak_nms outputs), centers [n][K-1][2][h][w] fp32
- *   n_obj   [n] int32                         objects per frame (= min(count[n][0], max_obj))
+ *   n_obj   [n] int32                         objects per frame (= min(count[n][0], max_obj)); max_obj <= 64
  *   sel     [n][max_obj][K-1][max_sel] int32  selected peak indices into map k, -1 = empty slot
  *   n_votes [n][max_obj][K-1] int32           votes the object received for that type (before the cut)
  *   assign  [n][K][cap] int32                 object index each peak voted for (-1: none / dropped / map 0)

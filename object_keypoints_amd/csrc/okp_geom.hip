@@ -101,54 +101,88 @@ struct GroupParams {
   int* n_obj; int* sel; int* n_votes; int* assign; double* pred;
 };
 
-// One lane per frame: tens of peaks per frame, the loops are tiny; what matters is that the batch never leaves the
-// device between peak extraction and the all-gather.  Distances are evaluated in fp64 like the reference (NumPy
-// promotes float32 centres + float64 pixel grid to float64).
-__global__ void okp_group_objects_kernel(const GroupParams p) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= p.n) return;
+// One wave per frame, one lane per peak.  The reference walks the peaks of a keypoint type in order and lets each
+// vote for the nearest object centre (pipeline.py:121-133); here the votes of up to 64 peaks are taken at once and
+// the order-dependent parts are rebuilt from ballots: a peak's slot among the votes of its object is the number of
+// lower lanes voting for the same object, and the "most confident vote, first one wins ties" rule is a wave-wide
+// (max confidence, lowest lane) reduction.  Lane o keeps the running vote count / best vote of object o.
+// Distances are evaluated in fp64 like the reference (NumPy promotes float32 centres + float64 pixel grid).
+__global__ __launch_bounds__(64) void okp_group_objects_kernel(const GroupParams p) {
+  __shared__ float oc[64 * 2];
+  const int f = blockIdx.x, lane = threadIdx.x;
   const int* cnt = p.count + (size_t)f * p.K;
   const float* pk = p.xyc + (size_t)f * p.K * p.cap * 3;
   const int nobj = min(min(cnt[0], p.cap), p.max_obj);
-  p.n_obj[f] = nobj;
+  if (lane == 0) p.n_obj[f] = nobj;
   int* sel = p.sel + (size_t)f * p.max_obj * (p.K - 1) * p.max_sel;
   int* votes = p.n_votes + (size_t)f * p.max_obj * (p.K - 1);
-  for (int i = 0; i < p.max_obj * (p.K - 1) * p.max_sel; ++i) sel[i] = -1;
-  for (int i = 0; i < p.max_obj * (p.K - 1); ++i) votes[i] = 0;
+  for (int i = lane; i < p.max_obj * (p.K - 1) * p.max_sel; i += 64) sel[i] = -1;
+  for (int i = lane; i < p.max_obj * (p.K - 1); i += 64) votes[i] = 0;
   int* assign = p.assign + (size_t)f * p.K * p.cap;
   double* pred = p.pred + (size_t)f * p.K * p.cap * 2;
-  for (int i = 0; i < p.K * p.cap; ++i) assign[i] = -1;
+  for (int i = lane; i < p.K * p.cap; i += 64) assign[i] = -1;
   if (nobj == 0) return;
+  if (lane < nobj) { oc[2 * lane] = pk[lane * 3 + 0]; oc[2 * lane + 1] = pk[lane * 3 + 1]; }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
   for (int k = 1; k < p.K; ++k) {
     const int want = p.type_count[k - 1];
     const float* cmap = p.centers + ((size_t)f * (p.K - 1) + (k - 1)) * 2 * p.H * p.W;
     const int npk = min(cnt[k], p.cap);
-    for (int j = 0; j < npk; ++j) {
-      const float* q = pk + ((size_t)k * p.cap + j) * 3;
-      int xi = (int)rintf(q[0]), yi = (int)rintf(q[1]);
-      xi = min(max(xi, 0), p.W - 1);
-      yi = min(max(yi, 0), p.H - 1);
-      const double cx = ((double)xi + 0.5) + (double)cmap[(size_t)yi * p.W + xi];
-      const double cy = ((double)yi + 0.5) + (double)cmap[(size_t)p.H * p.W + (size_t)yi * p.W + xi];
-      int best = 0;
-      double bestd = 1e300;
+    int my_votes = 0, my_best_j = -1;                    // state of object `lane`
+    float my_best_conf = 0.f;
+    for (int base = 0; base < npk; base += 64) {
+      const int j = base + lane;
+      const bool active = j < npk;
+      int best = -1;
+      float conf = 0.f;
+      bool ok = false;
+      if (active) {
+        const float* q = pk + ((size_t)k * p.cap + j) * 3;
+        int xi = (int)rintf(q[0]), yi = (int)rintf(q[1]);
+        xi = min(max(xi, 0), p.W - 1);
+        yi = min(max(yi, 0), p.H - 1);
+        const double cx = ((double)xi + 0.5) + (double)cmap[(size_t)yi * p.W + xi];
+        const double cy = ((double)yi + 0.5) + (double)cmap[(size_t)p.H * p.W + (size_t)yi * p.W + xi];
+        double bestd = 1e300;
+        best = 0;
+        for (int o = 0; o < nobj; ++o) {
+          const double dx = (double)oc[2 * o] - cx, dy = (double)oc[2 * o + 1] - cy;
+          const double d = sqrt(dx * dx + dy * dy);
+          if (d < bestd) { bestd = d; best = o; }
+        }
+        pred[((size_t)k * p.cap + j) * 2 + 0] = cx;
+        pred[((size_t)k * p.cap + j) * 2 + 1] = cy;
+        ok = !(bestd > (double)p.max_dist);
+        if (ok) assign[k * p.cap + j] = best;
+        conf = q[2];
+      }
       for (int o = 0; o < nobj; ++o) {
-        const double dx = (double)pk[o * 3 + 0] - cx, dy = (double)pk[o * 3 + 1] - cy;
-        const double d = sqrt(dx * dx + dy * dy);
-        if (d < bestd) { bestd = d; best = o; }
+        const bool mine = ok && best == o;
+        const unsigned long long m = __ballot(mine);
+        if (m == 0ull) continue;
+        const int v0 = __shfl(my_votes, o);              // votes object o had before this batch of peaks
+        if (want == 1) {                                 // most confident vote; the first one wins ties, as argmax does
+          float c = mine ? conf : -__builtin_inff();
+          int l = mine ? lane : 64;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const float c2 = __shfl_xor(c, off);
+            const int l2 = __shfl_xor(l, off);
+            if (c2 > c || (c2 == c && l2 < l)) { c = c2; l = l2; }
+          }
+          if (l == 64) l = __ffsll((long long)m) - 1;     // every confidence compared false (NaN): first voter
+          if (lane == o && (v0 == 0 || c > my_best_conf)) { my_best_conf = c; my_best_j = base + l; }
+        } else if (mine) {
+          const int v = v0 + __popcll(m & below);
+          if (v < p.max_sel) sel[((size_t)o * (p.K - 1) + (k - 1)) * p.max_sel + v] = j;   // peak order; the caller resolves v > want
+        }
+        if (lane == o) my_votes += __popcll(m);
       }
-      pred[((size_t)k * p.cap + j) * 2 + 0] = cx;
-      pred[((size_t)k * p.cap + j) * 2 + 1] = cy;
-      if (bestd > (double)p.max_dist) continue;
-      assign[k * p.cap + j] = best;
-      int* vs = votes + best * (p.K - 1) + (k - 1);
-      int* ss = sel + ((size_t)best * (p.K - 1) + (k - 1)) * p.max_sel;
-      const int v = (*vs)++;
-      if (want == 1) {                                   // keep the most confident vote (first one wins ties, as argmax does)
-        if (v == 0 || q[2] > pk[((size_t)k * p.cap + ss[0]) * 3 + 2]) ss[0] = j;
-      } else if (v < p.max_sel) {
-        ss[v] = j;                                        // peak order; the caller resolves v > want (k-means) itself
-      }
+    }
+    if (lane < nobj) {
+      votes[lane * (p.K - 1) + (k - 1)] = my_votes;
+      if (want == 1 && my_votes > 0) sel[((size_t)lane * (p.K - 1) + (k - 1)) * p.max_sel] = my_best_j;
     }
   }
 }
@@ -412,13 +446,13 @@ extern "C" int okp_group_objects(const int32_t* count, const float* xyc, const f
                                  int32_t h, int32_t w, const int32_t* type_count, float max_dist, int32_t max_obj, int32_t max_sel,
                                  int32_t* n_obj, int32_t* sel, int32_t* n_votes, int32_t* assign, double* pred, void* stream) {
   if (!count || !xyc || !centers || !type_count || !n_obj || !sel || !n_votes || !assign || !pred) { okp_set_error("okp_group_objects: null argument"); return OKP_EINVAL; }
-  if (K < 2 || K > 8 || max_sel < 1 || max_sel > 8 || max_obj < 1 || cap < 1) { okp_set_error("okp_group_objects: K in [2,8], max_sel in [1,8] required"); return OKP_EINVAL; }
+  if (K < 2 || K > 8 || max_sel < 1 || max_sel > 8 || max_obj < 1 || max_obj > 64 || cap < 1) { okp_set_error("okp_group_objects: K in [2,8], max_sel in [1,8], max_obj in [1,64] required"); return OKP_EINVAL; }
   if (n <= 0) return OKP_OK;
   GroupParams p;
   p.count = count; p.xyc = xyc; p.centers = centers; p.n = n; p.K = K; p.cap = cap; p.H = h; p.W = w;
   p.max_obj = max_obj; p.max_sel = max_sel; p.max_dist = max_dist; p.n_obj = n_obj; p.sel = sel; p.n_votes = n_votes; p.assign = assign; p.pred = pred;
   for (int k = 0; k < 8; ++k) p.type_count[k] = k < K - 1 ? type_count[k] : 0;
-  hipLaunchKernelGGL(okp_group_objects_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(okp_group_objects_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_group_objects launch");
 }
 
