@@ -10,20 +10,22 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int cap,
+constexpr int kNmsThreads = 1024;            // 4 pixels per thread on a 64x64 map: the map is latency-, not bandwidth-bound
+
+__global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int cap,
                                                            int* __restrict__ count, int* __restrict__ yx,
                                                            float* __restrict__ xyc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HW = H * W;
   float* prob = lds;            // [HW]
   float* box = lds + HW;        // [HW]
-  __shared__ int wave_tot[4];
+  __shared__ int wave_tot[kNmsThreads / 64];
   const int map = blockIdx.x;
   const int tid = threadIdx.x;
   const float* src = heat + (size_t)map * HW;
-  for (int i = tid; i < HW; i += 256) prob[i] = src[i];
+  for (int i = tid; i < HW; i += kNmsThreads) prob[i] = src[i];
   __syncthreads();
-  for (int i = tid; i < HW; i += 256) {
+  for (int i = tid; i < HW; i += kNmsThreads) {
     const int y = i / W, x = i - y * W;
     float s = 0.f;
     for (int dy = -2; dy <= 2; ++dy) {
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void okp_peak_nms_kernel(const float* __restri
   int running = 0;
   int* my_yx = yx + (size_t)map * cap * 2;
   float* my_xyc = xyc + (size_t)map * cap * 3;
-  for (int base = 0; base < HW; base += 256) {
+  for (int base = 0; base < HW; base += kNmsThreads) {
     const int i = base + tid;
     bool peak = false;
     int y = 0, x = 0;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void okp_peak_nms_kernel(const float* __restri
     int off = running + before;
     int tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kNmsThreads / 64; ++w) {
       const int t = wave_tot[w];
       if (w < wave) off += t;
       tot += t;
@@ -145,6 +147,6 @@ extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_
       return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream, heat, h, w, cap, count, yx, xyc);
+  hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(kNmsThreads), lds, (hipStream_t)stream, heat, h, w, cap, count, yx, xyc);
   return okp_check_hip(hipGetLastError(), "okp_peak_nms launch");
 }
