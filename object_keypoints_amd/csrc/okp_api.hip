@@ -199,6 +199,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.div_howo = okp_fastdiv((uint32_t)(a->ho * a->wo)); p.div_wo = okp_fastdiv((uint32_t)a->wo);
   p.out = a->out.data; p.OH = a->out.h; p.OW = a->out.w; p.out_step = a->out_step; p.out_oy = a->out_oy; p.out_ox = a->out_ox;
   p.out_pix_stride = a->out.pix_stride; p.cout = plan->cout;
+  p.out_bytes = (uint32_t)a->out.bytes; p.res_bytes = a->res.data ? (uint32_t)a->res.bytes : 0u;
   p.res = a->res.data; p.res_pix_stride = a->res.pix_stride; p.act = plan->act;
   for (int t = 0; t < plan->n_taps; ++t) p.taps[t] = plan->taps[t];
   p.n_classes = a->n_classes > 1 ? a->n_classes : 1;

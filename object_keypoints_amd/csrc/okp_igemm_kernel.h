@@ -24,6 +24,9 @@
 #ifndef OKP_XB
 #define OKP_XB 1
 #endif
+#ifndef OKP_DS
+#define OKP_DS 0      // direct-store epilogue of the 256x256 16x16-MFMA tile: correct, measured 3-4 % SLOWER than the LDS transposition
+#endif             // (dword stores, 4x the store instructions of the 16-byte path): kept as a compile-time experiment
 
 namespace {
 
@@ -147,6 +150,12 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
   static_assert(BPX * BCO * ESZ / PASSES <= LDS_BYTES, "epilogue staging must fit");
   constexpr int PX_PER_PASS = BPX / PASSES;
+  // DS (direct store, the bf16 256x256 16x16-MFMA tile): PIXELS are the MFMA rows and channels the columns, with the
+  // weight rows of every 32-channel group interleaved in LDS (row 16 b + j = channel 2 j + b, done by the LDS-DMA's
+  // source addressing).  A lane's accumulators of blocks 2 u, 2 u + 1 are then two ADJACENT channels of one pixel:
+  // the epilogue packs them into one dword and 16 lanes write one 64-byte line straight from registers - no LDS
+  // transposition, no barriers, and the stores drain while the next tile's gather runs.
+  constexpr bool DS = OKP_DS && ESZ == 2 && MT == 16 && BCO == 256 && WCO == 4 && TCO == 4;
   constexpr int PITCH = BCO * ESZ;
 
   // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   uint32_t wbase[WROWS];
 #pragma unroll
   for (int i = 0; i < WROWS; ++i) {
-    const int co = co0 + r0 + i * RPP;
+    const int wrow = r0 + i * RPP;                            // LDS row of the weight tile
+    const int co = co0 + (DS ? (wrow & ~31) + 2 * (wrow & 15) + ((wrow >> 4) & 1) : wrow);
     wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)c * 16u : kInvalidOff;
   }
   uint32_t xbase[NSRC][XROWS];
@@ -312,7 +322,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
     for (int i = 0; i < TCO; ++i)
 #pragma unroll
-      for (int j = 0; j < TPX; ++j) Mma<T, MT>::run(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < TPX; ++j) {
+        if constexpr (DS) Mma<T, MT>::run(b[j], a[i], acc[i][j]);      // pixels = rows, channels = columns
+        else Mma<T, MT>::run(a[i], b[j], acc[i][j]);
+      }
   };
 
   // ---- main loop: NS-deep LDS ring filled by LDS-DMA, one barrier per ring step -------------------------
@@ -438,6 +451,60 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // 256x256 tile fits the ring's LDS, so all waves stage at once and the tile leaves in ONE pass; the residual is
   // added after the read-back (bf16 + residual in fp32, ReLU, one more rounding).
   const bool dense_out = p.out_step == 1 && p.OH == p.Ho && p.OW == p.Wo;   // output pixel index == GEMM pixel index
+  if constexpr (DS) {
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)p.res_bytes, 0x00020000);
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    // this lane's channel pairs: blocks (0,1) -> pair 0, (2,3) -> pair 1; accumulator register r of pixel block j is
+    // pixel row 16 j + 4 fh + r
+    float bz[2][2];
+    uint32_t ch_b[2];                                  // byte offset of the pair inside a pixel, or invalid beyond cout
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cl = wco * 64 + 32 * u + 2 * fr;
+      // straight from HBM/L2 (padded to the tile): a wave that runs ahead into the next tile re-fills bias_lds
+      bz[u][0] = p.bias[co0 + cl];
+      bz[u][1] = p.bias[co0 + cl + 1];
+      ch_b[u] = co0 + cl < p.cout ? (uint32_t)(co0 + cl) * 2u : kInvalidOff;
+    }
+    const bool relu = p.act == OKP_ACT_RELU;
+#pragma unroll
+    for (int j = 0; j < TPX; ++j) {
+      uint32_t ob[4], rv[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pix = px0 + (wpx * TPX + j) * 16 + 4 * fh + r;
+        uint32_t opix = (uint32_t)pix;
+        if (!dense_out) {
+          const int pp = pix < P ? pix : 0;
+          const int n = fastdiv(pp, p.div_howo);
+          const int rem = pp - n * HoWo;
+          const int ho = fastdiv(rem, p.div_wo);
+          const int wo = rem - ho * p.Wo;
+          opix = (uint32_t)((n * p.OH + (ho * p.out_step + out_oy)) * p.OW + (wo * p.out_step + out_ox));
+        }
+        ob[r] = pix < P ? opix : kInvalidOff;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          rv[r][u] = 0u;
+          if (p.res) rv[r][u] = __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)((ob[r] | ch_b[u]) & kInvalidOff ? kInvalidOff : ob[r] * (uint32_t)(p.res_pix_stride * 2) + ch_b[u]), 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v0 = acc[2 * u][j][r] + bz[u][0], v1 = acc[2 * u + 1][j][r] + bz[u][1];
+          v0 += __builtin_bit_cast(float, rv[r][u] << 16);
+          v1 += __builtin_bit_cast(float, rv[r][u] & 0xffff0000u);
+          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          bf16x2 o;
+          o[0] = (__bf16)v0; o[1] = (__bf16)v1;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), rs_o,
+                                                (int)((ob[r] | ch_b[u]) & kInvalidOff ? kInvalidOff : ob[r] * (uint32_t)(p.out_pix_stride * 2) + ch_b[u]), 0, 0);
+        }
+    }
+  } else {
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wpx == pass) {
@@ -533,6 +600,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     }
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
+  }  // !DS
 
   // ---- optional fused depth-wise 3x3 branch over the same pixels / channel range (fire-module tail) -------
   // A thread owns one 16-byte channel group (its 9 x VN weights live in registers) and SEG consecutive pixels,

@@ -53,6 +53,7 @@ struct OkpIgemmParams {
   int32_t N, Ho, Wo;
   OkpFastDiv div_howo, div_wo;
   void* out;
+  uint32_t out_bytes, res_bytes;
   int32_t OH, OW, out_step, out_oy, out_ox, out_pix_stride;
   int32_t cout;
   const void* res;
