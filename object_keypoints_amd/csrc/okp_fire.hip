@@ -334,7 +334,7 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.w1 = squeeze->weights_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
     q.wa = expand->weights_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
     q.wd = dw_w_dev; q.bd = dw_bias_dev;
-    return okp_launch_fire2(q, (hipStream_t)stream);
+    return okp_launch_fire2(q, cin, mid, (hipStream_t)stream);
   }
   OkpFireParams p;
   memset(&p, 0, sizeof(p));

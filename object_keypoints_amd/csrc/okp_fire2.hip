@@ -1,22 +1,25 @@
-// Streaming one-launch fire module for the 256 -> 128 -> 256, stride-1 configuration (bf16, gfx950): the two
-// high-resolution hourglass levels, where the unfused module (squeeze launch + expand/depth-wise launch) is bound by
+// Streaming one-launch fire module for the stride-1 configurations (bf16, gfx950).  At the two high-resolution
+// hourglass levels (256 -> 128 -> 256) the unfused module (squeeze launch + expand/depth-wise launch) is bound by
 // HBM traffic: x read twice (GEMM input + skip), the squeeze tensor written and re-read.  Here x is read once (+halo,
 // mostly L2 hits) and the output written once; the squeeze tile never leaves LDS.
 //
-//     s   = W1 x + b1                                   squeeze 1x1 (+bn1, no ReLU)      256 -> 128
-//     y_a = relu(Wa s + ba (+ x[:, :128]))              expand 1x1 (+bn2 half, skip)     128 -> 128
-//     y_b = relu(dw3x3(s) * wd + bd (+ x[:, 128:]))     depth-wise 3x3 (+bn2 half, skip) 128 -> 128
+//     s   = W1 x + b1                                   squeeze 1x1 (+bn1, no ReLU)      CIN -> MID
+//     y_a = relu(Wa s + ba (+ x[:, :MID]))              expand 1x1 (+bn2 half, skip)     MID -> MID
+//     y_b = relu(dw3x3(s) * wd + bd (+ x[:, MID:]))     depth-wise 3x3 (+bn2 half, skip) MID -> MID
 // (reference: fire_module, corner_net_lite/core/models/CornerNet_Squeeze.py:10-30)
 //
-// Shape of the kernel (256 threads, ~71 KB LDS -> two workgroups per CU, persistent grid):
+// At the low-resolution levels (384 -> 192, 512 -> 256, ...) the same kernel replaces two latency-bound launches by one.
+//
+// Shape of the kernel (MID/32 waves; MID = 128: 256 threads, ~71 KB LDS -> two workgroups per CU; persistent grid):
 //  * A workgroup owns an IH x IW rectangle of output pixels; the squeeze tile is that rectangle plus a one-pixel
 //    halo (SH x SW <= 128 pixels).  Halo pixels outside the frame are zero in s (the reference zero-pads s).
 //  * Both GEMMs run on 16x16x32 MFMAs with PIXELS as rows (A operand, read from LDS) and CHANNELS as columns
 //    (B operand = weights).  Wave w owns 32 channels; column j of block b is channel 32 w + 2 j + b, so a lane's two
 //    accumulator blocks are two ADJACENT channels: one dword per pixel, 16 lanes = one 64-byte line.  The squeeze
 //    result goes to LDS with ds_write_b32, the expand result straight to HBM in whole lines - no transposition.
-//  * Squeeze weights stay in registers for the whole kernel (64 VGPRs per lane, gathered once from the packed
-//    [slice][cout][128 B] plan layout); expand weights are re-fetched per tile (L2 hits, 8 loads per lane).
+//  * CIN = 256: squeeze weights stay in registers for the whole kernel (64 VGPRs per lane, gathered once from the
+//    packed [slice][cout][128 B] plan layout).  Wider inputs stream them from L2 two k-steps ahead (three rotating
+//    fragment sets; the counted waits of the x ring include them).  Expand weights are re-fetched per tile.
 //  * x streams through a 4-stage LDS ring of 64-byte K-chunks (one MFMA k-step per stage) filled by LDS-DMA; the
 //    16-byte chunk position inside a row is rotated by 2*(row>>2) so that the 16x16 fragment reads are conflict-free.
 //  * The depth-wise branch reads its 3x3 neighbourhoods from the LDS squeeze tile (runs of 4 pixels share a
@@ -32,27 +35,52 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int CIN = 256, MID = 128, HALF = 128;
-constexpr int KS1 = CIN / 32;                    // squeeze k-steps (8)
-constexpr int KS2 = MID / 32;                    // expand k-steps (4)
 constexpr int SP = 128;                          // squeeze-tile rows in LDS
 constexpr int PBI = 6;                           // interior pixel blocks of 16 (IP <= 96)
 constexpr int NST = 4;                           // x ring stages
 constexpr int MAXIH = 6;                         // interior rows per tile (depth-wise phase keeps a column's residuals in registers)
 constexpr int XST = SP * 64;                     // bytes per stage
-constexpr int OFF_S = 0;                         // [128][256 B] squeeze tile, 16-B chunks XOR-swizzled by row & 15
-constexpr int OFF_X = OFF_S + SP * MID * 2;      // x ring
-constexpr int OFF_WD = OFF_X + NST * XST;        // [9][128] fp32 depth-wise weights, then [128] bias
-constexpr int OFF_TAB = OFF_WD + 10 * HALF * 4;  // interior pixel ip -> byte offset relative to the tile's first pixel, in x ([96]) and in out ([96])
-constexpr int OFF_MASK = OFF_TAB + 2 * 96 * 4;       // 4 x u32 validity bits of the squeeze pixels (OFF_TAB: [96] x-relative, [96] out-relative pixel byte offsets)
-constexpr int LDS_BYTES = OFF_MASK + 16;
+
+template <int MID> struct FireLds {
+  static constexpr int OFF_S = 0;                         // [128][MID x 2 B] squeeze tile, 16-B chunks XOR-swizzled by the row
+  static constexpr int OFF_X = OFF_S + SP * MID * 2;      // x ring
+  static constexpr int OFF_WD = OFF_X + NST * XST;        // [9][MID] fp32 depth-wise weights, then [MID] bias
+  static constexpr int OFF_TAB = OFF_WD + 10 * MID * 4;   // interior pixel ip -> byte offset relative to the tile's first pixel: [96] in x, [96] in out
+  static constexpr int OFF_MASK = OFF_TAB + 2 * 96 * 4;   // 4 x u32 validity bits of the squeeze pixels
+  static constexpr int BYTES = OFF_MASK + 16;
+};
 
 __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
 }
 
-__global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params p) {
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+__device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a constant)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  }
+}
+
+template <int CIN, int MID>
+__global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
+  constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
+  constexpr int NT = 64 * NW;
+  constexpr int HALF = MID;
+  constexpr int KS1 = CIN / 32;                    // squeeze k-steps
+  constexpr int KS2 = MID / 32;                    // expand k-steps
+  constexpr bool RES = CIN <= 256;                 // squeeze weights resident in registers
+  constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
+  constexpr int CG = MID / 8;                      // 8-channel groups of the depth-wise branch; NT / CG = 16 column slots
+  constexpr int NDM = (SP / 16 + NW - 1) / NW;     // LDS-DMA instructions per ring step, at most, per wave
+  using L = FireLds<MID>;
+  constexpr int OFF_S = L::OFF_S, OFF_X = L::OFF_X, OFF_WD = L::OFF_WD, OFF_TAB = L::OFF_TAB, OFF_MASK = L::OFF_MASK;
+  static_assert(NT / CG == 16 && L::BYTES <= 160 * 1024, "thread mapping / LDS");
+  __shared__ __attribute__((aligned(16))) char smem[L::BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,17 +92,21 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
   // ---- once per workgroup: resident squeeze weights, depth-wise constants -> LDS -----------------------------
   // B fragment (column = channel c, k-step ks, k-group q) = 16 bytes at [slice ks/2][row c][64 (ks&1) + 16 q]
   const int ch0 = 32 * w + 2 * l16;                         // this lane's channel pair (ch0, ch0 + 1) in both GEMMs
-  u32x4 w1f[2][KS1];
+  const char* const w1_lane = static_cast<const char*>(p.w1) + (size_t)ch0 * 128 + q * 16;
+  auto load_w1 = [&](int ks, u32x4 (&dst)[2]) {
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
+      dst[b] = *reinterpret_cast<const u32x4*>(w1_lane + (size_t)(ks >> 1) * p.w1_cout_pad * 128 + b * 128 + (ks & 1) * 64);
+  };
+  u32x4 w1f[RES ? KS1 : 3][2];                                // resident: all k-steps; streamed: three rotating sets
+  if constexpr (RES) {
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks)
-      w1f[b][ks] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w1) + (size_t)(ks >> 1) * p.w1_cout_pad * 128 +
-                                                   (size_t)(ch0 + b) * 128 + (ks & 1) * 64 + q * 16);
+    for (int ks = 0; ks < KS1; ++ks) load_w1(ks, w1f[ks]);
+  }
   const char* const wa_lane = static_cast<const char*>(p.wa) + (size_t)ch0 * 128 + q * 16;
   const float b1v0 = p.b1[ch0], b1v1 = p.b1[ch0 + 1];
   const float bav0 = p.ba[ch0], bav1 = p.ba[ch0 + 1];
-  for (int i = tid; i < 10 * HALF; i += 256)
+  for (int i = tid; i < 10 * HALF; i += NT)
     reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
   if (tid < 16 * PBI) {
     const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
@@ -92,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
     const int sp = (iy + 1) * p.SW + ix + 1;
     a_row[pb] = (uint32_t)sp * (MID * 2);
-    a_key[pb] = (uint32_t)(sp & 15);
+    a_key[pb] = (uint32_t)(sp & SWM);
   }
   // x-ring fragment read: row 16 pb + l16, chunk q sits at position (q + 2 (row >> 2)) & 3 = (q + 2 (l16 >> 2)) & 3
   const uint32_t xfrag_off = (uint32_t)l16 * 64u + (uint32_t)((q + 2 * (l16 >> 2)) & 3) * 16u;
@@ -101,15 +133,17 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rl = 4 * q + r;
-    s_dst[r] = (uint32_t)(OFF_S + rl * (MID * 2) + (((4 * w + (l16 >> 2)) ^ rl) << 4) + (l16 & 3) * 4);
+    s_dst[r] = (uint32_t)(OFF_S + rl * (MID * 2) + (((4 * w + (l16 >> 2)) ^ (rl & SWM)) << 4) + (l16 & 3) * 4);
   }
-  // LDS-DMA geometry: instruction i of this wave fills rows [32 w + 16 i, +16); lane -> (row, position).  The lane
-  // FETCHES the 16-byte k-chunk that the read-side rotation expects at its position.
-  int d_sy[2], d_sx[2];
-  uint32_t d_chunk[2];
+  // LDS-DMA geometry: a ring step is SP/16 = 8 instructions of 16 rows; wave w issues row blocks w, w + NW, ...
+  // lane -> (row, position).  The lane FETCHES the 16-byte k-chunk that the read-side rotation expects there.
+  constexpr bool UNI = (SP / 16) % NW == 0;                  // every wave issues the same number of instructions
+  const int nd = UNI ? NDM : (SP / 16 - w + NW - 1) / NW;    // instructions this wave issues per ring step (wave-uniform)
+  int d_sy[NDM], d_sx[NDM];
+  uint32_t d_chunk[NDM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 32 * w + 16 * i + (lane >> 2);
+  for (int i = 0; i < NDM; ++i) {
+    const int row = 16 * (w + NW * i) + (lane >> 2);
     d_sy[i] = fastdiv(row, p.div_sw);
     d_sx[i] = row - d_sy[i] * p.SW;
     if (row >= p.SH * p.SW) d_sy[i] = 1 << 20;              // rows beyond the tile: always out of frame
@@ -126,12 +160,12 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     y0 = ty * p.IH;                                          // frame coordinates of interior pixel (0, 0)
     x0 = (trem - ty * p.tiles_x) * p.IW;
   };
-  uint32_t d_off[2];
+  uint32_t d_off[NDM];
   auto tile_setup = [&](int tile) {                          // DMA source offsets + validity bits of `tile`
     int n, y0, x0;
     tile_origin(tile, n, y0, x0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NDM; ++i) {
       const int y = y0 - 1 + d_sy[i], x = x0 - 1 + d_sx[i];
       const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
       d_off[i] = ok ? (uint32_t)(((long)n * p.H + y) * p.W + x) * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
@@ -147,17 +181,18 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     }
   };
   auto issue_x = [&](int ks, int stage) {
-    char* dst = smem + OFF_X + stage * XST + (32 * w) * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(dst + i * 1024), 16,
-                                               (int)(d_off[i] == kInvalid ? kInvalid : d_off[i] + (uint32_t)ks * 64u), 0, 0, 0);
+    for (int i = 0; i < NDM; ++i)
+      if (UNI || i < nd)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + OFF_X + stage * XST + (w + NW * i) * 1024), 16,
+                                                 (int)(d_off[i] == kInvalid ? kInvalid : d_off[i] + (uint32_t)ks * 64u), 0, 0, 0);
   };
 
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
   __syncthreads();                                           // depth-wise constants are in LDS
   tile_setup(tile);
+  if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
 #pragma unroll
   for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
 
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     asm volatile("" : "+v"(qt), "+v"(tidt));
     // phase 2b residuals of column `ix` (thread = 8-channel group cg, column slot): one 16-byte load per output row
     auto load_col_residuals = [&](int ix, u32x4 (&rr)[MAXIH], uint32_t (&oo)[MAXIH]) {
-      const int cg = tidt & 15;
+      const int cg = tidt % CG;
       const int ox = x0 + ix;
       const uint32_t pix = (uint32_t)(((long)n * p.H + y0) * p.W + ox);
       uint32_t xo = pix * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u, oof = pix * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u;
@@ -199,13 +234,14 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     }
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
-      // ks == 0: everything older (the previous tile's stores, the prefetched steps) must be done, because loads
-      // and stores share the counter; afterwards steps ks+1, ks+2 may stay in flight (2 LDS-DMA each per wave)
-      if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (ks >= NST - 1 && ks + 2 < KS1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (ks >= NST - 1 && ks + 1 < KS1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (ks >= NST - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ks == 0: everything older (the previous tile's stores, the prefetched steps and weight sets) must be done,
+      // because loads and stores share the counter.  Later: ring steps ks+1, ks+2 may stay in flight (nd LDS-DMA each)
+      // and, when the squeeze weights are streamed, the weight set of step ks+1 issued between them.
+      if (ks == 0) wait_vm(0);
+      else if (ks >= (RES ? NST - 1 : 2))
+        wait_vm((ks + 1 < KS1 ? nd + (RES ? 0 : 2) : 0) + (ks + 2 < KS1 ? nd : 0));
       __builtin_amdgcn_s_barrier();
+      if constexpr (!RES) { if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % 3]); }
       if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
       const char* st = smem + OFF_X + (ks % NST) * XST + xfrag_off;
       u32x4 a[SP / 16];
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
       for (int pb = 0; pb < SP / 16; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[b][ks]),
+          acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[RES ? ks : ks % 3][b]),
                                                                acc[pb][b], 0, 0, 0);
     }
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
     // output rows that see it as tap row 2, 1, 0; depth-wise weights in registers for the phase.
     {
-      const int cg = tidt & 15;
+      const int cg = tidt % CG;
       const float* const wl = reinterpret_cast<const float*>(smem + OFF_WD) + cg * 8;     // [tap][128] fp32, bias at tap 9
       float breg[8];
       {
@@ -321,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
         for (int e = 0; e < 4; ++e) { breg[e] = u0[e]; breg[4 + e] = u1[e]; }
       }
       bool prefetched = false;
-      for (int ix = tidt >> 4; ix < ((p.IW + 15) & ~15); ix += 16) {       // uniform trip count: the prefetch sits inside
+      for (int ix = tidt / CG; ix < ((p.IW + 15) & ~15); ix += 16) {       // uniform trip count: the prefetch sits inside
         // residuals of the whole column first, then the next tile's first ring steps (HBM): those land behind the
         // residuals, while the taps run
         load_col_residuals(ix, rr, oo);
@@ -330,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
           const int next = tile + gridDim.x;
           if (next < p.n_tiles) {
             tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
+            if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
 #pragma unroll
             for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
           }
@@ -352,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
           for (int sr = 0; sr < MAXIH + 2; ++sr) {           // squeeze row sr is tap row dy of output row sr - dy
             if (sr < p.IH + 2) {
               const int sp = sr * p.SW + ixc + dx;
-              const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & 15)) << 4));
+              const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
               f32x2 s2[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) s2[e] = f32x2{__builtin_bit_cast(float, sv[e] << 16), __builtin_bit_cast(float, sv[e] & 0xffff0000u)};
@@ -389,10 +426,12 @@ __global__ __launch_bounds__(256, 2) void okp_fire2_kernel(const OkpFire2Params 
 }  // namespace
 
 bool okp_fire2_supported(int cin, int mid, int half, int stride) {
-  return cin == CIN && mid == MID && half == HALF && stride == 1;
+  if (stride != 1 || half != mid) return false;
+  return (cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 512 && mid == 256) ||
+         (cin == 384 && mid == 128) || (cin == 512 && mid == 192);
 }
 
-int okp_launch_fire2(OkpFire2Params p, hipStream_t stream) {
+int okp_launch_fire2(OkpFire2Params p, int cin, int mid, hipStream_t stream) {
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
   // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
   long best = -1;
@@ -414,8 +453,13 @@ int okp_launch_fire2(OkpFire2Params p, hipStream_t stream) {
   p.div_sw = okp_fastdiv((uint32_t)p.SW);
   p.div_iw = okp_fastdiv((uint32_t)p.IW);
   p.div_rpr = okp_fastdiv((uint32_t)p.RPR);
-  const int resident = 256 * 2;
-  const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  hipLaunchKernelGGL(okp_fire2_kernel, dim3(grid), dim3(256), 0, stream, p);
+  const int resident = 256 * (mid == 128 ? 2 : 1);
+  const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block((unsigned)(2 * mid));
+  if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192>), grid, block, 0, stream, p);
+  else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<512, 256>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<384, 128>), grid, block, 0, stream, p);
+  else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<512, 192>), grid, block, 0, stream, p);
+  else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d", cin, mid); return OKP_EINVAL; }
   return okp_check_hip(hipGetLastError(), "okp_fire2 launch");
 }

@@ -114,5 +114,5 @@ int okp_check_hip(hipError_t e, const char* what);
 int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
-int okp_launch_fire2(OkpFire2Params p, hipStream_t stream);
+int okp_launch_fire2(OkpFire2Params p, int cin, int mid, hipStream_t stream);
 int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip

@@ -176,15 +176,18 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64
-FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "32"))   # smaller maps: two launches are as fast
-FUSE_FIRE_ALL = False   # tests: also route the other configurations through the first-generation one-launch kernel
+FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "8"))    # 4x4 maps: two launches are faster (25 vs 20 us)
+FUSE_FIRE_ALL = os.environ.get("OKP_FUSE_FIRE_ALL", "0") == "1"   # tests / experiments: also route the other configurations through the first-generation one-launch kernel
                         # (okp_fire.hip: correct, but slower than squeeze + fused tail at every level)
+
+
+_FIRE2_CONFIGS = {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)}      # (cin, mid) instances of okp_fire2.hip
 
 
 def fire_fusable(inp_dim, mid, stride, h, w):
     if FUSE_FIRE_ALL:
         return inp_dim % 64 == 0 and mid % 64 == 0 and mid <= 256
-    return FUSE_FIRE and inp_dim == 256 and mid == 128 and stride == 1 and min(h, w) >= FUSE_FIRE_MIN_HW
+    return FUSE_FIRE and stride == 1 and (inp_dim, mid) in _FIRE2_CONFIGS and min(h, w) >= FUSE_FIRE_MIN_HW
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):

@@ -139,6 +139,9 @@ def test_bad_arguments_are_reported():
     (256, 256, 33, 21, 1, 2),      # streaming kernel (okp_fire2): odd sizes, partial tiles on both axes
     (256, 256, 7, 5, 1, 3),        # streaming kernel: one small tile per frame
     (256, 256, 32, 32, 1, 4),      # streaming kernel: the 32x32 hourglass level
+    (512, 384, 8, 8, 1, 2),        # streaming kernel <512,192>: no skip, streamed squeeze weights, 6 waves
+    (384, 384, 16, 16, 1, 5),      # streaming kernel <384,192>: the 16x16 level
+    (512, 512, 8, 8, 1, 3),        # streaming kernel <512,256>: 8 waves
 ])
 def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
     """One-launch bf16 fire module vs the oracle's fire_module (fp32) on the same bf16-rounded input, and vs the
