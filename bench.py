@@ -194,7 +194,7 @@ def main():
     n_launch, k_ms, k_flops = timer.summary()
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
-    traffic, traffic_src = pmc_traffic("okp_igemm_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E" if args.dtype == "bf16"
+    traffic, traffic_src = pmc_traffic("okp_igemm_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi128ELi16ELi1E" if args.dtype == "bf16"
                                        else "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E")
     result = {
         "metric": "frames/sec keypoint inference (511x511 -> heatmaps+3D)",
@@ -202,7 +202,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: batch={args.batch}/GPU synthetic 511x511 frames, {args.dtype} activations+weights, fp32 accumulate, "
-                               "CornerNet-Squeeze K=3 (valve) random-init procedural weights; pack -> hourglass+heads -> peak-NMS -> depth lifting"
+                               "CornerNet-Squeeze K=3 (valve) random-init procedural weights; pack -> hourglass+heads -> peak-NMS -> depth lifting -> object grouping"
                                + (" -> all-gather of 3D keypoints" if world > 1 else ""),
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
         "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
