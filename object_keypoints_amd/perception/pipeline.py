@@ -227,6 +227,44 @@ class TriangulationComponent:
         return self.stereo_camera.triangulate(left_keypoints, right_keypoints)
 
 
+class AssociationComponent:
+    """Left/right keypoint matching before triangulation: reset(stereo_camera); __call__(points_left (n,2),
+    points_right (m,2)) -> int array (n,), -1 = unmatched.  The reference tree has no implementation; the contract is
+    its test (test/test_pipeline.py:208-261).  Minimum-cost one-to-one assignment on the symmetric epipolar distance
+    of the (device-)undistorted points; matches beyond `max_distance` pixels are dropped."""
+
+    def __init__(self, max_distance=20.0):
+        self.max_distance = float(max_distance)
+
+    def reset(self, stereo_camera):
+        self.stereo_camera = stereo_camera
+
+    def cost(self, points_left, points_right):
+        cam = self.stereo_camera
+        ul = cam.left_camera.undistort(np.asarray(points_left, dtype=np.float64))
+        ur = cam.right_camera.undistort(np.asarray(points_right, dtype=np.float64))
+        hl = np.concatenate([ul, np.ones((ul.shape[0], 1))], axis=1)
+        hr = np.concatenate([ur, np.ones((ur.shape[0], 1))], axis=1)
+        lines_r, lines_l = hl @ cam.F.T, hr @ cam.F
+        num = np.abs(lines_r @ hr.T)
+        d_r = num / np.maximum(np.linalg.norm(lines_r[:, :2], axis=1), 1e-300)[:, None]
+        d_l = num / np.maximum(np.linalg.norm(lines_l[:, :2], axis=1), 1e-300)[None, :]
+        return 0.5 * (d_r + d_l)
+
+    def __call__(self, points_left, points_right):
+        from scipy.optimize import linear_sum_assignment
+        points_left, points_right = np.asarray(points_left), np.asarray(points_right)
+        out = np.full(points_left.shape[0], -1, dtype=np.int64)
+        if points_left.shape[0] == 0 or points_right.shape[0] == 0:
+            return out
+        cost = self.cost(points_left, points_right)
+        # gate first: a point without any admissible partner must not steal one (all its pairs cost the same)
+        rows, cols = linear_sum_assignment(np.where(cost <= self.max_distance, cost, 1e6))
+        keep = cost[rows, cols] <= self.max_distance
+        out[rows[keep]] = cols[keep]
+        return out
+
+
 class BatchedKeypointPipeline:
     """Frames -> heat/depth/centre maps -> peaks -> per-peak 3D points for a whole batch, device-resident.
 

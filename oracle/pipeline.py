@@ -211,6 +211,49 @@ class TriangulationComponent:
         return self.stereo_camera.triangulate(left_keypoints, right_keypoints)
 
 
+def epipolar_cost(stereo_camera, left_points, right_points):
+    """[n, m] symmetric point-to-epipolar-line distance (pixels, undistorted image space) between every left and right point."""
+    L, R = stereo_camera.left_camera, stereo_camera.right_camera
+    ul = geometry.fisheye_undistort(np.asarray(left_points, dtype=np.float64), L.K, L.D, P=L.K)
+    ur = geometry.fisheye_undistort(np.asarray(right_points, dtype=np.float64), R.K, R.D, P=R.K)
+    hl = np.concatenate([ul, np.ones((ul.shape[0], 1))], axis=1)
+    hr = np.concatenate([ur, np.ones((ur.shape[0], 1))], axis=1)
+    F = stereo_camera.F
+    lines_r = hl @ F.T                      # F x_l: the epipolar line of each left point in the right image
+    lines_l = hr @ F                        # F^T x_r
+    num = np.abs(hl @ F.T @ hr.T)           # |x_r^T F x_l|
+    d_r = num / np.maximum(np.linalg.norm(lines_r[:, :2], axis=1), 1e-300)[:, None]
+    d_l = num / np.maximum(np.linalg.norm(lines_l[:, :2], axis=1), 1e-300)[None, :]
+    return 0.5 * (d_r + d_l)
+
+
+class AssociationComponent:
+    """Left/right keypoint matching before triangulation.  There is NO implementation in the reference tree; the
+    contract is its test (test/test_pipeline.py:208-261): reset(stereo_camera); __call__(points_left (n,2),
+    points_right (m,2)) -> int array (n,), associations[i] = index of the right point matched to left point i or -1.
+    Built here as: minimum-cost one-to-one assignment (Hungarian) on the symmetric epipolar distance, pairs
+    farther than `max_distance` pixels from their epipolar lines being inadmissible."""
+
+    def __init__(self, max_distance=20.0):
+        self.max_distance = float(max_distance)
+
+    def reset(self, stereo_camera):
+        self.stereo_camera = stereo_camera
+
+    def __call__(self, points_left, points_right):
+        from scipy.optimize import linear_sum_assignment
+        points_left, points_right = np.asarray(points_left), np.asarray(points_right)
+        out = np.full(points_left.shape[0], -1, dtype=np.int64)
+        if points_left.shape[0] == 0 or points_right.shape[0] == 0:
+            return out
+        cost = epipolar_cost(self.stereo_camera, points_left, points_right)
+        # gate first: a point without any admissible partner must not steal one (all its pairs cost the same)
+        rows, cols = linear_sum_assignment(np.where(cost <= self.max_distance, cost, 1e6))
+        keep = cost[rows, cols] <= self.max_distance
+        out[rows[keep]] = cols[keep]
+        return out
+
+
 def eval_camera(calibration_file, prediction_size=64, height=720, width=1280, resized=511):
     """The 64x64-space camera of scripts/eval_model.py:61-69 (scale to 511, centre-crop, scale to 64)."""
     params = geometry.load_calibration_params(calibration_file)

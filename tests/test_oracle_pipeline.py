@@ -106,6 +106,39 @@ def test_triangulation_known_answer(known):
     assert np.linalg.norm(p_w2 - pts, axis=1).max() < 1e-4
 
 
+def test_association_reference_contract(known):
+    """AssociationComponent against the known-answer vectors of the reference's own tests (no reference implementation
+    exists; the tests are the contract): shuffled right points are un-shuffled, the unmatched point gets -1, and the
+    ambiguous 64x64 case yields three distinct matches."""
+    a = known["association"]
+    p = og.load_calibration_params(CALIB)
+    stereo = og.StereoCamera.from_file(CALIB)
+    assoc = op.AssociationComponent()
+    assoc.reset(stereo)
+    X = np.array(a["keypoints_X"])
+    left = stereo.left_camera.project(X, np.eye(4)) * a["simple_point_scale"]
+    right = stereo.right_camera.project(X, p["T_RL"]) * a["simple_point_scale"]
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        shuffled = right[rng.permutation(right.shape[0])]
+        got = assoc(left, shuffled)
+        assert (got != -1).all()
+        np.testing.assert_equal(right, shuffled[got])
+    got = assoc(np.array(a["two_same"]["left"]), np.array(a["two_same"]["right"]))
+    assert got.tolist() == a["two_same"]["expected"]
+    t = a["tricky"]
+    small = og.StereoCamera(og.FisheyeCamera(np.array(t["K"]), np.array(t["D"]), [64, 64]),
+                            og.FisheyeCamera(np.array(t["Kp"]), np.array(t["Dp"]), [64, 64]), p["T_RL"])
+    assoc.reset(small)
+    got = assoc(np.array(t["left"]), np.array(t["right"]))
+    assert got.shape[0] == 3 and np.unique(got).size == 3 and (got >= 0).all()
+    # consistently scaled camera: the matching pairs lie ON their epipolar lines
+    quarter = og.StereoCamera(stereo.left_camera.scale(0.25), stereo.right_camera.scale(0.25), p["T_RL"])
+    assert np.diag(op.epipolar_cost(quarter, left, right)).max() < 1e-6
+    assert assoc(np.zeros((0, 2)), right).shape == (0,)
+    assert (assoc.__class__(max_distance=20.0).__dict__["max_distance"]) == 20.0
+
+
 def test_undistort_inverts_project():
     p = og.load_calibration_params(CALIB)
     cam = og.FisheyeCamera(p["K"], p["D"], p["image_size"])
