@@ -152,6 +152,16 @@ int okp_pack_frames(int dtype, const float* frames_nchw_dev, int32_t n, int32_t 
 int okp_pack_frames_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int32_t h, int32_t w,
                        const float* mean3, const float* std3, void* out_dev, int32_t out_w, void* stream);
 
+/* Raw camera frames to the stem input in one pass: uint8 RGB NHWC (n, src_h, src_w, 3) -> bilinear resize to
+ * (resized_h, resized_w) -> crop (h, w) at (crop_y, crop_x) -> ((u8 / 255) - mean) / std -> packed as okp_pack_frames.
+ * Replaces albumentations.SmallestMaxSize + CenterCrop + the normalisation of the reference's data path
+ * (perception/datasets/video.py:95-96,215; 720x1280 -> 511x908 -> crop 511x511 at (0, 198)).  The resize restates
+ * cv::resize(INTER_LINEAR) for 8-bit images (OpenCV 3.4 fixed-point arithmetic, 11-bit weights); cv2 is absent from the
+ * build environment, so this entry point is pinned against the oracle's restatement and by properties only. */
+int okp_preprocess_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int32_t src_h, int32_t src_w,
+                      int32_t resized_h, int32_t resized_w, int32_t crop_y, int32_t crop_x, int32_t h, int32_t w,
+                      const float* mean3, const float* std3, void* out_dev, int32_t out_w, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * The 7x7 / stride-2 / pad-3 stem convolution 3 -> 128 + folded BatchNorm + ReLU in bf16 as its own kernel
  * (write-bound layer: whole 64-byte NHWC lines are stored straight from the MFMA accumulators).

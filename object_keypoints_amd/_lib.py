@@ -66,6 +66,8 @@ SIGNATURES = [
     ("okp_dwconv3x3_forward", c_int, [c_int, c_int32, c_int32, c_int32, POINTER(okp_tensor), c_void_p, c_void_p, POINTER(okp_tensor), POINTER(okp_tensor), c_int, c_void_p]),
     ("okp_pack_frames", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     ("okp_pack_frames_u8", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p, c_int32, c_void_p]),
+    ("okp_preprocess_u8", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                  POINTER(c_float), POINTER(c_float), c_void_p, c_int32, c_void_p]),
     ("okp_stem_create", c_void_p, [POINTER(c_float), POINTER(c_float)]),
     ("okp_stem_destroy", None, [c_void_p]),
     ("okp_stem_forward", c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),

@@ -205,6 +205,66 @@ __global__ __launch_bounds__(256) void okp_pack_frames_u8_kernel(const uint8_t* 
   }
 }
 
+
+// ---- resize (bilinear, 8-bit fixed point) + centre crop + normalise + pack, raw camera frames -> stem input ----------
+// Restates the arithmetic of cv::resize(INTER_LINEAR) for CV_8U as published in OpenCV 3.4 (imgproc/resize.cpp:
+// resizeGeneric_ with HResizeLinear<uchar,int,short,2048> and VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>),
+// which is what the reference's data path runs through albumentations.SmallestMaxSize + CenterCrop
+// (perception/datasets/video.py:95-96): per destination column  fx = (float)((dx + 0.5) * scale - 0.5),
+// sx = floor(fx), weights round((1 - fx) * 2048), round(fx * 2048) as int16; rows alike; then
+//   dst = ( ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 ) >> 2   with  h = S[sx] * a0 + S[sx + 1] * a1.
+// cv2 is not importable in the build container: PARITY UNPINNED against OpenCV itself; pinned against the oracle's
+// restatement (oracle/preprocess.py, integer arithmetic: bit-exact) and by properties (tests/test_oracle_preprocess.py).
+struct ResizeParams {
+  int srcH, srcW, rsH, rsW;       // source frame, resized frame (before the crop)
+  int cropY, cropX, H, W;         // crop origin inside the resized frame, cropped size (the network's input size)
+  double scaleY, scaleX;          // srcH / rsH, srcW / rsW as cv::resize derives them: 1.0 / ((double)rs / src)
+  NormParams np;
+};
+
+__device__ __forceinline__ void resize_coeff(int d, double scale, int ssize, int& s0, int& s1, int& w0, int& w1) {
+  float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  s0 = s;
+  s1 = s + 1 < ssize ? s + 1 : s;                    // weight 0 there (f == 0) or the in-range neighbour
+  w0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));   // saturate_cast<short>(cvRound(.)): values are within [0, 2048]
+  w1 = __float2int_rn(__fmul_rn(f, 2048.f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void okp_preprocess_u8_kernel(const uint8_t* __restrict__ in, int N, ResizeParams rp,
+                                                                 T* __restrict__ out, int OHt, int OWt) {
+  const long total = (long)N * OHt * OWt;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % OWt);
+    const long t = idx / OWt;
+    const int y = (int)(t % OHt);
+    const int n = (int)(t / OHt);
+    const int cy = y - 3, cx = x - 3;               // position inside the cropped frame
+    float v[3] = {0.f, 0.f, 0.f};
+    if (cy >= 0 && cy < rp.H && cx >= 0 && cx < rp.W) {
+      int sy0, sy1, b0, b1, sx0, sx1, a0, a1;
+      resize_coeff(cy + rp.cropY, rp.scaleY, rp.srcH, sy0, sy1, b0, b1);
+      resize_coeff(cx + rp.cropX, rp.scaleX, rp.srcW, sx0, sx1, a0, a1);
+      const uint8_t* r0 = in + ((size_t)n * rp.srcH + sy0) * rp.srcW * 3;
+      const uint8_t* r1 = in + ((size_t)n * rp.srcH + sy1) * rp.srcW * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0 = (int)r0[sx0 * 3 + c] * a0 + (int)r0[sx1 * 3 + c] * a1;
+        const int h1 = (int)r1[sx0 * 3 + c] * a0 + (int)r1[sx1 * 3 + c] * a1;
+        const int u = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        const int u8 = u < 0 ? 0 : (u > 255 ? 255 : u);
+        v[c] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)u8, 255.0f), rp.np.mean[c]), rp.np.stdv[c]);
+      }
+    }
+    T* o = out + idx * 4;
+    o[0] = (T)v[0]; o[1] = (T)v[1]; o[2] = (T)v[2]; o[3] = (T)0.f;
+  }
+}
+
 struct HeadParams {
   const void* src; int32_t src_ps;
   int32_t N, HW, n_out;
@@ -316,6 +376,29 @@ extern "C" int okp_pack_frames_u8(int dtype, const uint8_t* frames, int32_t n, i
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (__bf16*)out, h + 6, out_w);
   else hipLaunchKernelGGL(okp_pack_frames_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (float*)out, h + 6, out_w);
   return okp_check_hip(hipGetLastError(), "okp_pack_frames_u8 launch");
+}
+
+extern "C" int okp_preprocess_u8(int dtype, const uint8_t* frames, int32_t n, int32_t src_h, int32_t src_w, int32_t resized_h, int32_t resized_w,
+                                 int32_t crop_y, int32_t crop_x, int32_t h, int32_t w, const float* mean3, const float* std3,
+                                 void* out, int32_t out_w, void* stream) {
+  if (!frames || !out || !mean3 || !std3) { okp_set_error("okp_preprocess_u8: null argument"); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_preprocess_u8: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (n < 1 || src_h < 1 || src_w < 1 || resized_h < 1 || resized_w < 1 || h < 1 || w < 1 || crop_y < 0 || crop_x < 0 ||
+      crop_y + h > resized_h || crop_x + w > resized_w) {
+    okp_set_error("okp_preprocess_u8: crop %dx%d at (%d,%d) does not fit the resized frame %dx%d", h, w, crop_y, crop_x, resized_h, resized_w);
+    return OKP_EINVAL;
+  }
+  if (out_w < w + 6) { okp_set_error("okp_preprocess_u8: out_w %d < w+6", out_w); return OKP_EINVAL; }
+  ResizeParams rp;
+  rp.srcH = src_h; rp.srcW = src_w; rp.rsH = resized_h; rp.rsW = resized_w; rp.cropY = crop_y; rp.cropX = crop_x; rp.H = h; rp.W = w;
+  rp.scaleY = 1.0 / ((double)resized_h / (double)src_h);
+  rp.scaleX = 1.0 / ((double)resized_w / (double)src_w);
+  for (int c = 0; c < 3; ++c) { rp.np.mean[c] = mean3[c]; rp.np.stdv[c] = std3[c]; }
+  const long total = (long)n * (h + 6) * out_w;
+  const int grid = grid_for(total, 256);
+  if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_preprocess_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, rp, (__bf16*)out, h + 6, out_w);
+  else hipLaunchKernelGGL(okp_preprocess_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, rp, (float*)out, h + 6, out_w);
+  return okp_check_hip(hipGetLastError(), "okp_preprocess_u8 launch");
 }
 
 extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void* stream) {

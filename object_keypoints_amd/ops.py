@@ -277,6 +277,36 @@ def pack_frames_u8(frames, dtype, mean=RGB_MEAN, std=RGB_STD):
     return act
 
 
+def smallest_max_size(h, w, max_size):
+    """albumentations.SmallestMaxSize geometry: scale the shortest side to max_size, round half to even like py3round."""
+    scale = max_size / min(h, w)
+    return int(round(h * scale)), int(round(w * scale))
+
+
+def preprocess_u8(frames, dtype, size=511, mean=RGB_MEAN, std=RGB_STD):
+    """Raw uint8 RGB frames [N,H,W,3] (device) -> resized (shortest side = size), centre-cropped size x size, normalised and
+    packed stem input (okp_preprocess_u8; the reference's SmallestMaxSize + CenterCrop + normalisation, video.py:95-96,215)."""
+    require_cuda(frames, "frames")
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise OkpError("frames must be uint8 [N,H,W,3]")
+    frames = frames.contiguous()
+    n, sh, sw, _ = frames.shape
+    rh, rw = smallest_max_size(sh, sw, size)
+    if rh < size or rw < size:
+        raise OkpError("resized frame is smaller than the crop")
+    cy, cx = (rh - size) // 2, (rw - size) // 2
+    wp = stem_packed_width(size)
+    out = torch.empty((n, size + 6, wp, 4), dtype=dtype, device=frames.device)
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    _lib.check(_lib.lib().okp_preprocess_u8(okp_dtype(dtype), frames.data_ptr(), n, sh, sw, rh, rw, cy, cx, size, size, m, sd,
+                                            out.data_ptr(), wp, stream_handle()), "okp_preprocess_u8")
+    COUNTERS["launches"] += 1
+    act = Act(out)
+    act.orig_hw = (size, size)
+    return act
+
+
 def head_out(src, outputs, w_dev, bias_dev):
     """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
     a = _lib.okp_head_out_args()

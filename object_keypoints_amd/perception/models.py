@@ -91,6 +91,9 @@ class KeypointNet(_HipModule):
         self.features = features
         self.heatmaps_out = heatmaps_out
         self.compute_dtype = compute_dtype
+        # uint8 frames of any other size are resized (shortest side) and centre-cropped to this size on the device, as the
+        # reference's data path does (perception/datasets/video.py:63-69,95-96); None = uint8 frames are taken as they are
+        self.raw_frame_size = 511
 
     # ---- fused three-head plan for one stack ------------------------------------------------
     def _build_heads(self, stack, dtype, device):
@@ -130,7 +133,9 @@ class KeypointNet(_HipModule):
         ops.require_cuda(x, "frames")
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
-        if x.dtype == torch.uint8:      # raw RGB crop [N,H,W,3]: normalisation fused into the packing kernel
+        if x.dtype == torch.uint8:      # raw RGB [N,H,W,3]: normalisation (and resize + centre crop) fused into the packing kernel
+            if self.raw_frame_size is not None and tuple(x.shape[1:3]) != (self.raw_frame_size, self.raw_frame_size):
+                return self.backbone(ops.preprocess_u8(x, self.compute_dtype, size=self.raw_frame_size))
             return self.backbone(ops.pack_frames_u8(x, self.compute_dtype))
         return self.backbone(ops.pack_frames(x.float(), self.compute_dtype))
 
@@ -143,6 +148,8 @@ class KeypointNet(_HipModule):
 
     def _chunks(self, x):
         h, w = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
+        if x.dtype == torch.uint8 and self.raw_frame_size is not None:
+            h = w = self.raw_frame_size
         step = self.max_frames_per_pass(h, w)
         return [x[i:i + step] for i in range(0, x.shape[0], step)]
 
