@@ -58,6 +58,31 @@ def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
     return net.to(device).eval()
 
 
+def load_cornernet_backbone(net, pretrained):
+    """Copies the hourglass of a CornerNet-Squeeze checkpoint into `net.backbone`, as the reference's
+    KeypointNet._build_hourglass does with ./models/corner_net.pkl (perception/models.py:69-78: the pickle holds the
+    DataParallel-wrapped detector, keys `module.hg.*`, loaded by core/nnet/py_factory.py:119-123); the detector's own
+    corner heads (`module.tl_*`, `module.br_*`, ...) are not part of KeypointNet and are skipped.
+    `pretrained`: a state_dict or a path to a torch.save'd one.  Returns the number of tensors copied."""
+    if isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):
+        pretrained = torch.load(pretrained, map_location="cpu")
+    own = net.backbone.state_dict()
+    picked = {}
+    for k, v in pretrained.items():
+        for prefix in ("module.hg.", "hg."):
+            if k.startswith(prefix):
+                picked[k[len(prefix):]] = v
+                break
+    missing = [k for k in own if k not in picked]
+    if missing:
+        raise OkpError(f"CornerNet checkpoint lacks {len(missing)} hourglass tensors, e.g. {missing[0]}")
+    bad = [k for k in own if tuple(picked[k].shape) != tuple(own[k].shape)]
+    if bad:
+        raise OkpError(f"CornerNet checkpoint: shape mismatch at {bad[0]}")
+    net.backbone.load_state_dict({k: picked[k] for k in own})
+    return len(own)
+
+
 class InferenceComponent:
     name = "inference"
 

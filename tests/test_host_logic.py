@@ -143,3 +143,22 @@ def test_kmeans_branch_set_level():
     want = op.ObjectExtraction(cfg, [64, 64])(keypoints, conf, centers)[0]["heatmap_points"][1]
     key = lambda a: sorted(map(tuple, np.round(np.asarray(a, dtype=np.float64), 4).tolist()))
     assert key(got) == key(want)
+
+
+def test_cornernet_backbone_import():
+    """load_cornernet_backbone: `module.hg.*` keys of a CornerNet-Squeeze checkpoint land in KeypointNet.backbone
+    (the reference does this inside KeypointNet._build_hourglass, perception/models.py:69-78); detector-only keys are ignored."""
+    from object_keypoints_amd.perception import models, pipeline
+    net = models.KeypointNet(features=32, heatmaps_out=3)
+    own = net.backbone.state_dict()
+    gen = torch.Generator().manual_seed(3)
+    fake = {"module.hg." + k: (torch.rand(v.shape, generator=gen).to(v.dtype) if v.dtype.is_floating_point else v.clone())
+            for k, v in own.items()}
+    fake["module.tl_modules.0.0.conv.weight"] = torch.zeros(4, 4)       # the detector's corner heads: not ours
+    n = pipeline.load_cornernet_backbone(net, fake)
+    assert n == len(own)
+    for k, v in net.backbone.state_dict().items():
+        assert torch.equal(v, fake["module.hg." + k])
+    del fake["module.hg.pre.0.conv.weight"]
+    with pytest.raises(models.OkpError):
+        pipeline.load_cornernet_backbone(net, fake)
