@@ -66,8 +66,9 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
   }
 }
 
-template <int CIN, int MID>
+template <int CIN, int MID, int STR>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
+  static_assert(STR == 1 || STR == 2, "stride of both branches");
   constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
   constexpr int NT = 64 * NW;
   constexpr int HALF = MID;
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
   if (tid < 16 * PBI) {
     const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
-    const uint32_t rel = (uint32_t)(iy * p.W + ix);
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? rel * (uint32_t)(p.x_ps * 2) : kInvalid;
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? rel * (uint32_t)(p.out_ps * 2) : kInvalid;
+    // (the x table serves the skip connection: stride 1, where input and output geometry coincide)
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? (uint32_t)(iy * p.W + ix) * (uint32_t)(p.x_ps * 2) : kInvalid;
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? (uint32_t)(iy * p.Wo + ix) * (uint32_t)(p.out_ps * 2) : kInvalid;
   }
 
   // interior pixel block pb, row l16 -> squeeze-tile row (constant over tiles: depends on the tile geometry only)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     int ip = 16 * pb + l16;
     if (ip >= p.IP) ip = 0;
     const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
-    const int sp = (iy + 1) * p.SW + ix + 1;
+    const int sp = (STR * iy + 1) * p.SW + STR * ix + 1;     // the squeeze pixel the 1x1 branch samples
     a_row[pb] = (uint32_t)sp * (MID * 2);
     a_key[pb] = (uint32_t)(sp & SWM);
   }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     n = fastdiv(tile, p.div_tiles_frame);
     const int trem = tile - n * p.tiles_y * p.tiles_x;
     const int ty = fastdiv(trem, p.div_tiles_x);
-    y0 = ty * p.IH;                                          // frame coordinates of interior pixel (0, 0)
+    y0 = ty * p.IH;                                          // OUTPUT coordinates of interior pixel (0, 0)
     x0 = (trem - ty * p.tiles_x) * p.IW;
   };
   uint32_t d_off[NDM];
@@ -166,12 +167,12 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     tile_origin(tile, n, y0, x0);
 #pragma unroll
     for (int i = 0; i < NDM; ++i) {
-      const int y = y0 - 1 + d_sy[i], x = x0 - 1 + d_sx[i];
+      const int y = STR * y0 - 1 + d_sy[i], x = STR * x0 - 1 + d_sx[i];
       const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
       d_off[i] = ok ? (uint32_t)(((long)n * p.H + y) * p.W + x) * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
     }
     if (tid < SP) {
-      const int y = y0 - 1 + m_sy, x = x0 - 1 + m_sx;
+      const int y = STR * y0 - 1 + m_sy, x = STR * x0 - 1 + m_sx;
       const unsigned long long m = __ballot(y >= 0 && y < p.H && x >= 0 && x < p.W);
       if (lane == 0) {
         uint32_t* mk = reinterpret_cast<uint32_t*>(smem + OFF_MASK);
@@ -207,17 +208,17 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     auto load_col_residuals = [&](int ix, u32x4 (&rr)[MAXIH], uint32_t (&oo)[MAXIH]) {
       const int cg = tidt % CG;
       const int ox = x0 + ix;
-      const uint32_t pix = (uint32_t)(((long)n * p.H + y0) * p.W + ox);
+      const uint32_t pix = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + ox);
       uint32_t xo = pix * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u, oof = pix * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u;
-      const bool col_ok = ix < p.IW && ox < p.W;
+      const bool col_ok = ix < p.IW && ox < p.Wo;
 #pragma unroll
       for (int iy = 0; iy < MAXIH; ++iy) {
-        const bool ok = col_ok && iy < p.IH && y0 + iy < p.H;
+        const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
         oo[iy] = ok ? oof : kInvalid;
         rr[iy] = u32x4{0u, 0u, 0u, 0u};
         if (p.skip) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
         xo += (uint32_t)(p.W * p.x_ps * 2);
-        oof += (uint32_t)(p.W * p.out_ps * 2);
+        oof += (uint32_t)(p.Wo * p.out_ps * 2);
       }
     };
     uint32_t o_off[PBI][4], r_raw[PBI][4];                  // phase 2a: output offsets and residual pairs of this lane's pixels
@@ -284,8 +285,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     {
       // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
       // pixels from the per-workgroup table (one 16-byte LDS read per block); edge tiles do the arithmetic.
-      const bool full = y0 + p.IH <= p.H && x0 + p.IW <= p.W;
-      const uint32_t pix0 = (uint32_t)(((long)n * p.H + y0) * p.W + x0);
+      const bool full = y0 + p.IH <= p.Ho && x0 + p.IW <= p.Wo;
+      const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
       const uint32_t xb = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)ch0 * 2u, ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)ch0 * 2u;
 #pragma unroll
       for (int pb = 0; pb < PBI; ++pb) {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             for (int r = 0; r < 4; ++r) {
               const int ip = 16 * pb + 4 * qt + r;
               const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
-              if (y0 + iy >= p.H || x0 + ix >= p.W) { xr[r] = kInvalid; orr[r] = kInvalid; }
+              if (y0 + iy >= p.Ho || x0 + ix >= p.Wo) { xr[r] = kInvalid; orr[r] = kInvalid; }
             }
           }
         }
@@ -386,17 +387,17 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             wt[dy][0] = f32x2{u0[0], u0[1]}; wt[dy][1] = f32x2{u0[2], u0[3]}; wt[dy][2] = f32x2{u1[0], u1[1]}; wt[dy][3] = f32x2{u1[2], u1[3]};
           }
 #pragma unroll
-          for (int sr = 0; sr < MAXIH + 2; ++sr) {           // squeeze row sr is tap row dy of output row sr - dy
-            if (sr < p.IH + 2) {
-              const int sp = sr * p.SW + ixc + dx;
+          for (int sr = 0; sr < STR * (MAXIH - 1) + 3; ++sr) {   // squeeze row sr is tap row dy of output row (sr - dy) / STR
+            if (sr < STR * (p.IH - 1) + 3) {
+              const int sp = sr * p.SW + STR * ixc + dx;
               const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
               f32x2 s2[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) s2[e] = f32x2{__builtin_bit_cast(float, sv[e] << 16), __builtin_bit_cast(float, sv[e] & 0xffff0000u)};
 #pragma unroll
               for (int dy = 0; dy < 3; ++dy) {
-                const int iy = sr - dy;
-                if (iy >= 0 && iy < MAXIH) {
+                const int iy = (sr - dy) / STR;
+                if (sr - dy >= 0 && (sr - dy) % STR == 0 && iy < MAXIH) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_elementwise_fma(s2[e], wt[dy][e], v[iy][e]);
                 }
@@ -426,20 +427,22 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 }  // namespace
 
 bool okp_fire2_supported(int cin, int mid, int half, int stride) {
-  if (stride != 1 || half != mid) return false;
-  return (cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 512 && mid == 256) ||
-         (cin == 384 && mid == 128) || (cin == 512 && mid == 192);
+  if (half != mid) return false;
+  if (stride == 1)
+    return (cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 512 && mid == 256) ||
+           (cin == 384 && mid == 128) || (cin == 512 && mid == 192);
+  return stride == 2 && ((cin == 256 && mid == 128) || (cin == 256 && mid == 192) || (cin == 384 && mid == 192) || (cin == 384 && mid == 256));
 }
 
-int okp_launch_fire2(OkpFire2Params p, int cin, int mid, hipStream_t stream) {
+int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream) {
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
   // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
   long best = -1;
-  for (int ih = 1; ih <= p.H && ih <= MAXIH; ++ih)
-    for (int iw = 1; iw <= p.W && iw <= 96; ++iw) {
-      const int sh = ih + 2, sw = iw + 2;
+  for (int ih = 1; ih <= p.Ho && ih <= MAXIH; ++ih)
+    for (int iw = 1; iw <= p.Wo && iw <= 96; ++iw) {
+      const int sh = stride * (ih - 1) + 3, sw = stride * (iw - 1) + 3;
       if (sh * sw > SP || ih * iw > 16 * PBI) continue;
-      const long ty = (p.H + ih - 1) / ih, tx = (p.W + iw - 1) / iw;
+      const long ty = (p.Ho + ih - 1) / ih, tx = (p.Wo + iw - 1) / iw;
       const long score = ty * tx * 4096 - iw;
       if (best < 0 || score < best) { best = score; p.IH = ih; p.IW = iw; p.SH = sh; p.SW = sw; p.tiles_y = (int)ty; p.tiles_x = (int)tx; }
     }
@@ -455,11 +458,17 @@ int okp_launch_fire2(OkpFire2Params p, int cin, int mid, hipStream_t stream) {
   p.div_rpr = okp_fastdiv((uint32_t)p.RPR);
   const int resident = 256 * (mid == 128 ? 2 : 1);
   const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block((unsigned)(2 * mid));
-  if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128>), grid, block, 0, stream, p);
-  else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192>), grid, block, 0, stream, p);
-  else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<512, 256>), grid, block, 0, stream, p);
-  else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<384, 128>), grid, block, 0, stream, p);
-  else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<512, 192>), grid, block, 0, stream, p);
-  else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d", cin, mid); return OKP_EINVAL; }
+  if (stride == 1) {
+    if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128, 1>), grid, block, 0, stream, p);
+    else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192, 1>), grid, block, 0, stream, p);
+    else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<512, 256, 1>), grid, block, 0, stream, p);
+    else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<384, 128, 1>), grid, block, 0, stream, p);
+    else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<512, 192, 1>), grid, block, 0, stream, p);
+    else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d", cin, mid); return OKP_EINVAL; }
+  } else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128, 2>), grid, block, 0, stream, p);
+  else if (cin == 256 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<256, 192, 2>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192, 2>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<384, 256, 2>), grid, block, 0, stream, p);
+  else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d stride %d", cin, mid, stride); return OKP_EINVAL; }
   return okp_check_hip(hipGetLastError(), "okp_fire2 launch");
 }

@@ -82,7 +82,7 @@ struct OkpFireParams {
 
 struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 128 -> 256, stride 1
   const void* x; uint32_t x_bytes; int32_t H, W, x_ps;
-  void* out; uint32_t out_bytes; int32_t out_ps;
+  void* out; uint32_t out_bytes; int32_t Ho, Wo, out_ps;    // Ho x Wo = ceil(H / stride) x ceil(W / stride)
   int32_t N, skip;
   const void* w1; int32_t w1_cout_pad; const float* b1;     // squeeze plan: packed [slice][cout_pad][128 B] bf16
   const void* wa; int32_t wa_cout_pad; const float* ba;     // expand plan
@@ -114,5 +114,5 @@ int okp_check_hip(hipError_t e, const char* what);
 int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
-int okp_launch_fire2(OkpFire2Params p, int cin, int mid, hipStream_t stream);
+int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream);
 int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip

@@ -181,13 +181,17 @@ FUSE_FIRE_ALL = os.environ.get("OKP_FUSE_FIRE_ALL", "0") == "1"   # tests / expe
                         # (okp_fire.hip: correct, but slower than squeeze + fused tail at every level)
 
 
-_FIRE2_CONFIGS = {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)}      # (cin, mid) instances of okp_fire2.hip
+_FIRE2_CONFIGS = {1: {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)},      # stride -> (cin, mid) instances of okp_fire2.hip
+                  2: {(256, 128), (256, 192), (384, 192), (384, 256)}}
+FUSE_FIRE_S2 = os.environ.get("OKP_FUSE_FIRE_S2", "1") == "1"
 
 
 def fire_fusable(inp_dim, mid, stride, h, w):
     if FUSE_FIRE_ALL:
         return inp_dim % 64 == 0 and mid % 64 == 0 and mid <= 256
-    return FUSE_FIRE and stride == 1 and (inp_dim, mid) in _FIRE2_CONFIGS and min(h, w) >= FUSE_FIRE_MIN_HW
+    if stride == 2 and not FUSE_FIRE_S2:
+        return False
+    return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):

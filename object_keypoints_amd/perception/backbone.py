@@ -26,6 +26,7 @@ from ..ops import Act, ConvPlan, OkpError, StemPlan
 
 import os
 STEM_KERNEL = os.environ.get("OKP_STEM_KERNEL", "1") != "0"     # bf16: dedicated stem kernel (okp_stem.hip); 0 = generic tap-list kernel
+UNPOOL_TILE = int(os.environ.get("OKP_UNPOOL_TILE", "0"))   # experiments: tile code of the transposed-conv launches (0 = heuristic)
 STEM_TILE = int(os.environ.get("OKP_STEM_TILE", "4"))      # 7x7/s2 stem: 128 co x 256 px tile measured fastest (603 vs 728 us)
 
 
@@ -244,7 +245,7 @@ class unpool_merge(_HipModule):
         if up1.h != 2 * low.h or up1.w != 2 * low.w:
             raise OkpError("unpool_merge: up1 must be twice the size of low")
         out = Act.empty(low.n, 2 * low.h, 2 * low.w, self.dim, low.dtype, low.t.device)
-        plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4)     # four output parities, one launch
+        plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4, tile=UNPOOL_TILE)     # four output parities, one launch
         return out
 
 

@@ -142,6 +142,9 @@ def test_bad_arguments_are_reported():
     (512, 384, 8, 8, 1, 2),        # streaming kernel <512,192>: no skip, streamed squeeze weights, 6 waves
     (384, 384, 16, 16, 1, 5),      # streaming kernel <384,192>: the 16x16 level
     (512, 512, 8, 8, 1, 3),        # streaming kernel <512,256>: 8 waves
+    (256, 256, 64, 64, 2, 1),      # streaming kernel, stride 2: 64x64 -> 32x32
+    (256, 256, 21, 35, 2, 2),      # stride 2, odd sizes (partial tiles)
+    (384, 384, 16, 16, 2, 3),      # stride 2 <384,192>
 ])
 def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
     """One-launch bf16 fire module vs the oracle's fire_module (fp32) on the same bf16-rounded input, and vs the
