@@ -25,7 +25,7 @@ def _rand(shape, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
     (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
     (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
