@@ -8,6 +8,8 @@ The deployed wrapper of scripts/package_model.py:21-28 is `KeypointNet.deployed(
 Device work is done by libokp_hip.so; inputs must be CUDA(HIP) tensors and the module must be in
 eval mode.  There is no CPU path here (the CPU restatement lives in oracle/ and is test-only).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -165,8 +167,9 @@ class KeypointNet(_HipModule):
     def deployed(self, x):
         """What the packaged model returns (scripts/package_model.py:26-28):
         sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed."""
+        chunks = self._chunks(x)
         outs = []
-        for xc in self._chunks(x):
+        for xc in chunks:
             feats = self._features(xc)
             outs.append(self._run_heads(1, feats[1], sigmoid=True))
         return tuple(torch.cat(t) if len(outs) > 1 else t[0] for t in zip(*outs))

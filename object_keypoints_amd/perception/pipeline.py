@@ -327,8 +327,15 @@ class BatchedKeypointPipeline:
             self.forward_device(static_in)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = self.forward_device(static_in)
+        # The hourglass' side streams are switched off while capturing: with them, replays of the captured graph were
+        # observed to differ intermittently from the eager result at batch 64 (scripts/probe_determinism.py; eager
+        # runs with side streams are bit-reproducible), i.e. the forked branches are not safely ordered by the graph.
+        keep, ops.SIDE_STREAMS = ops.SIDE_STREAMS, False
+        try:
+            with torch.cuda.graph(graph):
+                static_out = self.forward_device(static_in)
+        finally:
+            ops.SIDE_STREAMS = keep
         return graph, static_in, static_out
 
     def postprocess_device(self, heat, depth, centers):
