@@ -182,7 +182,7 @@ FUSE_FIRE_ALL = os.environ.get("OKP_FUSE_FIRE_ALL", "0") == "1"   # tests / expe
 
 
 _FIRE2_CONFIGS = {1: {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)},      # stride -> (cin, mid) instances of okp_fire2.hip
-                  2: {(256, 128), (256, 192), (384, 192), (384, 256)}}
+                  2: {(256, 128), (384, 192), (384, 256)}}
 FUSE_FIRE_S2 = os.environ.get("OKP_FUSE_FIRE_S2", "1") == "1"
 
 
