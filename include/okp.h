@@ -204,7 +204,7 @@ int okp_head_out_forward(int dtype, const okp_head_out_args* args, void* stream)
  *   peak = box == maxpool5x5(box) (padding ignored)  and  box > 0.5      [bit-exact contract]
  *   per peak (row-major order): confidence = sum of p over the clipped 5x5 window,
  *   (x, y) = sum(p * (x, y)) / confidence.
- * heat: [n_maps][h][w] fp32 (h*w <= 16384).  Outputs per map, capacity `cap` peaks:
+ * heat: [n_maps][h][w] fp32 (any height; w <= 2340: the map is walked in LDS-resident strips).  Outputs per map, capacity `cap` peaks:
  *   count[n_maps]        total peaks found (may exceed cap; only the first cap are stored)
  *   yx[n_maps][cap][2]   int32 (y, x)
  *   xyc[n_maps][cap][3]  fp32 (x, y, confidence)

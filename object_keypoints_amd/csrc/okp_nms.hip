@@ -1,4 +1,4 @@
-// Heat-map peak extraction: one workgroup per (frame, keypoint-type) map, the whole map and its
+// Heat-map peak extraction: one workgroup per (frame, keypoint-type) map, the map (or a strip of it) and its
 // 5x5 box sums resident in LDS, ordered compaction with wave-level ballot/prefix reductions.
 //
 // Restates KeypointExtractionComponent._extract_keypoints/_compute_points
@@ -12,86 +12,95 @@ namespace {
 
 constexpr int kNmsThreads = 1024;            // 4 pixels per thread on a 64x64 map: the map is latency-, not bandwidth-bound
 
-__global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int cap,
-                                                           int* __restrict__ count, int* __restrict__ yx,
-                                                           float* __restrict__ xyc) {
+// The map is walked in strips of R rows (R = H when it fits: one strip for the 64x64 maps of the network).  A strip keeps
+// the probabilities of rows [r0-4, r0+R+4) and the box sums of rows [r0-2, r0+R+2) in LDS: the 5x5 maximum of a box-sum
+// row needs box rows +-2, each of which needs probability rows +-2.  Strips are processed in order by the same workgroup
+// with a running peak count, so the row-major peak order of the reference is kept for maps of any size.
+__global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int R, int cap,
+                                                                   int* __restrict__ count, int* __restrict__ yx,
+                                                                   float* __restrict__ xyc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int HW = H * W;
-  float* prob = lds;            // [HW]
-  float* box = lds + HW;        // [HW]
+  float* prob = lds;                       // [(R+8) rows][W]
+  float* box = lds + (size_t)(R + 8) * W;  // [(R+4) rows][W]
   __shared__ int wave_tot[kNmsThreads / 64];
   const int map = blockIdx.x;
   const int tid = threadIdx.x;
-  const float* src = heat + (size_t)map * HW;
-  for (int i = tid; i < HW; i += kNmsThreads) prob[i] = src[i];
-  __syncthreads();
-  for (int i = tid; i < HW; i += kNmsThreads) {
-    const int y = i / W, x = i - y * W;
-    float s = 0.f;
-    for (int dy = -2; dy <= 2; ++dy) {
-      const int yy = y + dy;
-      for (int dx = -2; dx <= 2; ++dx) {
-        const int xx = x + dx;
-        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? prob[yy * W + xx] : 0.f;
-        s = s + v;     // sequential fp32, row-major taps: the reference's accumulation order
-      }
-    }
-    box[i] = s;
-  }
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
+  const float* src = heat + (size_t)map * H * W;
   int running = 0;
   int* my_yx = yx + (size_t)map * cap * 2;
   float* my_xyc = xyc + (size_t)map * cap * 3;
-  for (int base = 0; base < HW; base += kNmsThreads) {
-    const int i = base + tid;
-    bool peak = false;
-    int y = 0, x = 0;
-    if (i < HW) {
-      y = i / W; x = i - y * W;
-      const float b = box[i];
-      float m = b;
+  for (int r0 = 0; r0 < H; r0 += R) {
+    const int p0 = max(r0 - 4, 0), p1 = min(r0 + R + 4, H);        // probability rows held
+    const int b0 = max(r0 - 2, 0), b1 = min(r0 + R + 2, H);        // box-sum rows held
+    const int s1 = min(r0 + R, H);                                 // rows [r0, s1) are classified in this strip
+    for (int i = tid; i < (p1 - p0) * W; i += kNmsThreads) prob[i] = src[(size_t)p0 * W + i];
+    __syncthreads();
+    for (int i = tid; i < (b1 - b0) * W; i += kNmsThreads) {
+      const int y = b0 + i / W, x = i % W;
+      float s = 0.f;
       for (int dy = -2; dy <= 2; ++dy) {
         const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
         for (int dx = -2; dx <= 2; ++dx) {
           const int xx = x + dx;
-          if (xx < 0 || xx >= W) continue;
-          m = fmaxf(m, box[yy * W + xx]);
+          const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? prob[(yy - p0) * W + xx] : 0.f;
+          s = s + v;     // sequential fp32, row-major taps: the reference's accumulation order
         }
       }
-      peak = (b == m) && (b > 0.5f);
+      box[i] = s;
     }
-    const unsigned long long ball = __ballot(peak);
-    const int before = __popcll(ball & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(ball);
     __syncthreads();
-    int off = running + before;
-    int tot = 0;
-#pragma unroll
-    for (int w = 0; w < kNmsThreads / 64; ++w) {
-      const int t = wave_tot[w];
-      if (w < wave) off += t;
-      tot += t;
-    }
-    if (peak && off < cap) {
-      const int y0 = max(y - 2, 0), y1 = min(y + 3, H), x0 = max(x - 2, 0), x1 = min(x + 3, W);
-      float sp = 0.f, sy = 0.f, sx = 0.f;
-      for (int yy = y0; yy < y1; ++yy)
-        for (int xx = x0; xx < x1; ++xx) {
-          const float pv = prob[yy * W + xx];
-          sp += pv;
-          sy += pv * (float)yy;
-          sx += pv * (float)xx;
+    const int n_px = (s1 - r0) * W;
+    for (int base = 0; base < n_px; base += kNmsThreads) {
+      const int i = base + tid;
+      bool peak = false;
+      int y = 0, x = 0;
+      if (i < n_px) {
+        y = r0 + i / W; x = i % W;
+        const float b = box[(y - b0) * W + x];
+        float m = b;
+        for (int dy = -2; dy <= 2; ++dy) {
+          const int yy = y + dy;
+          if (yy < 0 || yy >= H) continue;
+          for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            m = fmaxf(m, box[(yy - b0) * W + xx]);
+          }
         }
-      my_yx[off * 2 + 0] = y;
-      my_yx[off * 2 + 1] = x;
-      my_xyc[off * 3 + 0] = sx / sp;
-      my_xyc[off * 3 + 1] = sy / sp;
-      my_xyc[off * 3 + 2] = sp;
+        peak = (b == m) && (b > 0.5f);
+      }
+      const unsigned long long ball = __ballot(peak);
+      const int before = __popcll(ball & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[wave] = __popcll(ball);
+      __syncthreads();
+      int off = running + before;
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < kNmsThreads / 64; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) off += t;
+        tot += t;
+      }
+      if (peak && off < cap) {
+        const int y0 = max(y - 2, 0), y1 = min(y + 3, H), x0 = max(x - 2, 0), x1 = min(x + 3, W);
+        float sp = 0.f, sy = 0.f, sx = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+          for (int xx = x0; xx < x1; ++xx) {
+            const float pv = prob[(yy - p0) * W + xx];
+            sp += pv;
+            sy += pv * (float)yy;
+            sx += pv * (float)xx;
+          }
+        my_yx[off * 2 + 0] = y;
+        my_yx[off * 2 + 1] = x;
+        my_xyc[off * 3 + 0] = sx / sp;
+        my_xyc[off * 3 + 1] = sy / sp;
+        my_xyc[off * 3 + 2] = sp;
+      }
+      running += tot;
+      __syncthreads();
     }
-    running += tot;
-    __syncthreads();
   }
   if (tid == 0) count[map] = running;
 }
@@ -136,17 +145,21 @@ extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_
                             int32_t* yx, float* xyc, void* stream) {
   if (!heat || !count || !yx || !xyc) { okp_set_error("okp_peak_nms: null argument"); return OKP_EINVAL; }
   if (n_maps < 0 || h < 1 || w < 1 || cap < 1) { okp_set_error("okp_peak_nms: bad sizes n_maps=%d h=%d w=%d cap=%d", n_maps, h, w, cap); return OKP_EINVAL; }
-  if ((long)h * w > 16384) { okp_set_error("okp_peak_nms: map %dx%d exceeds the 16384-pixel LDS-resident limit", h, w); return OKP_EINVAL; }
+  // strip height: (R + 8) probability rows + (R + 4) box-sum rows of w floats in at most 128 KiB of LDS
+  constexpr long kLdsFloats = 32768;
+  long rmax = (kLdsFloats / w - 12) / 2;
+  if (rmax < 1) { okp_set_error("okp_peak_nms: maps wider than %ld pixels are not supported (width %d)", kLdsFloats / 14, w); return OKP_EINVAL; }
+  const int R = (int)(rmax < h ? rmax : h);
   if (n_maps == 0) return OKP_OK;
-  const size_t lds = (size_t)h * w * 2 * sizeof(float);
+  const size_t lds = (size_t)(2 * R + 12) * w * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (int e = okp_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(okp_peak_nms_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 2 * sizeof(float)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))),
                               "okp_peak_nms: hipFuncSetAttribute"))
       return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(kNmsThreads), lds, (hipStream_t)stream, heat, h, w, cap, count, yx, xyc);
+  hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(kNmsThreads), lds, (hipStream_t)stream, heat, h, w, R, cap, count, yx, xyc);
   return okp_check_hip(hipGetLastError(), "okp_peak_nms launch");
 }

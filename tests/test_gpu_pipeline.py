@@ -264,3 +264,79 @@ def test_association_component_matches_oracle_and_reference_contract(known):
         r2 = np.concatenate([r[perm], rng.uniform(100, 1100, (2, 2))])
         np.testing.assert_allclose(assoc.cost(l, r2), op.epipolar_cost(ostereo, l, r2), rtol=1e-4, atol=5e-3)   # device undistort takes fp32 pixels
         assert assoc(l, r2).tolist() == oassoc(l, r2).tolist()
+
+
+def test_stereo_keypoints_end_to_end(known):
+    """BASELINE config 5 in miniature: known 3D keypoints seen by both cameras of the rig -> Gaussian-bump heat maps in
+    the two 160x90... (quarter-resolution) prediction spaces -> device peak extraction (okp_peak_nms) in each view ->
+    AssociationComponent -> TriangulationComponent (device undistort + Hartley-Sturm + DLT) -> the 3D points again.
+    Sub-pixel centroids of 2 px-wide bumps at quarter resolution bound the error: centimetres at one metre."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import geometry as og
+    calib = os.path.join(REPO, "config", "calibration.yaml")
+    p = og.load_calibration_params(calib)
+    scale = 0.25
+    oleft = og.FisheyeCamera(p["K"], p["D"], p["image_size"]).scale(scale)
+    oright = og.FisheyeCamera(p["Kp"], p["Dp"], p["image_size"]).scale(scale)
+    X = np.array([[0.05, 0.02, 1.0], [0.21, 0.10, 1.1], [-0.18, -0.12, 0.9], [0.10, -0.20, 1.2], [-0.25, 0.15, 1.05]])
+    pl = oleft.project(X, np.eye(4))
+    pr = oright.project(X, p["T_RL"])
+    H, W = 180, 320
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+
+    def render(points):
+        m = np.zeros((H, W), np.float32)
+        for x, y in points:
+            m += np.exp(-((xs - x) ** 2 + (ys - y) ** 2) / 4.0).astype(np.float32)
+        return np.clip(m, 0, 1)
+
+    heat = torch.from_numpy(np.stack([render(pl), render(pr)])[:, None]).cuda()      # [2 views, 1 map, H, W]
+    count, yx, xyc = [t.cpu().numpy() for t in ops.peak_nms(heat, cap=16)]
+    assert count[:, 0].tolist() == [5, 5]
+    left2d, right2d = xyc[0, 0, :5, :2].astype(np.float64), xyc[1, 0, :5, :2].astype(np.float64)
+    # the extraction orders peaks row-major: the two views see them in different orders
+    stereo = cu.StereoCamera(cu.FisheyeCamera(oleft.K, oleft.D, oleft.image_size), cu.FisheyeCamera(oright.K, oright.D, oright.image_size), p["T_RL"])
+    assoc = pp.AssociationComponent(max_distance=3.0)
+    assoc.reset(stereo)
+    match = assoc(left2d, right2d)
+    assert sorted(match.tolist()) == [0, 1, 2, 3, 4]
+    tri = pp.TriangulationComponent()
+    tri.reset(stereo)
+    X_hat = tri(left2d, right2d[match])
+    # match each recovered point to the nearest ground-truth point
+    d = np.linalg.norm(X_hat[:, None] - X[None], axis=2)
+    assert sorted(d.argmin(axis=1).tolist()) == [0, 1, 2, 3, 4]
+    assert d.min(axis=1).max() < 0.05, d.min(axis=1)
+    # and the 2D centroids are sub-pixel accurate in both views
+    e_l = np.linalg.norm(left2d[:, None] - pl[None], axis=2).min(axis=1).max()
+    e_r = np.linalg.norm(right2d[:, None] - pr[None], axis=2).min(axis=1).max()
+    assert e_l < 0.25 and e_r < 0.25
+
+
+@pytest.mark.parametrize("h,w", [(180, 320), (97, 33), (300, 7), (5, 700)])
+def test_peak_nms_on_large_maps_matches_oracle(h, w):
+    """Maps that do not fit LDS in one piece are processed in strips: indices, order, centroids and confidences must
+    equal the oracle's (the reference's own tests extract from 180x320 predictions, test/test_pipeline.py:97)."""
+    from object_keypoints_amd import ops
+    from oracle import pipeline as op
+    rng = np.random.default_rng(h * 1000 + w)
+    maps = np.zeros((3, h, w), np.float32)
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    for k in range(3):
+        for _ in range(12):
+            cy, cx = rng.uniform(0, h - 1), rng.uniform(0, w - 1)
+            maps[k] += np.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 4.0).astype(np.float32)
+    maps = np.clip(maps, 0, 1)
+    maps[2] += (rng.random((h, w)) < 0.0005).astype(np.float32) * 0.9         # isolated hot pixels (each a 5x5 plateau of tied box sums = 25 peaks)
+    maps = np.clip(maps, 0, 1).astype(np.float32)
+    count, yx, xyc = [t.cpu().numpy() for t in ops.peak_nms(torch.from_numpy(maps[None]).cuda(), cap=4096)]
+    for k in range(3):
+        idx = op.peak_indices(maps[k])
+        n = idx.shape[0]
+        assert int(count[0, k]) == n and n > 0
+        assert yx[0, k, :n].tolist() == idx.tolist()
+        pts, conf = op.refine_peaks(maps[k], idx)
+        np.testing.assert_allclose(xyc[0, k, :n, :2], np.stack(pts), rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(xyc[0, k, :n, 2], np.array(conf), rtol=1e-6, atol=1e-6)
