@@ -63,6 +63,8 @@ SIGNATURES = [
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_fire_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(okp_fire_args), c_void_p]),
+    ("okp_fire_chain_forward", c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int32,
+                                       POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),
     ("okp_dwconv3x3_forward", c_int, [c_int, c_int32, c_int32, c_int32, POINTER(okp_tensor), c_void_p, c_void_p, POINTER(okp_tensor), POINTER(okp_tensor), c_int, c_void_p]),
     ("okp_pack_frames", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     ("okp_pack_frames_u8", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p, c_int32, c_void_p]),

@@ -324,7 +324,8 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
   if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||
       ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) { okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL; }
   if (a->x.bytes <= 0 || a->x.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: x spans %lld bytes; views must be < 2 GiB", (long long)a->x.bytes); return OKP_EINVAL; }
-  if (okp_fire2_supported(cin, mid, half, a->stride) && !getenv("OKP_FIRE_V1")) {
+  static const bool force_v1 = getenv("OKP_FIRE_V1") != nullptr;      // experiments: first-generation kernel for every shape
+  if (okp_fire2_supported(cin, mid, half, a->stride) && !force_v1) {
     if (a->out.bytes <= 0 || a->out.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: out spans %lld bytes; views must be < 2 GiB", (long long)a->out.bytes); return OKP_EINVAL; }
     OkpFire2Params q;
     memset(&q, 0, sizeof(q));

@@ -1,0 +1,249 @@
+// A CHAIN of stride-1 fire modules (CIN -> CIN/2 -> CIN, with skip) on maps of at most 16 pixels, one workgroup per
+// frame, activations resident in LDS from the first module to the last (bf16, gfx950).
+//
+// The innermost hourglass level runs six consecutive fire_module(512, 512) on 4x4 maps (low1[1], low2[0..3], low3[0];
+// corner_net_lite/core/models/CornerNet_Squeeze.py:10-51 with modules [2,2,2,2,4]).  As separate launches each costs
+// about 20 us of launch and memory latency for ~3 MMAC per frame; here the frame's 16 x 512 activation stays in LDS,
+// only the weights stream from L2 (390 KB per module and workgroup), and the chain costs one launch.
+//
+//   per module:  s = W1 x + b1 (no ReLU)            squeeze 1x1            CIN -> MID = CIN/2
+//                y[:, :MID] = relu(Wa s + ba + x[:, :MID])                 expand 1x1
+//                y[:, MID:] = relu(dw3x3(s) * wd + bd + x[:, MID:])        depth-wise 3x3, zero padding
+//
+// 16x16x32 MFMAs with the 16 pixels as rows (A operand from LDS) and channels as columns (B operand = weight fragments
+// gathered from the packed [slice][cout][128 B] plan layout, prefetched PF k-steps ahead); wave w owns channels
+// [32 w, 32 w + 32) of both GEMMs, columns interleaved (2 j + b) so that a lane's two accumulator blocks are adjacent
+// channels (one dword per pixel).  The depth-wise branch: thread = (8-channel group, pixel), its 72 weights fetched at
+// the start of the module.
+#include <cstring>
+
+#include "okp_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CIN>
+struct ChainCfg {
+  static constexpr int MID = CIN / 2;
+  static constexpr int NW = MID / 32;                  // waves
+  static constexpr int NT = 64 * NW;
+  static constexpr int KS1 = CIN / 32, KS2 = MID / 32;
+  static constexpr int XROW = CIN * 2;                 // bytes per pixel row of an activation buffer
+  static constexpr int SROW = MID * 2;
+  static constexpr int OFF_X = 0;                      // two activation buffers [16][CIN]
+  static constexpr int OFF_S = 2 * 16 * XROW;          // squeeze tile [6 x 6 = 36 rows, zero halo][MID]
+  static constexpr int CONST_BYTES = 12 * MID * 4;    // per module: depth-wise weights [9][MID], bd, b1, ba (fp32)
+  static constexpr int OFF_C = OFF_S + 36 * SROW;      // two such blocks: the next module's constants arrive by LDS-DMA while this one runs
+  static constexpr int BYTES = OFF_C + 2 * CONST_BYTES;
+  static_assert((CIN / 8) % 16 == 0 && (MID / 8) % 16 == 0, "row swizzle needs whole 16-chunk groups");
+};
+
+// 16-byte chunk c of row r, XOR-swizzled by the row (16 rows x 4 k-groups of a fragment read hit distinct banks)
+// (rows of 16 k chunks, k >= 1: the XOR stays inside a 16-chunk group)
+__device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & 15)) << 4); }
+
+template <int CIN>
+__global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const OkpFireChainParams p) {
+  using C = ChainCfg<CIN>;
+  constexpr int MID = C::MID, NT = C::NT, KS1 = C::KS1, KS2 = C::KS2, XROW = C::XROW, SROW = C::SROW;
+  constexpr int PF = 8;                                // weight fragments in flight ahead of the MFMAs
+  __shared__ __attribute__((aligned(16))) char smem[C::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, q = lane >> 4;
+  const int n = blockIdx.x;
+  const int HW = p.H * p.W;
+  const int ch0 = 32 * w + 2 * l16;                    // this lane's channel pair in both GEMMs
+
+  // frame -> LDS (buffer 0), squeeze tile cleared once: its halo stays zero for the whole chain
+  {
+    const char* src = static_cast<const char*>(p.x) + (size_t)n * HW * p.x_ps * 2;
+    for (int i = tid; i < 16 * (CIN / 8); i += NT) {
+      const int px = i / (CIN / 8), c = i % (CIN / 8);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (px < HW) v = *reinterpret_cast<const u32x4*>(src + (size_t)px * p.x_ps * 2 + c * 16);
+      *reinterpret_cast<u32x4*>(smem + C::OFF_X + xoff(px, c, XROW)) = v;
+    }
+    for (int i = tid; i < 36 * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // interior pixel l16 -> squeeze-tile row (zero halo of one pixel around the H x W map, row pitch W + 2)
+  const int SW = p.W + 2;
+  auto srow = [&](int px) { const int py = px / p.W; return (py + 1) * SW + (px - py * p.W) + 1; };
+  __syncthreads();
+
+  // per-module constants -> LDS by LDS-DMA (no registers, nobody waits until the module that needs them starts):
+  // a module then has no dependent global round trips besides its streamed weight fragments
+  auto fetch_consts = [&](const OkpFireChainModule& mod, int slot) {
+    char* dst = smem + C::OFF_C + slot * C::CONST_BYTES;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.wd), 0, 9 * MID * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.bd), 0, MID * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.b1), 0, MID * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.ba), 0, MID * 4, 0x00020000);
+    // 12 * MID * 4 bytes = 12 KiB at MID = 256: instruction i covers bytes [1024 i, +1024); wave w takes i = w, w + NW, ...
+    for (int i = w; i < C::CONST_BYTES / 1024; i += C::NW) {
+      const int off = i * 1024;                         // wave-uniform: which array this KiB belongs to
+      lds_ptr_t d = (lds_ptr_t)(dst + off);
+      if (off < 9 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, d, 16, off + lane * 16, 0, 0, 0);
+      else if (off < 10 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, d, 16, off - 9 * MID * 4 + lane * 16, 0, 0, 0);
+      else if (off < 11 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, d, 16, off - 10 * MID * 4 + lane * 16, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, d, 16, off - 11 * MID * 4 + lane * 16, 0, 0, 0);
+    }
+  };
+  static_assert((MID * 4) % 1024 == 0, "every constant array is a whole number of 1 KiB LDS-DMA instructions");
+  fetch_consts(p.mod[0], 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int m = 0; m < p.n_modules; ++m) {
+    const OkpFireChainModule mod = p.mod[m];
+    const float* cst = reinterpret_cast<const float*>(smem + C::OFF_C + (m & 1) * C::CONST_BYTES);
+    if (m + 1 < p.n_modules) fetch_consts(p.mod[m + 1], (m + 1) & 1);     // lands during this module; waited at its end
+    const char* w1_lane = static_cast<const char*>(mod.w1) + (size_t)ch0 * 128 + q * 16;
+    const char* wa_lane = static_cast<const char*>(mod.wa) + (size_t)ch0 * 128 + q * 16;
+    auto frag = [&](const char* base, int cout_pad, int ks, int b) {
+      return *reinterpret_cast<const u32x4*>(base + (size_t)(ks >> 1) * cout_pad * 128 + b * 128 + (ks & 1) * 64);
+    };
+    const int cg = tid % (MID / 8), dpx = tid / (MID / 8);   // depth-wise branch: 8-channel group, pixel
+    const char* xc = smem + C::OFF_X + cur * 16 * XROW;
+    char* xn = smem + C::OFF_X + (cur ^ 1) * 16 * XROW;
+
+    // ---- squeeze: s[px][ch] for the 16 pixel rows, weights streamed PF k-steps ahead ------------------------------
+    {
+      const float b0 = cst[10 * MID + ch0], b1 = cst[10 * MID + ch0 + 1];
+      f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+      u32x4 wf[PF][2];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, mod.w1_cout_pad, i, 0); wf[i][1] = frag(w1_lane, mod.w1_cout_pad, i, 1); }
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(xc + xoff(l16, 4 * ks + q, XROW));
+        const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
+        if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, mod.w1_cout_pad, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, mod.w1_cout_pad, ks + PF, 1); }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
+      }
+      // accumulator register r is pixel 4 q + r; the channel pair is one dword of the squeeze tile's interior
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = 4 * q + r;
+        if (px < HW) {
+          bf16x2 v;
+          v[0] = (__bf16)acc0[r]; v[1] = (__bf16)acc1[r];
+          const int row = srow(px);
+          *reinterpret_cast<bf16x2*>(smem + C::OFF_S + xoff(row, (ch0 * 2) >> 4, SROW) + ((ch0 * 2) & 15)) = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- expand: y[:, :MID] = relu(Wa s + ba + x[:, :MID]) -> next activation buffer ----------------------------------
+    {
+      const float b0 = cst[11 * MID + ch0], b1 = cst[11 * MID + ch0 + 1];
+      f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+      const int arow = srow(l16 < HW ? l16 : 0);
+      u32x4 wf[PF][2];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(wa_lane, mod.wa_cout_pad, i, 0); wf[i][1] = frag(wa_lane, mod.wa_cout_pad, i, 1); }
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff(arow, 4 * ks + q, SROW));
+        const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
+        if (ks + PF < KS2) { wf[ks % PF][0] = frag(wa_lane, mod.wa_cout_pad, ks + PF, 0); wf[ks % PF][1] = frag(wa_lane, mod.wa_cout_pad, ks + PF, 1); }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = 4 * q + r;
+        const uint32_t o = xoff(px, (ch0 * 2) >> 4, XROW) + ((ch0 * 2) & 15);
+        const bf16x2 xv = *reinterpret_cast<const bf16x2*>(xc + o);
+        bf16x2 v;
+        v[0] = (__bf16)fmaxf(acc0[r] + (float)xv[0], 0.f);
+        v[1] = (__bf16)fmaxf(acc1[r] + (float)xv[1], 0.f);
+        if (px >= HW) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; }
+        *reinterpret_cast<bf16x2*>(xn + o) = v;
+      }
+    }
+
+    // ---- depth-wise: y[:, MID:] = relu(dw3x3(s) + bd + x[:, MID:]) -----------------------------------------------------
+    {
+      float v[8];
+      {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(cst + 9 * MID + cg * 8), u1 = *reinterpret_cast<const f32x4*>(cst + 9 * MID + cg * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
+      }
+      const int px = dpx < HW ? dpx : 0;
+      const int py = px / p.W, pxx = px - py * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int row = (py + t / 3) * SW + pxx + t % 3;         // (py + 1 + dy) * SW + pxx + 1 + dx with dy, dx in -1..1
+        const bf16x8 sv = *reinterpret_cast<const bf16x8*>(smem + C::OFF_S + xoff(row, cg, SROW));
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8), w1 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaf((float)sv[e], w0[e], v[e]); v[4 + e] = fmaf((float)sv[4 + e], w1[e], v[4 + e]); }
+      }
+      const uint32_t o = xoff(dpx, (MID * 2) / 16 + cg, XROW);
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xc + o);
+      bf16x8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = (__bf16)(dpx < HW ? fmaxf(v[e] + (float)xv[e], 0.f) : 0.f);
+      *reinterpret_cast<bf16x8*>(xn + o) = out;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next module's constants have landed (this wave's share)
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // result -> HBM
+  {
+    const char* xc = smem + C::OFF_X + cur * 16 * XROW;
+    char* dst = static_cast<char*>(p.out) + (size_t)n * HW * p.out_ps * 2;
+    for (int i = tid; i < HW * (CIN / 8); i += NT) {
+      const int px = i / (CIN / 8), c = i % (CIN / 8);
+      *reinterpret_cast<u32x4*>(dst + (size_t)px * p.out_ps * 2 + c * 16) = *reinterpret_cast<const u32x4*>(xc + xoff(px, c, XROW));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int okp_fire_chain_forward(int32_t n_modules, const okp_conv* const* squeeze, const okp_conv* const* expand,
+                                      const float* const* dw_w_dev, const float* const* dw_bias_dev,
+                                      int32_t n, const okp_tensor* x, const okp_tensor* out, void* stream) {
+  if (!squeeze || !expand || !dw_w_dev || !dw_bias_dev || !x || !out || !x->data || !out->data) { okp_set_error("okp_fire_chain_forward: null argument"); return OKP_EINVAL; }
+  if (n_modules < 1 || n_modules > OKP_FIRE_CHAIN_MAX) { okp_set_error("okp_fire_chain_forward: 1..%d modules", OKP_FIRE_CHAIN_MAX); return OKP_EINVAL; }
+  if (n < 1) return OKP_OK;
+  OkpFireChainParams p;
+  std::memset(&p, 0, sizeof(p));
+  int cin = 0;
+  for (int m = 0; m < n_modules; ++m) {
+    const okp_conv *sq = squeeze[m], *ex = expand[m];
+    if (!sq || !ex || !dw_w_dev[m] || !dw_bias_dev[m]) { okp_set_error("okp_fire_chain_forward: null module %d", m); return OKP_EINVAL; }
+    if (sq->dtype != OKP_BF16 || ex->dtype != OKP_BF16 || sq->n_taps != 1 || ex->n_taps != 1 || sq->n_src != 1 || ex->n_src != 1) {
+      okp_set_error("okp_fire_chain_forward: module %d: bf16 single-tap 1x1 plans expected", m); return OKP_EINVAL;
+    }
+    if (m == 0) cin = sq->cin[0];
+    if (sq->cin[0] != cin || sq->cout * 2 != cin || ex->cin[0] != sq->cout || ex->cout != sq->cout) {
+      okp_set_error("okp_fire_chain_forward: module %d is not a %d -> %d -> %d fire module", m, cin, cin / 2, cin); return OKP_EINVAL;
+    }
+    p.mod[m].w1 = sq->weights_dev; p.mod[m].w1_cout_pad = sq->cout_pad; p.mod[m].b1 = sq->bias_dev;
+    p.mod[m].wa = ex->weights_dev; p.mod[m].wa_cout_pad = ex->cout_pad; p.mod[m].ba = ex->bias_dev;
+    p.mod[m].wd = dw_w_dev[m]; p.mod[m].bd = dw_bias_dev[m];
+  }
+  if (cin != 512) { okp_set_error("okp_fire_chain_forward: built for 512-channel chains (the innermost hourglass level), got %d", cin); return OKP_EINVAL; }
+  if (x->h != out->h || x->w != out->w || x->h > 4 || x->w > 4 || x->h < 1 || x->w < 1) { okp_set_error("okp_fire_chain_forward: maps of at most 4 x 4 pixels, same size in and out"); return OKP_EINVAL; }
+  if (x->pix_stride < cin || out->pix_stride < cin || x->pix_stride % 8 || out->pix_stride % 8 || ((uintptr_t)x->data) % 16 || ((uintptr_t)out->data) % 16) {
+    okp_set_error("okp_fire_chain_forward: views must be 16-byte aligned with >= %d channels", cin); return OKP_EINVAL;
+  }
+  if ((int64_t)n * x->h * x->w * x->pix_stride * 2 > x->bytes + (int64_t)(x->pix_stride - cin) * 2 ||
+      (int64_t)n * out->h * out->w * out->pix_stride * 2 > out->bytes + (int64_t)(out->pix_stride - cin) * 2) {
+    okp_set_error("okp_fire_chain_forward: views too small for %d frames", n); return OKP_EINVAL;
+  }
+  p.n_modules = n_modules; p.x = x->data; p.out = out->data; p.x_ps = x->pix_stride; p.out_ps = out->pix_stride; p.H = x->h; p.W = x->w;
+  hipLaunchKernelGGL((okp_fire_chain_kernel<512>), dim3(n), dim3(ChainCfg<512>::NT), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_fire_chain launch");
+}

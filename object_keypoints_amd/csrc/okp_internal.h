@@ -91,6 +91,16 @@ struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 12
   OkpFastDiv div_tiles_frame, div_tiles_x, div_sw, div_iw, div_rpr;
 };
 
+struct OkpFireChainModule {   // okp_fire_chain.hip
+  const void* w1; int32_t w1_cout_pad; const float* b1;
+  const void* wa; int32_t wa_cout_pad; const float* ba;
+  const float* wd; const float* bd;
+};
+struct OkpFireChainParams {
+  const void* x; void* out; int32_t x_ps, out_ps, H, W, n_modules;
+  OkpFireChainModule mod[OKP_FIRE_CHAIN_MAX];
+};
+
 struct okp_conv {
   int dtype;
   int n_src;

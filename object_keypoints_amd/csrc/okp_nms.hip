@@ -6,6 +6,8 @@
 // The index contract is bit-exact: the box sum is accumulated in fp32 in row-major tap order
 // (dy outer, dx inner) starting from 0 with zero padding — any other association changes which
 // pixels tie with their 5x5 maximum (SURVEY.md §7 "Bit-exact peaks").
+#include <atomic>
+
 #include "okp_internal.h"
 
 namespace {
@@ -152,13 +154,13 @@ extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_
   const int R = (int)(rmax < h ? rmax : h);
   if (n_maps == 0) return OKP_OK;
   const size_t lds = (size_t)(2 * R + 12) * w * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};          // idempotent attribute: a race only repeats the call
+  if (!attr_set.load(std::memory_order_acquire)) {
     if (int e = okp_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(okp_peak_nms_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))),
                               "okp_peak_nms: hipFuncSetAttribute"))
       return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(kNmsThreads), lds, (hipStream_t)stream, heat, h, w, R, cap, count, yx, xyc);
   return okp_check_hip(hipGetLastError(), "okp_peak_nms launch");

@@ -173,6 +173,25 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
     COUNTERS["launches"] += 1
 
 
+FIRE_CHAIN_MAX = 8
+FUSE_FIRE_CHAIN = os.environ.get("OKP_FUSE_FIRE_CHAIN", "1") == "1"   # consecutive 512-channel fire modules on <= 4x4 maps: one resident launch
+
+
+def fire_chain(modules, x, out):
+    """modules: list of (squeeze plan, expand plan, dw weights, dw bias) of consecutive fire(512, 512) modules; x, out: Acts."""
+    n = len(modules)
+    sq = (ctypes.c_void_p * n)(*[m[0]._h for m in modules])
+    ex = (ctypes.c_void_p * n)(*[m[1]._h for m in modules])
+    wd = (ctypes.c_void_p * n)(*[m[2].data_ptr() for m in modules])
+    bd = (ctypes.c_void_p * n)(*[m[3].data_ptr() for m in modules])
+    xv, ov = x.view(), out.view()
+    _lib.check(_lib.lib().okp_fire_chain_forward(n, sq, ex, wd, bd, x.n, ctypes.byref(xv), ctypes.byref(ov), stream_handle()), "okp_fire_chain_forward")
+    for m in modules:
+        half = m[1].cout
+        COUNTERS["macs"] += x.n * x.h * x.w * (m[0].cout * m[0].cins[0] + half * (m[1].cins[0] + 9))
+    COUNTERS["launches"] += 1
+
+
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64

@@ -253,11 +253,32 @@ def make_unpool_layer(dim):
     return unpool_merge(dim)
 
 
+def run_fire_modules(mods, x):
+    """Apply consecutive fire modules.  Runs of stride-1 fire(512, 512) modules on maps of at most 4 x 4 pixels (the
+    innermost hourglass level: six in a row) go through ONE resident launch (ops.fire_chain / okp_fire_chain_forward)."""
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        j = i
+        if ops.FUSE_FIRE_CHAIN and x.dtype == torch.bfloat16 and x.h <= 4 and x.w <= 4:
+            while (j < len(mods) and j - i < ops.FIRE_CHAIN_MAX and mods[j].stride == 1 and mods[j].skip
+                   and mods[j].inp_dim == 512 and mods[j].out_dim == 512):
+                j += 1
+        if j - i >= 2:
+            plans = [m._plan(("p", x.dtype), lambda m=m: m._build(x.dtype, x.t.device)) for m in mods[i:j]]
+            out = Act.empty(x.n, x.h, x.w, 512, x.dtype, x.t.device)
+            ops.fire_chain(plans, x, out)
+            x = out
+            i = j
+        else:
+            x = mods[i](x)
+            i += 1
+    return x
+
+
 class _FireSeq(nn.Sequential):
     def forward(self, x):
-        for m in self:
-            x = m(x)
-        return x
+        return run_fire_modules(self, x)
 
 
 def make_layer(inp_dim, out_dim, modules):
@@ -290,7 +311,7 @@ class hg_module(nn.Module):
         them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph)."""
         if not ops.SIDE_STREAMS:
             up1 = self.up1(x)
-            low3 = self.low3(self.low2(self.low1(x)))  # max1 is the identity (CornerNet_Squeeze.py:32-33)
+            low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)
             return self.up2(low3, up1)
         main = torch.cuda.current_stream()
         side = self._side_stream(x.t.device)
@@ -298,10 +319,15 @@ class hg_module(nn.Module):
         with torch.cuda.stream(side):
             up1 = self.up1(x)
         x.t.record_stream(side)
-        low3 = self.low3(self.low2(self.low1(x)))
+        low3 = self._low_path(x)
         main.wait_stream(side)                          # join before the merge
         up1.t.record_stream(main)
         return self.up2(low3, up1)
+
+    def _low_path(self, x):
+        if isinstance(self.low2, _FireSeq):             # innermost level: low1, low2, low3 are one list of fire modules
+            return run_fire_modules(list(self.low1) + list(self.low2) + list(self.low3), x)
+        return self.low3(self.low2(self.low1(x)))
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)

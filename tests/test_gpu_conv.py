@@ -261,3 +261,39 @@ def test_stem_kernel_rejects_bad_views():
         plan(packed, ops.Act.empty(1, 17, 17, 64, torch.bfloat16, dev))        # too few channels
     with pytest.raises(ops.OkpError):
         ops.StemPlan(np.zeros((64, 3, 7, 7), np.float32), np.zeros(64, np.float32))
+
+
+@pytest.mark.parametrize("h,w,n,count", [(4, 4, 5, 6), (3, 4, 2, 2), (2, 2, 3, 8), (1, 3, 1, 3)])
+def test_fire_chain_matches_module_by_module(h, w, n, count):
+    """okp_fire_chain_forward (activations resident in LDS across `count` fire(512, 512) modules) against the oracle's
+    modules applied one by one (fp32) and against the product's own module-by-module path."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    dev = _dev()
+    omods = [onet.load_synthetic(onet.fire_module(512, 512), seed=30 + i) for i in range(count)]
+    mods = []
+    for o in omods:
+        m = bb.fire_module(512, 512)
+        m.load_state_dict(o.state_dict())
+        mods.append(m.eval())
+    x = _rand((n, 512, h, w), 77).bfloat16().float()
+    ref = x
+    with torch.no_grad():
+        for o in omods:
+            ref = o(ref)
+    xa = ops.Act.from_nchw(x.to(dev), torch.bfloat16)
+    keep = ops.FUSE_FIRE_CHAIN
+    try:
+        ops.FUSE_FIRE_CHAIN = True
+        l0 = ops.COUNTERS["launches"]
+        got = bb.run_fire_modules(mods, xa).to_nchw().float().cpu()
+        assert ops.COUNTERS["launches"] - l0 == 1
+        ops.FUSE_FIRE_CHAIN = False
+        single = bb.run_fire_modules(mods, xa).to_nchw().float().cpu()
+    finally:
+        ops.FUSE_FIRE_CHAIN = keep
+    scale = float(ref.abs().max())
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 0.03 * scale * max(1, count // 2) + 0.02, float((got - ref).abs().max())
+    assert float((got - single).abs().max()) <= 0.02 * scale * max(1, count // 2) + 0.02
