@@ -133,7 +133,7 @@ int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const floa
  * fire_module(512, 512) of the innermost hourglass level (CornerNet_Squeeze.py:10-51, modules [2,2,2,2,4]).
  * Module m is given as for okp_fire_forward: squeeze[m], expand[m] plans, depth-wise weights / bias on the device. */
 #define OKP_FIRE_CHAIN_MAX 8
-int okp_fire_chain_forward(int32_t n_modules, const okp_conv* const* squeeze, const okp_conv* const* expand,
+int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv* const* expand,   /* plans gain a fragment-order weight copy on first use */
                            const float* const* dw_w_dev, const float* const* dw_bias_dev,
                            int32_t n, const okp_tensor* x, const okp_tensor* out, void* stream);
 

@@ -144,6 +144,7 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
   if (plan->weights_dev) (void)hipFree(plan->weights_dev);
   if (plan->bias_dev) (void)hipFree(plan->bias_dev);
   if (plan->slices_dev) (void)hipFree(plan->slices_dev);
+  if (plan->frag_dev) (void)hipFree(plan->frag_dev);
   delete plan;
 }
 

@@ -332,8 +332,10 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
     q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.Ho = ho; q.Wo = wo; q.out_ps = a->out.pix_stride;
     q.N = a->n; q.skip = a->skip;
-    q.w1 = squeeze->weights_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
-    q.wa = expand->weights_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
+    if (int e = okp_ensure_frags(squeeze, (hipStream_t)stream)) return e;
+    if (int e = okp_ensure_frags(expand, (hipStream_t)stream)) return e;
+    q.w1 = squeeze->frag_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
+    q.wa = expand->frag_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
     q.wd = dw_w_dev; q.bd = dw_bias_dev;
     return okp_launch_fire2(q, cin, mid, a->stride, (hipStream_t)stream);
   }

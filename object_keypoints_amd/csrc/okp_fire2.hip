@@ -93,18 +93,19 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   // ---- once per workgroup: resident squeeze weights, depth-wise constants -> LDS -----------------------------
   // B fragment (column = channel c, k-step ks, k-group q) = 16 bytes at [slice ks/2][row c][64 (ks&1) + 16 q]
   const int ch0 = 32 * w + 2 * l16;                         // this lane's channel pair (ch0, ch0 + 1) in both GEMMs
-  const char* const w1_lane = static_cast<const char*>(p.w1) + (size_t)ch0 * 128 + q * 16;
+  // weights in fragment order [wave][block b][k-step][lane][16 B] (okp_ensure_frags): one load = 1 KiB contiguous per
+  // wave (the packed plan layout would give 16 separate 64-byte segments per load: measured 4x slower to stream)
+  const u32x4* const w1_lane = static_cast<const u32x4*>(p.w1) + (size_t)w * 2 * KS1 * 64 + lane;
   auto load_w1 = [&](int ks, u32x4 (&dst)[2]) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-      dst[b] = *reinterpret_cast<const u32x4*>(w1_lane + (size_t)(ks >> 1) * p.w1_cout_pad * 128 + b * 128 + (ks & 1) * 64);
+    for (int b = 0; b < 2; ++b) dst[b] = w1_lane[(size_t)(b * KS1 + ks) * 64];
   };
   u32x4 w1f[RES ? KS1 : 3][2];                                // resident: all k-steps; streamed: three rotating sets
   if constexpr (RES) {
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) load_w1(ks, w1f[ks]);
   }
-  const char* const wa_lane = static_cast<const char*>(p.wa) + (size_t)ch0 * 128 + q * 16;
+  const u32x4* const wa_lane = static_cast<const u32x4*>(p.wa) + (size_t)w * 2 * KS2 * 64 + lane;
   const float b1v0 = p.b1[ch0], b1v1 = p.b1[ch0 + 1];
   const float bav0 = p.ba[ch0], bav1 = p.ba[ch0 + 1];
   for (int i = tid; i < 10 * HALF; i += NT)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks)
-        waf[b][ks] = *reinterpret_cast<const u32x4*>(wa_lane + (size_t)(ks >> 1) * p.wa_cout_pad * 128 + b * 128 + (ks & 1) * 64);
+        waf[b][ks] = wa_lane[(size_t)(b * KS2 + ks) * 64];
     // s -> LDS (zero outside the frame: the reference zero-pads the squeeze output)
     {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(smem + OFF_MASK);

@@ -11,7 +11,7 @@
 //                y[:, MID:] = relu(dw3x3(s) * wd + bd + x[:, MID:])        depth-wise 3x3, zero padding
 //
 // 16x16x32 MFMAs with the 16 pixels as rows (A operand from LDS) and channels as columns (B operand = weight fragments
-// gathered from the packed [slice][cout][128 B] plan layout, prefetched PF k-steps ahead); wave w owns channels
+// re-laid once per plan into fragment order so that a load is 1 KiB contiguous, prefetched PF k-steps ahead); wave w owns channels
 // [32 w, 32 w + 32) of both GEMMs, columns interleaved (2 j + b) so that a lane's two accumulator blocks are adjacent
 // channels (one dword per pixel).  The depth-wise branch: thread = (8-channel group, pixel), its 72 weights fetched at
 // the start of the module.
@@ -101,11 +101,10 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
     const OkpFireChainModule mod = p.mod[m];
     const float* cst = reinterpret_cast<const float*>(smem + C::OFF_C + (m & 1) * C::CONST_BYTES);
     if (m + 1 < p.n_modules) fetch_consts(p.mod[m + 1], (m + 1) & 1);     // lands during this module; waited at its end
-    const char* w1_lane = static_cast<const char*>(mod.w1) + (size_t)ch0 * 128 + q * 16;
-    const char* wa_lane = static_cast<const char*>(mod.wa) + (size_t)ch0 * 128 + q * 16;
-    auto frag = [&](const char* base, int cout_pad, int ks, int b) {
-      return *reinterpret_cast<const u32x4*>(base + (size_t)(ks >> 1) * cout_pad * 128 + b * 128 + (ks & 1) * 64);
-    };
+    // weights in fragment order [wave][block b][k-step][lane][16 B]: one load = 1 KiB contiguous per wave
+    const u32x4* w1_lane = static_cast<const u32x4*>(mod.w1) + (size_t)w * 2 * KS1 * 64 + lane;
+    const u32x4* wa_lane = static_cast<const u32x4*>(mod.wa) + (size_t)w * 2 * KS2 * 64 + lane;
+    auto frag = [&](const u32x4* base, int ksteps, int ks, int b) { return base[(size_t)(b * ksteps + ks) * 64]; };
     const int cg = tid % (MID / 8), dpx = tid / (MID / 8);   // depth-wise branch: 8-channel group, pixel
     const char* xc = smem + C::OFF_X + cur * 16 * XROW;
     char* xn = smem + C::OFF_X + (cur ^ 1) * 16 * XROW;
@@ -116,12 +115,12 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
       f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
       u32x4 wf[PF][2];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, mod.w1_cout_pad, i, 0); wf[i][1] = frag(w1_lane, mod.w1_cout_pad, i, 1); }
+      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, KS1, i, 0); wf[i][1] = frag(w1_lane, KS1, i, 1); }
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(xc + xoff(l16, 4 * ks + q, XROW));
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
-        if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, mod.w1_cout_pad, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, mod.w1_cout_pad, ks + PF, 1); }
+        if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
       }
@@ -146,12 +145,12 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
       const int arow = srow(l16 < HW ? l16 : 0);
       u32x4 wf[PF][2];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(wa_lane, mod.wa_cout_pad, i, 0); wf[i][1] = frag(wa_lane, mod.wa_cout_pad, i, 1); }
+      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(wa_lane, KS2, i, 0); wf[i][1] = frag(wa_lane, KS2, i, 1); }
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff(arow, 4 * ks + q, SROW));
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
-        if (ks + PF < KS2) { wf[ks % PF][0] = frag(wa_lane, mod.wa_cout_pad, ks + PF, 0); wf[ks % PF][1] = frag(wa_lane, mod.wa_cout_pad, ks + PF, 1); }
+        if (ks + PF < KS2) { wf[ks % PF][0] = frag(wa_lane, KS2, ks + PF, 0); wf[ks % PF][1] = frag(wa_lane, KS2, ks + PF, 1); }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
       }
@@ -211,7 +210,36 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
 
 }  // namespace
 
-extern "C" int okp_fire_chain_forward(int32_t n_modules, const okp_conv* const* squeeze, const okp_conv* const* expand,
+namespace {
+// packed [slice][cout_pad][128 B] -> fragment order: lane (j = l & 15, q = l >> 4) of wave w, block b, k-step ks holds
+// the 16 bytes of channel 32 w + 2 j + b at K offset 32 ks + 8 q
+__global__ void okp_frag_relayout_kernel(const u32x4* __restrict__ packed, int cout_pad, int ksteps, int n_waves, u32x4* __restrict__ out) {
+  const int total = n_waves * 2 * ksteps * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, ks = (i >> 6) % ksteps, b = ((i >> 6) / ksteps) & 1, w = (i >> 6) / ksteps / 2;
+    const int ch = 32 * w + 2 * (lane & 15) + b, q = lane >> 4;
+    out[i] = packed[((size_t)(ks >> 1) * cout_pad + ch) * 8 + (ks & 1) * 4 + q];
+  }
+}
+
+}  // namespace
+
+int okp_ensure_frags(const okp_conv* cplan, hipStream_t stream) {
+  okp_conv* plan = const_cast<okp_conv*>(cplan);          // a cache inside the plan, not a change of its meaning
+  if (plan->frag_dev) return OKP_OK;
+  const int ksteps = plan->cin[0] / 32, n_waves = plan->cout / 32;
+  const size_t bytes = (size_t)n_waves * 2 * ksteps * 64 * 16;
+  void* buf = nullptr;
+  if (int e = okp_check_hip(hipMalloc(&buf, bytes), "okp_fire_chain_forward: hipMalloc(fragments)")) return e;
+  hipLaunchKernelGGL(okp_frag_relayout_kernel, dim3(64), dim3(256), 0, stream, static_cast<const u32x4*>(plan->weights_dev), plan->cout_pad, ksteps, n_waves,
+                     static_cast<u32x4*>(buf));
+  if (int e = okp_check_hip(hipGetLastError(), "okp_frag_relayout launch")) { (void)hipFree(buf); return e; }
+  plan->frag_dev = buf;          // same stream as the consumer: ordered
+  return OKP_OK;
+}
+
+
+extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv* const* expand,
                                       const float* const* dw_w_dev, const float* const* dw_bias_dev,
                                       int32_t n, const okp_tensor* x, const okp_tensor* out, void* stream) {
   if (!squeeze || !expand || !dw_w_dev || !dw_bias_dev || !x || !out || !x->data || !out->data) { okp_set_error("okp_fire_chain_forward: null argument"); return OKP_EINVAL; }
@@ -221,7 +249,7 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, const okp_conv* const* 
   std::memset(&p, 0, sizeof(p));
   int cin = 0;
   for (int m = 0; m < n_modules; ++m) {
-    const okp_conv *sq = squeeze[m], *ex = expand[m];
+    okp_conv *sq = squeeze[m], *ex = expand[m];
     if (!sq || !ex || !dw_w_dev[m] || !dw_bias_dev[m]) { okp_set_error("okp_fire_chain_forward: null module %d", m); return OKP_EINVAL; }
     if (sq->dtype != OKP_BF16 || ex->dtype != OKP_BF16 || sq->n_taps != 1 || ex->n_taps != 1 || sq->n_src != 1 || ex->n_src != 1) {
       okp_set_error("okp_fire_chain_forward: module %d: bf16 single-tap 1x1 plans expected", m); return OKP_EINVAL;
@@ -230,8 +258,10 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, const okp_conv* const* 
     if (sq->cin[0] != cin || sq->cout * 2 != cin || ex->cin[0] != sq->cout || ex->cout != sq->cout) {
       okp_set_error("okp_fire_chain_forward: module %d is not a %d -> %d -> %d fire module", m, cin, cin / 2, cin); return OKP_EINVAL;
     }
-    p.mod[m].w1 = sq->weights_dev; p.mod[m].w1_cout_pad = sq->cout_pad; p.mod[m].b1 = sq->bias_dev;
-    p.mod[m].wa = ex->weights_dev; p.mod[m].wa_cout_pad = ex->cout_pad; p.mod[m].ba = ex->bias_dev;
+    if (int e = okp_ensure_frags(sq, (hipStream_t)stream)) return e;
+    if (int e = okp_ensure_frags(ex, (hipStream_t)stream)) return e;
+    p.mod[m].w1 = sq->frag_dev; p.mod[m].w1_cout_pad = sq->cout_pad; p.mod[m].b1 = sq->bias_dev;
+    p.mod[m].wa = ex->frag_dev; p.mod[m].wa_cout_pad = ex->cout_pad; p.mod[m].ba = ex->bias_dev;
     p.mod[m].wd = dw_w_dev[m]; p.mod[m].bd = dw_bias_dev[m];
   }
   if (cin != 512) { okp_set_error("okp_fire_chain_forward: built for 512-channel chains (the innermost hourglass level), got %d", cin); return OKP_EINVAL; }

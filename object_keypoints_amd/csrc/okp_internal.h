@@ -115,6 +115,7 @@ struct okp_conv {
   uint32_t w_bytes;
   float* bias_dev;
   OkpSlice* slices_dev;
+  void* frag_dev;          // 1x1 plans used by okp_fire_chain: weights re-laid in MFMA-fragment order (built on first use)
 };
 
 void okp_set_error(const char* fmt, ...);
@@ -123,6 +124,7 @@ int okp_check_hip(hipError_t e, const char* what);
 // launchers implemented in the .hip files
 int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
+int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_chain.hip: fragment-order weight copy of a 1x1 plan
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream);
 int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip
