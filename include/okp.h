@@ -128,9 +128,10 @@ typedef struct okp_fire_args {
 int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const float* dw_w_dev, const float* dw_bias_dev,
                      const okp_fire_args* args, void* stream);
 
-/* A chain of up to OKP_FIRE_CHAIN_MAX consecutive stride-1 fire modules cin -> cin/2 -> cin with skip on maps of at
- * most 4 x 4 pixels, in ONE launch with the activations resident in LDS (one workgroup per frame): the six
- * fire_module(512, 512) of the innermost hourglass level (CornerNet_Squeeze.py:10-51, modules [2,2,2,2,4]).
+/* A chain of up to OKP_FIRE_CHAIN_MAX consecutive stride-1 fire modules cin -> cin/2 -> cin with skip, in ONE launch with
+ * the activations resident in LDS (one workgroup per frame): cin = 512 on maps of at most 4 x 4 pixels (the six
+ * fire_module(512, 512) of the innermost hourglass level, CornerNet_Squeeze.py:10-51, modules [2,2,2,2,4]) and cin = 384
+ * on maps of at most 8 x 8 pixels (the pairs of fire_module(384, 384) one level up).
  * Module m is given as for okp_fire_forward: squeeze[m], expand[m] plans, depth-wise weights / bias on the device. */
 #define OKP_FIRE_CHAIN_MAX 8
 int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv* const* expand,   /* plans gain a fragment-order weight copy on first use */

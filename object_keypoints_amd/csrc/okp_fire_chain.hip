@@ -24,30 +24,39 @@ namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int CIN>
+template <int CIN, int PXB>
 struct ChainCfg {
   static constexpr int MID = CIN / 2;
   static constexpr int NW = MID / 32;                  // waves
   static constexpr int NT = 64 * NW;
   static constexpr int KS1 = CIN / 32, KS2 = MID / 32;
+  static constexpr int NPX = 16 * PXB;                 // pixel rows of an activation buffer (map of at most NPX pixels)
+  static constexpr int SIDE = PXB == 1 ? 4 : 8;        // largest map side: 4x4 (one MFMA row block) or 8x8 (four)
+  static constexpr int SROWS = (SIDE + 2) * (SIDE + 2);
   static constexpr int XROW = CIN * 2;                 // bytes per pixel row of an activation buffer
   static constexpr int SROW = MID * 2;
-  static constexpr int OFF_X = 0;                      // two activation buffers [16][CIN]
-  static constexpr int OFF_S = 2 * 16 * XROW;          // squeeze tile [6 x 6 = 36 rows, zero halo][MID]
-  static constexpr int CONST_BYTES = 12 * MID * 4;    // per module: depth-wise weights [9][MID], bd, b1, ba (fp32)
-  static constexpr int OFF_C = OFF_S + 36 * SROW;      // two such blocks: the next module's constants arrive by LDS-DMA while this one runs
+  // 16-byte chunks per row are XOR-swizzled with the row inside groups of KEY+1 chunks: the group must divide the row
+  static constexpr int XKEY = (CIN / 8) % 16 == 0 ? 15 : 7;
+  static constexpr int SKEY = (MID / 8) % 16 == 0 ? 15 : 7;
+  static constexpr int OFF_X = 0;                      // two activation buffers [NPX][CIN]
+  static constexpr int OFF_S = 2 * NPX * XROW;         // squeeze tile [(SIDE+2)^2 rows, zero halo][MID]
+  // per module: depth-wise weights [9][MID], bd, b1, ba (fp32), every array padded to whole 1 KiB LDS-DMA instructions
+  static constexpr int WD_BYTES = (9 * MID * 4 + 1023) / 1024 * 1024, B_BYTES = (MID * 4 + 1023) / 1024 * 1024;
+  static constexpr int CONST_BYTES = WD_BYTES + 3 * B_BYTES;
+  static constexpr int OFF_C = OFF_S + SROWS * SROW;   // two such blocks: the next module's constants arrive by LDS-DMA while this one runs
   static constexpr int BYTES = OFF_C + 2 * CONST_BYTES;
-  static_assert((CIN / 8) % 16 == 0 && (MID / 8) % 16 == 0, "row swizzle needs whole 16-chunk groups");
+  static_assert((CIN / 8) % 8 == 0 && (MID / 8) % 8 == 0 && BYTES <= 160 * 1024, "row swizzle / LDS");
 };
 
-// 16-byte chunk c of row r, XOR-swizzled by the row (16 rows x 4 k-groups of a fragment read hit distinct banks)
-// (rows of 16 k chunks, k >= 1: the XOR stays inside a 16-chunk group)
-__device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & 15)) << 4); }
+// 16-byte chunk c of row r, XOR-swizzled by the row (the rows and k-groups of a fragment read hit distinct banks)
+template <int KEY>
+__device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & KEY)) << 4); }
 
-template <int CIN>
-__global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const OkpFireChainParams p) {
-  using C = ChainCfg<CIN>;
-  constexpr int MID = C::MID, NT = C::NT, KS1 = C::KS1, KS2 = C::KS2, XROW = C::XROW, SROW = C::SROW;
+template <int CIN, int PXB>
+__global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kernel(const OkpFireChainParams p) {
+  using C = ChainCfg<CIN, PXB>;
+  constexpr int MID = C::MID, NT = C::NT, KS1 = C::KS1, KS2 = C::KS2, XROW = C::XROW, SROW = C::SROW, NPX = C::NPX;
+  constexpr int XK = C::XKEY, SK = C::SKEY;
   constexpr int PF = 8;                                // weight fragments in flight ahead of the MFMAs
   __shared__ __attribute__((aligned(16))) char smem[C::BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -60,13 +69,13 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
   // frame -> LDS (buffer 0), squeeze tile cleared once: its halo stays zero for the whole chain
   {
     const char* src = static_cast<const char*>(p.x) + (size_t)n * HW * p.x_ps * 2;
-    for (int i = tid; i < 16 * (CIN / 8); i += NT) {
+    for (int i = tid; i < NPX * (CIN / 8); i += NT) {
       const int px = i / (CIN / 8), c = i % (CIN / 8);
       u32x4 v = {0u, 0u, 0u, 0u};
       if (px < HW) v = *reinterpret_cast<const u32x4*>(src + (size_t)px * p.x_ps * 2 + c * 16);
-      *reinterpret_cast<u32x4*>(smem + C::OFF_X + xoff(px, c, XROW)) = v;
+      *reinterpret_cast<u32x4*>(smem + C::OFF_X + xoff<XK>(px, c, XROW)) = v;
     }
-    for (int i = tid; i < 36 * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < C::SROWS * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   // interior pixel l16 -> squeeze-tile row (zero halo of one pixel around the H x W map, row pitch W + 2)
   const int SW = p.W + 2;
@@ -81,17 +90,18 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.bd), 0, MID * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.b1), 0, MID * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mod.ba), 0, MID * 4, 0x00020000);
-    // 12 * MID * 4 bytes = 12 KiB at MID = 256: instruction i covers bytes [1024 i, +1024); wave w takes i = w, w + NW, ...
-    for (int i = w; i < C::CONST_BYTES / 1024; i += C::NW) {
-      const int off = i * 1024;                         // wave-uniform: which array this KiB belongs to
-      lds_ptr_t d = (lds_ptr_t)(dst + off);
-      if (off < 9 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, d, 16, off + lane * 16, 0, 0, 0);
-      else if (off < 10 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, d, 16, off - 9 * MID * 4 + lane * 16, 0, 0, 0);
-      else if (off < 11 * MID * 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, d, 16, off - 10 * MID * 4 + lane * 16, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, d, 16, off - 11 * MID * 4 + lane * 16, 0, 0, 0);
-    }
+    // instruction i of an array covers its bytes [1024 i, +1024) (lanes beyond the array read zeros into the padding);
+    // the instructions of the four arrays are dealt round-robin over the waves
+    int k = 0;
+    for (int i = 0; i < C::WD_BYTES / 1024; ++i, ++k)
+      if (k % C::NW == w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
+    for (int i = 0; i < C::B_BYTES / 1024; ++i, ++k)
+      if (k % C::NW == w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(dst + C::WD_BYTES + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
+    for (int i = 0; i < C::B_BYTES / 1024; ++i, ++k)
+      if (k % C::NW == w) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(dst + C::WD_BYTES + C::B_BYTES + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
+    for (int i = 0; i < C::B_BYTES / 1024; ++i, ++k)
+      if (k % C::NW == w) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + C::WD_BYTES + 2 * C::B_BYTES + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
   };
-  static_assert((MID * 4) % 1024 == 0, "every constant array is a whole number of 1 KiB LDS-DMA instructions");
   fetch_consts(p.mod[0], 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -99,79 +109,105 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
   int cur = 0;
   for (int m = 0; m < p.n_modules; ++m) {
     const OkpFireChainModule mod = p.mod[m];
-    const float* cst = reinterpret_cast<const float*>(smem + C::OFF_C + (m & 1) * C::CONST_BYTES);
+    const float* cst = reinterpret_cast<const float*>(smem + C::OFF_C + (m & 1) * C::CONST_BYTES);   // [9][MID] depth-wise weights
+    const float* cbd = cst + C::WD_BYTES / 4;              // then bd, b1, ba
+    const float* cb1 = cbd + C::B_BYTES / 4;
+    const float* cba = cb1 + C::B_BYTES / 4;
     if (m + 1 < p.n_modules) fetch_consts(p.mod[m + 1], (m + 1) & 1);     // lands during this module; waited at its end
     // weights in fragment order [wave][block b][k-step][lane][16 B]: one load = 1 KiB contiguous per wave
     const u32x4* w1_lane = static_cast<const u32x4*>(mod.w1) + (size_t)w * 2 * KS1 * 64 + lane;
     const u32x4* wa_lane = static_cast<const u32x4*>(mod.wa) + (size_t)w * 2 * KS2 * 64 + lane;
     auto frag = [&](const u32x4* base, int ksteps, int ks, int b) { return base[(size_t)(b * ksteps + ks) * 64]; };
-    const int cg = tid % (MID / 8), dpx = tid / (MID / 8);   // depth-wise branch: 8-channel group, pixel
-    const char* xc = smem + C::OFF_X + cur * 16 * XROW;
-    char* xn = smem + C::OFF_X + (cur ^ 1) * 16 * XROW;
+    const int cg = tid % (MID / 8);                          // depth-wise branch: this thread's 8-channel group
+    const char* xc = smem + C::OFF_X + cur * NPX * XROW;
+    char* xn = smem + C::OFF_X + (cur ^ 1) * NPX * XROW;
 
-    // ---- squeeze: s[px][ch] for the 16 pixel rows, weights streamed PF k-steps ahead ------------------------------
+    // ---- squeeze: s[px][ch] for the NPX pixel rows, weights streamed PF k-steps ahead ------------------------------
     {
-      const float b0 = cst[10 * MID + ch0], b1 = cst[10 * MID + ch0 + 1];
-      f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+      const float b0 = cb1[ch0], b1 = cb1[ch0 + 1];
+      f32x4 acc0[PXB], acc1[PXB];
+#pragma unroll
+      for (int pb = 0; pb < PXB; ++pb) { acc0[pb] = f32x4{b0, b0, b0, b0}; acc1[pb] = f32x4{b1, b1, b1, b1}; }
       u32x4 wf[PF][2];
 #pragma unroll
       for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, KS1, i, 0); wf[i][1] = frag(w1_lane, KS1, i, 1); }
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(xc + xoff(l16, 4 * ks + q, XROW));
+        u32x4 a[PXB];
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(xc + xoff<XK>(16 * pb + l16, 4 * ks + q, XROW));
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
-      }
-      // accumulator register r is pixel 4 q + r; the channel pair is one dword of the squeeze tile's interior
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int px = 4 * q + r;
-        if (px < HW) {
-          bf16x2 v;
-          v[0] = (__bf16)acc0[r]; v[1] = (__bf16)acc1[r];
-          const int row = srow(px);
-          *reinterpret_cast<bf16x2*>(smem + C::OFF_S + xoff(row, (ch0 * 2) >> 4, SROW) + ((ch0 * 2) & 15)) = v;
+        for (int pb = 0; pb < PXB; ++pb) {
+          acc0[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc0[pb], 0, 0, 0);
+          acc1[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc1[pb], 0, 0, 0);
         }
       }
+      // accumulator register r of block pb is pixel 16 pb + 4 q + r; the channel pair is one dword of the squeeze tile's interior
+#pragma unroll
+      for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 16 * pb + 4 * q + r;
+          if (px < HW) {
+            bf16x2 v;
+            v[0] = (__bf16)acc0[pb][r]; v[1] = (__bf16)acc1[pb][r];
+            const int row = srow(px);
+            *reinterpret_cast<bf16x2*>(smem + C::OFF_S + xoff<SK>(row, (ch0 * 2) >> 4, SROW) + ((ch0 * 2) & 15)) = v;
+          }
+        }
     }
     __syncthreads();
 
     // ---- expand: y[:, :MID] = relu(Wa s + ba + x[:, :MID]) -> next activation buffer ----------------------------------
     {
-      const float b0 = cst[11 * MID + ch0], b1 = cst[11 * MID + ch0 + 1];
-      f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
-      const int arow = srow(l16 < HW ? l16 : 0);
-      u32x4 wf[PF][2];
+      const float b0 = cba[ch0], b1 = cba[ch0 + 1];
+      f32x4 acc0[PXB], acc1[PXB];
+      int arow[PXB];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(wa_lane, KS2, i, 0); wf[i][1] = frag(wa_lane, KS2, i, 1); }
+      for (int pb = 0; pb < PXB; ++pb) {
+        acc0[pb] = f32x4{b0, b0, b0, b0}; acc1[pb] = f32x4{b1, b1, b1, b1};
+        arow[pb] = srow(16 * pb + l16 < HW ? 16 * pb + l16 : 0);
+      }
+      u32x4 wf[PF][2];
+      constexpr int PF2 = PF < KS2 ? PF : KS2;
+#pragma unroll
+      for (int i = 0; i < PF2; ++i) { wf[i][0] = frag(wa_lane, KS2, i, 0); wf[i][1] = frag(wa_lane, KS2, i, 1); }
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff(arow, 4 * ks + q, SROW));
-        const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
-        if (ks + PF < KS2) { wf[ks % PF][0] = frag(wa_lane, KS2, ks + PF, 0); wf[ks % PF][1] = frag(wa_lane, KS2, ks + PF, 1); }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f0), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f1), acc1, 0, 0, 0);
+        u32x4 a[PXB];
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff<SK>(arow[pb], 4 * ks + q, SROW));
+        const u32x4 f0 = wf[ks % PF2][0], f1 = wf[ks % PF2][1];
+        if (ks + PF2 < KS2) { wf[ks % PF2][0] = frag(wa_lane, KS2, ks + PF2, 0); wf[ks % PF2][1] = frag(wa_lane, KS2, ks + PF2, 1); }
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) {
+          acc0[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc0[pb], 0, 0, 0);
+          acc1[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc1[pb], 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int px = 4 * q + r;
-        const uint32_t o = xoff(px, (ch0 * 2) >> 4, XROW) + ((ch0 * 2) & 15);
-        const bf16x2 xv = *reinterpret_cast<const bf16x2*>(xc + o);
-        bf16x2 v;
-        v[0] = (__bf16)fmaxf(acc0[r] + (float)xv[0], 0.f);
-        v[1] = (__bf16)fmaxf(acc1[r] + (float)xv[1], 0.f);
-        if (px >= HW) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; }
-        *reinterpret_cast<bf16x2*>(xn + o) = v;
-      }
+      for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 16 * pb + 4 * q + r;
+          const uint32_t o = xoff<XK>(px, (ch0 * 2) >> 4, XROW) + ((ch0 * 2) & 15);
+          const bf16x2 xv = *reinterpret_cast<const bf16x2*>(xc + o);
+          bf16x2 v;
+          v[0] = (__bf16)fmaxf(acc0[pb][r] + (float)xv[0], 0.f);
+          v[1] = (__bf16)fmaxf(acc1[pb][r] + (float)xv[1], 0.f);
+          if (px >= HW) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; }
+          *reinterpret_cast<bf16x2*>(xn + o) = v;
+        }
     }
 
     // ---- depth-wise: y[:, MID:] = relu(dw3x3(s) + bd + x[:, MID:]) -----------------------------------------------------
-    {
+    // thread = (8-channel group cg, pixel slot); NT / (MID / 8) = 16 pixel slots per pass
+    for (int dpx = tid / (MID / 8); dpx < NPX; dpx += 16) {
       float v[8];
       {
-        const f32x4 u0 = *reinterpret_cast<const f32x4*>(cst + 9 * MID + cg * 8), u1 = *reinterpret_cast<const f32x4*>(cst + 9 * MID + cg * 8 + 4);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(cbd + cg * 8), u1 = *reinterpret_cast<const f32x4*>(cbd + cg * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
       }
@@ -180,12 +216,12 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int row = (py + t / 3) * SW + pxx + t % 3;         // (py + 1 + dy) * SW + pxx + 1 + dx with dy, dx in -1..1
-        const bf16x8 sv = *reinterpret_cast<const bf16x8*>(smem + C::OFF_S + xoff(row, cg, SROW));
+        const bf16x8 sv = *reinterpret_cast<const bf16x8*>(smem + C::OFF_S + xoff<SK>(row, cg, SROW));
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8), w1 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = fmaf((float)sv[e], w0[e], v[e]); v[4 + e] = fmaf((float)sv[4 + e], w1[e], v[4 + e]); }
       }
-      const uint32_t o = xoff(dpx, (MID * 2) / 16 + cg, XROW);
+      const uint32_t o = xoff<XK>(dpx, (MID * 2) / 16 + cg, XROW);
       const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xc + o);
       bf16x8 out;
 #pragma unroll
@@ -199,11 +235,11 @@ __global__ __launch_bounds__(ChainCfg<CIN>::NT) void okp_fire_chain_kernel(const
 
   // result -> HBM
   {
-    const char* xc = smem + C::OFF_X + cur * 16 * XROW;
+    const char* xc = smem + C::OFF_X + cur * NPX * XROW;
     char* dst = static_cast<char*>(p.out) + (size_t)n * HW * p.out_ps * 2;
     for (int i = tid; i < HW * (CIN / 8); i += NT) {
       const int px = i / (CIN / 8), c = i % (CIN / 8);
-      *reinterpret_cast<u32x4*>(dst + (size_t)px * p.out_ps * 2 + c * 16) = *reinterpret_cast<const u32x4*>(xc + xoff(px, c, XROW));
+      *reinterpret_cast<u32x4*>(dst + (size_t)px * p.out_ps * 2 + c * 16) = *reinterpret_cast<const u32x4*>(xc + xoff<XK>(px, c, XROW));
     }
   }
 }
@@ -264,8 +300,12 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
     p.mod[m].wa = ex->frag_dev; p.mod[m].wa_cout_pad = ex->cout_pad; p.mod[m].ba = ex->bias_dev;
     p.mod[m].wd = dw_w_dev[m]; p.mod[m].bd = dw_bias_dev[m];
   }
-  if (cin != 512) { okp_set_error("okp_fire_chain_forward: built for 512-channel chains (the innermost hourglass level), got %d", cin); return OKP_EINVAL; }
-  if (x->h != out->h || x->w != out->w || x->h > 4 || x->w > 4 || x->h < 1 || x->w < 1) { okp_set_error("okp_fire_chain_forward: maps of at most 4 x 4 pixels, same size in and out"); return OKP_EINVAL; }
+  const bool small = x->h <= 4 && x->w <= 4;
+  if (!((cin == 512 && small) || (cin == 384 && x->h <= 8 && x->w <= 8))) {
+    okp_set_error("okp_fire_chain_forward: built for 512-channel chains on <= 4x4 maps and 384-channel chains on <= 8x8 maps (got %d channels, %dx%d)", cin, x->h, x->w);
+    return OKP_EINVAL;
+  }
+  if (x->h != out->h || x->w != out->w || x->h < 1 || x->w < 1) { okp_set_error("okp_fire_chain_forward: same map size in and out"); return OKP_EINVAL; }
   if (x->pix_stride < cin || out->pix_stride < cin || x->pix_stride % 8 || out->pix_stride % 8 || ((uintptr_t)x->data) % 16 || ((uintptr_t)out->data) % 16) {
     okp_set_error("okp_fire_chain_forward: views must be 16-byte aligned with >= %d channels", cin); return OKP_EINVAL;
   }
@@ -274,6 +314,8 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
     okp_set_error("okp_fire_chain_forward: views too small for %d frames", n); return OKP_EINVAL;
   }
   p.n_modules = n_modules; p.x = x->data; p.out = out->data; p.x_ps = x->pix_stride; p.out_ps = out->pix_stride; p.H = x->h; p.W = x->w;
-  hipLaunchKernelGGL((okp_fire_chain_kernel<512>), dim3(n), dim3(ChainCfg<512>::NT), 0, (hipStream_t)stream, p);
+  if (cin == 512) hipLaunchKernelGGL((okp_fire_chain_kernel<512, 1>), dim3(n), dim3(ChainCfg<512, 1>::NT), 0, (hipStream_t)stream, p);
+  else if (small) hipLaunchKernelGGL((okp_fire_chain_kernel<384, 1>), dim3(n), dim3(ChainCfg<384, 1>::NT), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((okp_fire_chain_kernel<384, 4>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_fire_chain launch");
 }

@@ -255,18 +255,23 @@ def make_unpool_layer(dim):
 
 def run_fire_modules(mods, x):
     """Apply consecutive fire modules.  Runs of stride-1 fire(512, 512) modules on maps of at most 4 x 4 pixels (the
-    innermost hourglass level: six in a row) go through ONE resident launch (ops.fire_chain / okp_fire_chain_forward)."""
+    innermost hourglass level: six in a row) and of fire(384, 384) modules on maps of at most 8 x 8 pixels go through
+    ONE resident launch (ops.fire_chain / okp_fire_chain_forward)."""
     mods = list(mods)
+
+    def chainable(m, x):
+        if not (ops.FUSE_FIRE_CHAIN and x.dtype == torch.bfloat16 and m.stride == 1 and m.skip and m.inp_dim == m.out_dim):
+            return False
+        return (m.inp_dim == 512 and x.h <= 4 and x.w <= 4) or (m.inp_dim == 384 and x.h <= 8 and x.w <= 8)
+
     i = 0
     while i < len(mods):
         j = i
-        if ops.FUSE_FIRE_CHAIN and x.dtype == torch.bfloat16 and x.h <= 4 and x.w <= 4:
-            while (j < len(mods) and j - i < ops.FIRE_CHAIN_MAX and mods[j].stride == 1 and mods[j].skip
-                   and mods[j].inp_dim == 512 and mods[j].out_dim == 512):
-                j += 1
+        while j < len(mods) and j - i < ops.FIRE_CHAIN_MAX and chainable(mods[j], x) and mods[j].inp_dim == mods[i].inp_dim:
+            j += 1
         if j - i >= 2:
             plans = [m._plan(("p", x.dtype), lambda m=m: m._build(x.dtype, x.t.device)) for m in mods[i:j]]
-            out = Act.empty(x.n, x.h, x.w, 512, x.dtype, x.t.device)
+            out = Act.empty(x.n, x.h, x.w, mods[i].out_dim, x.dtype, x.t.device)
             ops.fire_chain(plans, x, out)
             x = out
             i = j

@@ -263,21 +263,22 @@ def test_stem_kernel_rejects_bad_views():
         ops.StemPlan(np.zeros((64, 3, 7, 7), np.float32), np.zeros(64, np.float32))
 
 
-@pytest.mark.parametrize("h,w,n,count", [(4, 4, 5, 6), (3, 4, 2, 2), (2, 2, 3, 8), (1, 3, 1, 3)])
-def test_fire_chain_matches_module_by_module(h, w, n, count):
+@pytest.mark.parametrize("c,h,w,n,count", [(512, 4, 4, 5, 6), (512, 3, 4, 2, 2), (512, 2, 2, 3, 8), (512, 1, 3, 1, 3),
+                                             (384, 8, 8, 3, 2), (384, 7, 5, 2, 3), (384, 4, 4, 2, 2), (384, 8, 3, 1, 4)])
+def test_fire_chain_matches_module_by_module(c, h, w, n, count):
     """okp_fire_chain_forward (activations resident in LDS across `count` fire(512, 512) modules) against the oracle's
     modules applied one by one (fp32) and against the product's own module-by-module path."""
     from object_keypoints_amd import ops
     from object_keypoints_amd.perception import backbone as bb
     from oracle import net as onet
     dev = _dev()
-    omods = [onet.load_synthetic(onet.fire_module(512, 512), seed=30 + i) for i in range(count)]
+    omods = [onet.load_synthetic(onet.fire_module(c, c), seed=30 + i) for i in range(count)]
     mods = []
     for o in omods:
-        m = bb.fire_module(512, 512)
+        m = bb.fire_module(c, c)
         m.load_state_dict(o.state_dict())
         mods.append(m.eval())
-    x = _rand((n, 512, h, w), 77).bfloat16().float()
+    x = _rand((n, c, h, w), 77).bfloat16().float()
     ref = x
     with torch.no_grad():
         for o in omods:
