@@ -202,7 +202,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: batch={args.batch}/GPU synthetic 511x511 frames, {args.dtype} activations+weights, fp32 accumulate, "
-                               "CornerNet-Squeeze K=3 (valve) random-init procedural weights; pack -> hourglass+heads -> peak-NMS -> depth lifting -> object grouping"
+                               "CornerNet-Squeeze K=3 (valve) random-init procedural weights; fp32 NCHW frames -> stem -> hourglass+heads -> peak-NMS -> depth lifting -> object grouping"
                                + (" -> all-gather of 3D keypoints" if world > 1 else ""),
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
         "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,

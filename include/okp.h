@@ -184,6 +184,9 @@ typedef struct okp_stem okp_stem;
 okp_stem* okp_stem_create(const float* w_host, const float* bias_host);
 void okp_stem_destroy(okp_stem* stem);
 int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream);
+/* Same layer straight from the reference's input layout, fp32 NCHW frames (n,3,h,w): the bf16 rounding and the zero
+ * padding happen while the input patch is staged in LDS, so okp_pack_frames and its round trip through HBM are not needed. */
+int okp_stem_forward_nchw(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Final 1x1 convolutions of the three heads, NHWC -> NCHW fp32, optional sigmoid per output.

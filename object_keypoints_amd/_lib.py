@@ -73,6 +73,7 @@ SIGNATURES = [
     ("okp_stem_create", c_void_p, [POINTER(c_float), POINTER(c_float)]),
     ("okp_stem_destroy", None, [c_void_p]),
     ("okp_stem_forward", c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),
+    ("okp_stem_forward_nchw", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(okp_tensor), c_void_p]),
     ("okp_head_out_forward", c_int, [c_int, POINTER(okp_head_out_args), c_void_p]),
     ("okp_peak_nms", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("okp_nms_maxpool", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -40,9 +40,9 @@ constexpr int KSTEPS = 14;
 constexpr uint32_t kInvalidOff = 0x80000000u;
 
 struct StemParams {
-  const void* src;          // packed frames [N][Hp][Wp][4] bf16
+  const void* src;          // packed frames [N][Hp][Wp][4] bf16, or fp32 frames [N][3][H][W]
   uint32_t src_bytes;
-  int32_t Hp, Wp;
+  int32_t Hp, Wp, H, W;
   const void* wfrag;        // [wc 2][block 2][k-step 14][lane 64][16 B]  B-operand fragments
   const float* bias;        // [128], natural channel order
   void* out;
@@ -59,7 +59,10 @@ __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
 }
 
-__global__ __launch_bounds__(256) void okp_stem_kernel(const StemParams p) {
+// NCHW = true: the patch is read straight from the caller's fp32 NCHW frames (zero padding by range checks), rounded to
+// bf16 and written to LDS by the threads themselves - the packing pass (okp_pack_frames) and its 138 MB round trip go away.
+template <bool NCHW>
+__global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,16 +116,53 @@ __global__ __launch_bounds__(256) void okp_stem_kernel(const StemParams p) {
     }
   };
 
+  // fp32 NCHW source: thread t owns patch pixels t, t + 256, ... (row-major over the 21 x 70 patch), three planes each
+  constexpr int PPT = (PR * PC + 255) / 256;                // 6 pixels per thread
+  float pv[NCHW ? PPT : 1][3];
+  auto load_patch = [&](int tile) {
+    if constexpr (NCHW) {
+      int n, oy0, ox0;
+      tile_coords(tile, n, oy0, ox0);
+      const uint32_t plane = (uint32_t)p.H * (uint32_t)p.W * 4u;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / PC, col = idx - row * PC;
+        const int y = 2 * oy0 - 3 + row, x = 2 * ox0 - 3 + col;
+        const bool ok = idx < PR * PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const uint32_t off = ok ? ((uint32_t)(n * 3) * (uint32_t)p.H + (uint32_t)y) * (uint32_t)p.W * 4u + (uint32_t)x * 4u : kInvalidOff;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(ok ? off + (uint32_t)c * plane : kInvalidOff), 0, 0));
+      }
+    }
+  };
+  auto store_patch = [&](int buf) {
+    if constexpr (NCHW) {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < PATCH_BYTES / 8) {
+          typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+          bf16x4v o;
+          o[0] = (__bf16)pv[i][0]; o[1] = (__bf16)pv[i][1]; o[2] = (__bf16)pv[i][2]; o[3] = (__bf16)0.f;
+          *reinterpret_cast<bf16x4v*>(smem + buf * PATCH_BYTES + idx * 8) = o;
+        }
+      }
+    }
+  };
+
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
-  issue_patch(tile, 0);
+  if constexpr (NCHW) { load_patch(tile); store_patch(0); }
+  else issue_patch(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int buf = 0;
   for (; tile < p.n_tiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
-    if (next < p.n_tiles) issue_patch(next, buf ^ 1);
+    if (next < p.n_tiles) { if constexpr (NCHW) load_patch(next); else issue_patch(next, buf ^ 1); }
     int n, oy0, ox0;
     tile_coords(tile, n, oy0, ox0);
     const char* patch = smem + buf * PATCH_BYTES;
@@ -169,6 +209,7 @@ __global__ __launch_bounds__(256) void okp_stem_kernel(const StemParams p) {
         }
       }
     }
+    if constexpr (NCHW) { if (next < p.n_tiles) store_patch(buf ^ 1); }     // (its loads were waited for with the stores above)
     __syncthreads();            // every wave's part of the next patch is in LDS; this patch is free
     buf ^= 1;
   }
@@ -253,6 +294,34 @@ extern "C" int okp_stem_forward(const okp_stem* st, int32_t n, int32_t h, int32_
   p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   const int resident = 256 * 2;        // two workgroups per CU: one computes while the other's stores drain
   const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  hipLaunchKernelGGL(okp_stem_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(okp_stem_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_stem launch");
+}
+
+extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream) {
+  if (!st || !frames_nchw_dev || !out || !out->data) { okp_set_error("okp_stem_forward_nchw: null argument"); return OKP_EINVAL; }
+  if (n < 1 || h < 1 || w < 1) { okp_set_error("okp_stem_forward_nchw: empty problem"); return OKP_EINVAL; }
+  const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
+  const int64_t src_bytes = (int64_t)n * 3 * h * w * 4;
+  if (src_bytes >= 0x7FFF0000ll || out->bytes <= 0 || out->bytes >= 0x7FFF0000ll) { okp_set_error("okp_stem_forward_nchw: views must be < 2 GiB (sub-batch the frames)"); return OKP_EINVAL; }
+  if (out->h != ho || out->w != wo || out->pix_stride < kCout || (out->pix_stride * 2) % 64 || ((uintptr_t)out->data) % 64 || ((uintptr_t)frames_nchw_dev) % 4) {
+    okp_set_error("okp_stem_forward_nchw: out must be %dx%d with 64-byte aligned pixels of >= 128 channels", ho, wo);
+    return OKP_EINVAL;
+  }
+  if ((int64_t)n * ho * wo * out->pix_stride * 2 > out->bytes + (int64_t)(out->pix_stride - kCout) * 2) { okp_set_error("okp_stem_forward_nchw: out view too small"); return OKP_EINVAL; }
+  StemParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.src = frames_nchw_dev; p.src_bytes = (uint32_t)src_bytes; p.H = h; p.W = w;
+  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev;
+  p.out = out->data; p.out_bytes = (uint32_t)out->bytes; p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
+  p.tiles_x = (wo + TW - 1) / TW; p.tiles_y = (ho + TH - 1) / TH;
+  const long tiles = (long)n * p.tiles_x * p.tiles_y;
+  if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_stem_forward_nchw: too many tiles"); return OKP_EINVAL; }
+  p.n_tiles = (int)tiles;
+  p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_x * p.tiles_y));
+  p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
+  const int resident = 256 * 2;
+  const int grid = p.n_tiles < resident ? p.n_tiles : resident;
+  hipLaunchKernelGGL(okp_stem_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
 }

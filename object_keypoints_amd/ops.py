@@ -267,6 +267,18 @@ class StemPlan:
         except Exception:
             pass
 
+    def from_nchw(self, frames, out):
+        """frames: fp32 NCHW [N,3,H,W] on the device (the reference's input layout); no packing pass."""
+        require_cuda(frames, "frames")
+        if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3 or out.dtype != torch.bfloat16:
+            raise OkpError("frames must be float32 [N,3,H,W] and the output bf16")
+        frames = frames.contiguous()
+        n, _, h, w = frames.shape
+        ov = out.view()
+        _lib.check(_lib.lib().okp_stem_forward_nchw(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw")
+        COUNTERS["macs"] += out.n * out.h * out.w * 128 * 147
+        COUNTERS["launches"] += 1
+
     def __call__(self, packed, out):
         if packed.orig_hw is None or packed.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
             raise OkpError("stem input must be the bf16 output of ops.pack_frames")

@@ -25,6 +25,7 @@ from ..ops import Act, ConvPlan, OkpError, StemPlan
 # ------------------------------------------------------------------------------------------
 
 import os
+STEM_DIRECT = os.environ.get("OKP_STEM_DIRECT", "1") != "0"     # bf16: the stem kernel reads fp32 NCHW frames itself (no pack launch)
 STEM_KERNEL = os.environ.get("OKP_STEM_KERNEL", "1") != "0"     # bf16: dedicated stem kernel (okp_stem.hip); 0 = generic tap-list kernel
 UNPOOL_TILE = int(os.environ.get("OKP_UNPOOL_TILE", "0"))   # experiments: tile code of the transposed-conv launches (0 = heuristic)
 STEM_TILE = int(os.environ.get("OKP_STEM_TILE", "4"))      # 7x7/s2 stem: 128 co x 256 px tile measured fastest (603 vs 728 us)
@@ -105,6 +106,17 @@ class convolution(_HipModule):
                 taps.append((0, r, 0, m.reshape(self.out_dim, 32)))
             return ConvPlan(dtype, [32], [2], self.out_dim, taps, b, relu=True, alg_k=147)
         return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
+
+    def forward_frames(self, frames, dtype):
+        """The stem on raw fp32 NCHW frames.  bf16: one launch of the dedicated kernel reading the frames directly;
+        otherwise pack (ops.pack_frames) + the generic path."""
+        if self.inp_dim == 3 and dtype == torch.bfloat16 and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
+            plan = self._plan(("p", dtype), lambda: self._build(dtype))
+            n, _, h, w = frames.shape
+            out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
+            plan.from_nchw(frames, out)
+            return out
+        return self.forward(ops.pack_frames(frames, dtype))
 
     def forward(self, x):
         plan = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
@@ -367,10 +379,15 @@ class hg(_HipModule):
         taps = [(0, 0, 0, np.ascontiguousarray(wa[:, :, 0, 0])), (1, 0, 0, np.ascontiguousarray(wb[:, :, 0, 0]))]
         return ConvPlan(dtype, [256, 256], [1, 1], 256, taps, ba + bb, relu=True)
 
-    def forward(self, x):
-        """x: packed frames (ops.pack_frames).  Returns [cnv0, cnv1] as NHWC activations."""
-        inter = x
-        for m in self.pre:
+    def forward(self, x, dtype=None):
+        """x: packed frames (ops.pack_frames), or raw fp32 NCHW frames with the compute dtype given (the stem then reads
+        them itself where it can).  Returns [cnv0, cnv1] as NHWC activations."""
+        if isinstance(x, torch.Tensor):
+            inter = self.pre[0].forward_frames(x, dtype)
+            rest = list(self.pre)[1:]
+        else:
+            inter, rest = x, list(self.pre)
+        for m in rest:
             inter = m(inter)
         cnvs = []
         last = len(self.hgs) - 1

@@ -139,7 +139,7 @@ class KeypointNet(_HipModule):
             if self.raw_frame_size is not None and tuple(x.shape[1:3]) != (self.raw_frame_size, self.raw_frame_size):
                 return self.backbone(ops.preprocess_u8(x, self.compute_dtype, size=self.raw_frame_size))
             return self.backbone(ops.pack_frames_u8(x, self.compute_dtype))
-        return self.backbone(ops.pack_frames(x.float(), self.compute_dtype))
+        return self.backbone(x.float(), self.compute_dtype)
 
     def max_frames_per_pass(self, h, w):
         """Frames per launch sequence such that the largest activation (the stem output, 128 channels at half

@@ -248,6 +248,11 @@ def test_stem_kernel_matches_torch(n, h, w):
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err <= _tol(torch.bfloat16, ref), f"max err {err}"
+    # the variant that reads the fp32 NCHW frames itself (no packing pass) produces the same bits
+    out2 = ops.Act.empty(n, ho, wo, 128, torch.bfloat16, dev)
+    out2.t.fill_(float("nan"))
+    plan.from_nchw(x.to(dev), out2)
+    assert torch.equal(out2.t, out.t)
 
 
 def test_stem_kernel_rejects_bad_views():
