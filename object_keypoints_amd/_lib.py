@@ -75,6 +75,7 @@ SIGNATURES = [
     ("okp_stem_forward", c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),
     ("okp_stem_forward_nchw", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(okp_tensor), c_void_p]),
     ("okp_head_out_forward", c_int, [c_int, POINTER(okp_head_out_args), c_void_p]),
+    ("okp_heads_forward", c_int, [c_void_p, c_void_p, POINTER(okp_head_out_args), POINTER(okp_tensor), c_void_p]),
     ("okp_peak_nms", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("okp_nms_maxpool", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_unproject_depth", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -1,0 +1,200 @@
+// The three prediction heads of one stack in ONE launch (bf16, features = 128, gfx950):
+//
+//   per head h (heat, depth, centre):   h1 = relu(W1_h x + b1_h)        1x1 + BN + ReLU   256 -> 128
+//                                       h2 = relu(W2_h h1 + b2_h)       1x1 + BN + ReLU   128 -> 32
+//                                       out_o = act(w3_o . h2 + b3_o)   1x1 + bias        32 -> K (or 2 (K-1)), NCHW fp32
+//
+// Replaces prediction_module (perception/models.py:13-18) x 3 + the deployed wrapper's sigmoid
+// (scripts/package_model.py:28).  As three launches (a 256 -> 384 GEMM, a block-diagonal 384 -> 96 GEMM and the
+// pointwise output kernel) the 384- and 96-channel intermediates make a round trip through HBM (201 + 50 MB written
+// and read per 64 frames against 134 MB of input); here they live in LDS.
+//
+// A workgroup (4 waves) owns 64 consecutive pixels.  Its x tile (64 x 512 B) is fetched once by LDS-DMA; per head,
+// GEMM 1 runs on 16x16x32 MFMAs with pixels as rows and wave w owning channels [32 w, 32 w + 32) of the head (weight
+// fragments streamed from the fragment-ordered copy of the plan, okp_ensure_frags), the result goes to LDS as bf16;
+// GEMM 2 (K = 128, 32 output channels) gives each wave one 16-pixel block; the last layer is a 32-term dot product per
+// (pixel, output) on the vector ALUs with pixels along the lanes, so the NCHW stores are contiguous.
+#include <cstring>
+
+#include "okp_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr uint32_t kInvalid = 0x80000000u;
+
+constexpr int TP = 64;                    // pixels per tile
+constexpr int CIN = 256, F = 128, F2 = 32;
+constexpr int KS1 = CIN / 32, KS2 = F / 32;
+constexpr int OFF_X = 0;                  // [64][512 B], 16-byte chunks XOR-swizzled by row & 15
+constexpr int OFF_H1 = OFF_X + TP * CIN * 2;     // [64][256 B]
+constexpr int H2_PITCH = F2 + 1;          // floats per row: odd pitch, so that a column walk over pixels is conflict-free
+constexpr int OFF_H2 = OFF_H1 + TP * F * 2;      // [64][33] fp32
+constexpr int OFF_W3 = OFF_H2 + TP * H2_PITCH * 4;   // [n_out][32] fp32, then [n_out] bias
+constexpr int LDS_BYTES = OFF_W3 + OKP_HEAD_MAX_OUT * 33 * 4;
+
+struct HeadsParams {
+  const void* x; uint32_t x_bytes; int32_t x_ps;
+  long n_pix;                             // N * H * W
+  int32_t HW;
+  const void* w1; const float* b1;        // fragment-ordered 256 -> 384 weights: [12 waves][2][8][64][16 B]; bias [384]
+  const void* w2; const float* b2;        // fragment-ordered 384 -> 96 (block diagonal): [3][2][12][64][16 B]; bias [96]
+  const float* w3; const float* b3;       // [n_out][32], [n_out]
+  int32_t n_out;
+  int32_t head_of[OKP_HEAD_MAX_OUT];      // which head (0..2) output o reads
+  int32_t act[OKP_HEAD_MAX_OUT];
+  float* out_ptr[OKP_HEAD_MAX_OUT];
+  int64_t out_n_stride[OKP_HEAD_MAX_OUT];
+  int32_t n_tiles;
+};
+
+__device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & 15)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  float* const h2 = reinterpret_cast<float*>(smem + OFF_H2);
+  float* const w3s = reinterpret_cast<float*>(smem + OFF_W3);
+  for (int i = tid; i < p.n_out * 33; i += 256) w3s[i] = i < p.n_out * 32 ? p.w3[i] : p.b3[i - p.n_out * 32];
+  const int ch0 = 32 * w + 2 * l16;                 // this lane's channel pair inside a head (GEMM 1)
+  // LDS-DMA of the x tile: instruction i of this wave covers linear bytes [1024 (8 w + i), +1024) = two 512-byte rows
+  int d_row[8];
+  uint32_t d_chunk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lin = (8 * w + i) * 64 + lane;        // 16-byte position in the tile
+    d_row[i] = lin >> 5;
+    d_chunk[i] = (uint32_t)(((lin & 31) ^ (d_row[i] & 15)) << 4);      // the chunk the read-side swizzle expects there
+  }
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const long pix0 = (long)tile * TP;
+    __syncthreads();                                // the previous tile's readers of x / h2 are done; w3 is in LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long pix = pix0 + d_row[i];
+      const uint32_t off = pix < p.n_pix ? (uint32_t)pix * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + OFF_X + (8 * w + i) * 1024), 16, (int)off, 0, 0, 0);
+    }
+    // head 0's first weight fragments travel with the x tile
+    constexpr int PF = 4;
+    auto frag1 = [&](int h, int ks, int b) { return static_cast<const u32x4*>(p.w1)[(size_t)(((4 * h + w) * 2 + b) * KS1 + ks) * 64 + lane]; };
+    auto frag2 = [&](int h, int kk, int b) { return static_cast<const u32x4*>(p.w2)[(size_t)((h * 2 + b) * (3 * KS2) + KS2 * h + kk) * 64 + lane]; };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll 1
+    for (int h = 0; h < 3; ++h) {
+      // ---- GEMM 1: h1[64 px][128] = relu(W1_h x + b1_h) ------------------------------------------------------
+      {
+        const float b0 = p.b1[F * h + ch0], b1 = p.b1[F * h + ch0 + 1];
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) { acc[pb][0] = f32x4{b0, b0, b0, b0}; acc[pb][1] = f32x4{b1, b1, b1, b1}; }
+        u32x4 wf[PF][2];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { wf[i][0] = frag1(h, i, 0); wf[i][1] = frag1(h, i, 1); }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          u32x4 a[4];
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + OFF_X + xoff(16 * pb + l16, 4 * ks + q, CIN * 2));
+          const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
+          if (ks + PF < KS1) { wf[ks % PF][0] = frag1(h, ks + PF, 0); wf[ks % PF][1] = frag1(h, ks + PF, 1); }
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) {
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc[pb][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bf16x2 v;
+            v[0] = (__bf16)fmaxf(acc[pb][0][r], 0.f); v[1] = (__bf16)fmaxf(acc[pb][1][r], 0.f);
+            const int px = 16 * pb + 4 * q + r;
+            *reinterpret_cast<bf16x2*>(smem + OFF_H1 + xoff(px, (ch0 * 2) >> 4, F * 2) + ((ch0 * 2) & 15)) = v;
+          }
+      }
+      __syncthreads();
+      // ---- GEMM 2: h2[64 px][32] = relu(W2_h h1 + b2_h); wave w takes pixel block w ---------------------------------
+      {
+        const float b0 = p.b2[F2 * h + 2 * l16], b1 = p.b2[F2 * h + 2 * l16 + 1];
+        f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+#pragma unroll
+        for (int kk = 0; kk < KS2; ++kk) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_H1 + xoff(16 * w + l16, 4 * kk + q, F * 2));
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, frag2(h, kk, 0)), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, frag2(h, kk, 1)), acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 16 * w + 4 * q + r;
+          // rounded to bf16 like the stored activation of the unfused path, kept as fp32 for the dot products
+          h2[px * H2_PITCH + 2 * l16] = (float)(__bf16)fmaxf(acc0[r], 0.f);
+          h2[px * H2_PITCH + 2 * l16 + 1] = (float)(__bf16)fmaxf(acc1[r], 0.f);
+        }
+      }
+      __syncthreads();
+      // ---- last layer: out_o = act(w3_o . h2 + b3_o) for the outputs of this head; lanes along the pixels -------------
+      {
+        const int px = tid & 63, slot = tid >> 6;
+        const long pix = pix0 + px;
+        int seen = 0;
+        for (int o = 0; o < p.n_out; ++o) {
+          if (p.head_of[o] != h) continue;
+          if ((seen++ & 3) != slot) continue;          // the head's outputs are dealt round-robin over the four waves
+          float acc = w3s[p.n_out * 32 + o];
+#pragma unroll
+          for (int c = 0; c < F2; ++c) acc = fmaf(h2[px * H2_PITCH + c], w3s[o * 32 + c], acc);
+          if (p.act[o] == OKP_ACT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
+          else if (p.act[o] == OKP_ACT_RELU) acc = fmaxf(acc, 0.f);
+          if (pix < p.n_pix) {
+            const long n = pix / p.HW;
+            p.out_ptr[o][(size_t)n * p.out_n_stride[o] + (size_t)(pix - n * p.HW)] = acc;
+          }
+        }
+      }
+      // (the next head's GEMM 1 writes h1 only: its readers, GEMM 2 above, are behind the barrier that follows GEMM 2;
+      //  h2 is rewritten after the next two barriers)
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const okp_head_out_args* a, const okp_tensor* x, void* stream) {
+  if (!l1 || !l2 || !a || !x || !x->data || !a->w_dev || !a->bias_dev) { okp_set_error("okp_heads_forward: null argument"); return OKP_EINVAL; }
+  if (l1->dtype != OKP_BF16 || l2->dtype != OKP_BF16 || l1->n_taps != 1 || l2->n_taps != 1 || l1->cin[0] != CIN || l1->cout != 3 * F ||
+      l2->cin[0] != 3 * F || l2->cout != 3 * F2) {
+    okp_set_error("okp_heads_forward: expects bf16 1x1 plans 256 -> 384 and 384 -> 96 (three heads of 128 features)"); return OKP_EINVAL;
+  }
+  if (a->n_out < 1 || a->n_out > OKP_HEAD_MAX_OUT) { okp_set_error("okp_heads_forward: n_out %d out of range", a->n_out); return OKP_EINVAL; }
+  if (a->n < 1 || a->h < 1 || a->w < 1) return OKP_OK;
+  if (x->pix_stride < CIN || x->pix_stride % 8 || ((uintptr_t)x->data) % 16 || x->bytes <= 0 || x->bytes >= 0x7FFF0000ll) {
+    okp_set_error("okp_heads_forward: x must be a 16-byte aligned view of >= 256 channels, < 2 GiB"); return OKP_EINVAL;
+  }
+  if (int e = okp_ensure_frags(l1, (hipStream_t)stream)) return e;
+  if (int e = okp_ensure_frags(l2, (hipStream_t)stream)) return e;
+  HeadsParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.x = x->data; p.x_bytes = (uint32_t)x->bytes; p.x_ps = x->pix_stride;
+  p.HW = a->h * a->w; p.n_pix = (long)a->n * p.HW;
+  p.w1 = l1->frag_dev; p.b1 = l1->bias_dev; p.w2 = l2->frag_dev; p.b2 = l2->bias_dev;
+  p.w3 = a->w_dev; p.b3 = a->bias_dev; p.n_out = a->n_out;
+  for (int o = 0; o < a->n_out; ++o) {
+    if (a->in_c_off[o] % F2 || a->in_c_off[o] < 0 || a->in_c_off[o] >= 3 * F2 || !a->out_ptr[o]) { okp_set_error("okp_heads_forward: output %d: bad channel offset or null pointer", o); return OKP_EINVAL; }
+    p.head_of[o] = a->in_c_off[o] / F2; p.act[o] = a->act[o]; p.out_ptr[o] = a->out_ptr[o]; p.out_n_stride[o] = a->out_n_stride[o];
+  }
+  const long tiles = (p.n_pix + TP - 1) / TP;
+  if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_heads_forward: too many pixels"); return OKP_EINVAL; }
+  p.n_tiles = (int)tiles;
+  const int resident = 256 * 2;
+  hipLaunchKernelGGL(okp_heads_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(256), 0, (hipStream_t)stream, p);
+  return okp_check_hip(hipGetLastError(), "okp_heads launch");
+}

@@ -342,11 +342,9 @@ def preprocess_u8(frames, dtype, size=511, mean=RGB_MEAN, std=RGB_STD):
     return act
 
 
-def head_out(src, outputs, w_dev, bias_dev):
-    """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
+def _head_out_args(n, h, w, outputs, w_dev, bias_dev):
     a = _lib.okp_head_out_args()
-    a.n, a.h, a.w = src.n, src.h, src.w
-    a.src = src.view()
+    a.n, a.h, a.w = n, h, w
     a.n_out = len(outputs)
     for i, (off, act, t, ch) in enumerate(outputs):
         a.in_c_off[i] = off
@@ -354,8 +352,27 @@ def head_out(src, outputs, w_dev, bias_dev):
         a.out_ptr[i] = t.data_ptr() + ch * t.shape[2] * t.shape[3] * 4
         a.out_n_stride[i] = t.shape[1] * t.shape[2] * t.shape[3]
     a.w_dev, a.bias_dev = w_dev.data_ptr(), bias_dev.data_ptr()
+    return a
+
+
+def head_out(src, outputs, w_dev, bias_dev):
+    """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
+    a = _head_out_args(src.n, src.h, src.w, outputs, w_dev, bias_dev)
+    a.src = src.view()
     _lib.check(_lib.lib().okp_head_out_forward(okp_dtype(src.dtype), ctypes.byref(a), stream_handle()), "okp_head_out_forward")
     COUNTERS["macs"] += src.n * src.h * src.w * 32 * len(outputs)
+    COUNTERS["launches"] += 1
+
+
+FUSE_HEADS = os.environ.get("OKP_FUSE_HEADS", "1") == "1"    # bf16, 128 features: the three heads of a stack in one launch
+
+
+def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):
+    """The three prediction heads in one launch (okp_heads_forward): l1 256 -> 384, l2 block-diagonal 384 -> 96 plans."""
+    a = _head_out_args(x.n, x.h, x.w, outputs, w_dev, bias_dev)
+    xv = x.view()
+    _lib.check(_lib.lib().okp_heads_forward(l1._h, l2._h, ctypes.byref(a), ctypes.byref(xv), stream_handle()), "okp_heads_forward")
+    COUNTERS["macs"] += x.n * x.h * x.w * (l1.cout * l1.alg_k + l2.cout * l2.alg_k + 32 * len(outputs))
     COUNTERS["launches"] += 1
 
 

@@ -118,17 +118,20 @@ class KeypointNet(_HipModule):
         l1, l2, w3, b3 = self._plan(("heads", stack, cnv.dtype), lambda: self._build_heads(stack, cnv.dtype, cnv.t.device))
         K = self.heatmaps_out
         n, h, w = cnv.n, cnv.h, cnv.w
-        a1 = Act.empty(n, h, w, 3 * self.features, cnv.dtype, cnv.t.device)
-        l1([cnv], a1, h, w)
-        a2 = Act.empty(n, h, w, 96, cnv.dtype, cnv.t.device)
-        l2([a1], a2, h, w)
         heat = torch.empty((n, K, h, w), dtype=torch.float32, device=cnv.t.device)
         depth = torch.empty((n, K, h, w), dtype=torch.float32, device=cnv.t.device)
         centers = torch.empty((n, 2 * (K - 1), h, w), dtype=torch.float32, device=cnv.t.device)
         outs = [(0, ops.ACT_SIGMOID if sigmoid else ops.ACT_NONE, heat, k) for k in range(K)]
         outs += [(32, ops.ACT_NONE, depth, k) for k in range(K)]
         outs += [(64, ops.ACT_NONE, centers, k) for k in range(2 * (K - 1))]
-        ops.head_out(a2, outs, w3, b3)
+        if ops.FUSE_HEADS and cnv.dtype == torch.bfloat16 and self.features == 128:
+            ops.heads_fused(l1, l2, cnv, outs, w3, b3)           # one launch, the 384- and 96-channel tensors stay in LDS
+        else:
+            a1 = Act.empty(n, h, w, 3 * self.features, cnv.dtype, cnv.t.device)
+            l1([cnv], a1, h, w)
+            a2 = Act.empty(n, h, w, 96, cnv.dtype, cnv.t.device)
+            l2([a1], a2, h, w)
+            ops.head_out(a2, outs, w3, b3)
         return heat, depth, centers.reshape(n, K - 1, 2, h, w)
 
     def _features(self, x):

@@ -136,3 +136,32 @@ def test_graph_capture_replays_the_same_step():
     assert torch.equal(static_out["heat"], eager["heat"])
     assert torch.equal(static_out["count"], eager["count"])
     assert torch.equal(torch.nan_to_num(static_out["points"]), torch.nan_to_num(eager["points"]))
+
+
+@pytest.mark.parametrize("n,h,w,k", [(2, 64, 64, 3), (1, 13, 9, 4), (3, 8, 8, 3)])
+def test_fused_heads_match_the_three_launch_path(n, h, w, k):
+    """okp_heads_forward (the three prediction heads of a stack in one launch, intermediates in LDS) against the
+    unfused path (256 -> 384 GEMM, block-diagonal 384 -> 96 GEMM, pointwise output kernel) on the same backbone output."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception.models import KeypointNet
+    net = KeypointNet(features=128, heatmaps_out=k, compute_dtype=torch.bfloat16)
+    shapes = {kk: tuple(v.shape) for kk, v in net.state_dict().items()}
+    vals = synth.fill_state_dict(shapes, seed=3)
+    net.load_state_dict({kk: torch.from_numpy(np.array(v)) for kk, v in vals.items()})
+    net.eval().cuda()
+    gen = torch.Generator().manual_seed(5)
+    cnv = ops.Act((torch.randn(n, h, w, 256, generator=gen) * 0.7).cuda().bfloat16())
+    keep = ops.FUSE_HEADS
+    try:
+        ops.FUSE_HEADS = True
+        l0 = ops.COUNTERS["launches"]
+        fused = net._run_heads(1, cnv, sigmoid=True)
+        assert ops.COUNTERS["launches"] - l0 == 1
+        ops.FUSE_HEADS = False
+        ref = net._run_heads(1, cnv, sigmoid=True)
+    finally:
+        ops.FUSE_HEADS = keep
+    for a, b in zip(fused, ref):
+        assert a.shape == b.shape
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-2 * scale + 2e-3, (float((a - b).abs().max()), scale)
