@@ -540,12 +540,41 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     constexpr int U = ITEMS / NT;                  // 8-channel output items per thread and pass
     constexpr int UB = U >= 2 ? 2 : 1;             // items per batch: their LDS reads are in flight together
     constexpr int CH8 = 8 * ESZ / 16;              // 16-B chunks per item (1 for bf16, 2 for fp32)
-    static_assert(ITEMS % NT == 0 && U % UB == 0, "epilogue work split");
-    for (int u0 = 0; u0 < U; u0 += UB) {
+    static_assert(ITEMS % NT == 0 && U % UB == 0 && (U < 8 || (U / 4) % UB == 0 || U < 16), "epilogue work split");
+    // Residual vectors: requested UH items at a time (the accumulators are dead - they were staged above - so registers
+    // are available), instead of one exposed memory round trip per batch of two items.
+    constexpr int UH = U >= 16 ? U / 4 : (U >= 8 ? U / 2 : U);
+#pragma unroll 1
+    for (int ub = 0; ub < U; ub += UH) {
+    u32x4 rres[UH][CH8];
+    if (p.res) {
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int it = tid + (ub + u) * NT;
+        const int q = it % GROUPS, prow = it / GROUPS;
+        const int pix = px0 + pass * PX_PER_PASS + prow;
+        const int co = co0 + q * 8;
+        const bool ok = pix < P && co < p.cout;
+        size_t opix = (size_t)(ok ? pix : 0);
+        if (!dense_out) {
+          const int pp = ok ? pix : 0;
+          const int n = fastdiv(pp, p.div_howo);
+          const int rem = pp - n * HoWo;
+          const int ho = fastdiv(rem, p.div_wo);
+          const int wo = rem - ho * p.Wo;
+          opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
+        }
+        const char* rp = static_cast<const char*>(p.res) + (opix * p.res_pix_stride + (ok ? co : 0)) * ESZ;
+#pragma unroll
+        for (int h = 0; h < CH8; ++h) rres[u][h] = *reinterpret_cast<const u32x4*>(rp + 16 * h);
+      }
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < UH; u0 += UB) {
       u32x4 raw[UB][CH8];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int it = tid + (u0 + u) * NT;
+        const int it = tid + (ub + u0 + u) * NT;
         const int q = it % GROUPS, prow = it / GROUPS;
 #pragma unroll
         for (int h = 0; h < CH8; ++h)
@@ -553,7 +582,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int it = tid + (u0 + u) * NT;
+        const int it = tid + (ub + u0 + u) * NT;
         const int q = it % GROUPS, prow = it / GROUPS;
         const int pix = px0 + pass * PX_PER_PASS + prow;
         const int co = co0 + q * 8;
@@ -588,7 +617,17 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[e] = a4[e]; v[4 + e] = b4[e]; }
             }
-            if (p.res) Io<T>::add8(v, static_cast<const char*>(p.res) + (opix * p.res_pix_stride + co) * ESZ);
+            if (p.res) {
+              if constexpr (ESZ == 2) {
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rres[u0 + u][0]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+              } else {
+                const f32x4 ra = __builtin_bit_cast(f32x4, rres[u0 + u][0]), rb = __builtin_bit_cast(f32x4, rres[u0 + u][CH8 - 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb[e]; }
+              }
+            }
             if (p.act == OKP_ACT_RELU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -598,6 +637,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         }
       }
     }
+    }  // ub
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
   }  // !DS
