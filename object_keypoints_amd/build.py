@@ -47,7 +47,7 @@ def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
     if _stale(obj, [src] + _deps()):
         extra = [] if os.path.basename(src) in AGPR_FILES else VGPR_FORM
-        cmd = [HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + CFLAGS + extra + os.environ.get("OKP_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -131,6 +131,68 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
       }
     }
   }
+  // ---- step table of the patch-resident kernel (bf16, 256-channel tiles; okp_igemm_patch.hip) -----------------
+  // Eligible when every slice is 64 channels of ONE tap, the taps of a stride-1 source span at most 3x3 and a strided
+  // source has a single tap (the 1x1 skip of `residual`): the 16x16-pixel tile's input patch of a 64-channel chunk is
+  // loaded once and serves all its taps.
+  std::vector<OkpPatchStep> psteps;
+  {
+    bool ok = dtype == OKP_BF16 && plan->cout_pad % 256 == 0 && plan->n_slices <= 256;
+    int lo_y[2] = {1 << 20, 1 << 20}, lo_x[2] = {1 << 20, 1 << 20}, hi_y[2] = {-(1 << 20), -(1 << 20)}, hi_x[2] = {-(1 << 20), -(1 << 20)};
+    int ntap[2] = {0, 0};
+    for (int t = 0; t < n_taps; ++t) {
+      const int sidx = taps[t].src;
+      lo_y[sidx] = std::min(lo_y[sidx], (int)taps[t].dy); hi_y[sidx] = std::max(hi_y[sidx], (int)taps[t].dy);
+      lo_x[sidx] = std::min(lo_x[sidx], (int)taps[t].dx); hi_x[sidx] = std::max(hi_x[sidx], (int)taps[t].dx);
+      ++ntap[sidx];
+    }
+    for (int sidx = 0; sidx < n_src && ok; ++sidx) {
+      if (!ntap[sidx] || cin[sidx] % 64) { ok = false; break; }
+      const bool single = hi_y[sidx] == lo_y[sidx] && hi_x[sidx] == lo_x[sidx];
+      if (conv_stride[sidx] != 1 && !single) { ok = false; break; }
+      plan->patch_step[sidx] = single ? conv_stride[sidx] : 1;
+      plan->patch_PH[sidx] = 16 + (single ? 0 : hi_y[sidx] - lo_y[sidx]);
+      plan->patch_PW[sidx] = 16 + (single ? 0 : hi_x[sidx] - lo_x[sidx]);
+      plan->patch_oy[sidx] = lo_y[sidx]; plan->patch_ox[sidx] = lo_x[sidx];
+      if (plan->patch_PH[sidx] * plan->patch_PW[sidx] > 18 * 18) ok = false;
+    }
+    struct Group { int src, c0, first, n; };
+    std::vector<Group> groups;
+    for (int si = 0; si < plan->n_slices && ok; ++si) {
+      const OkpSlice& sl = slices[si];
+      if (sl.tap_lo != sl.tap_hi || sl.nvalid != 8 || sl.c0_hi != sl.c0_lo + 32 || sl.c0_lo % 64) { ok = false; break; }
+      if (groups.empty() || groups.back().src != sl.src || groups.back().c0 != sl.c0_lo) groups.push_back({(int)sl.src, sl.c0_lo, si, 0});
+      ++groups.back().n;
+    }
+    if (ok && !groups.empty()) {
+      auto passes = [&](int sidx) { return (plan->patch_PH[sidx] * 18 + 63) / 64; };   // rows of 18 pixels (the kernel's pitch); 64 px = 8 KiB per pass of 512 lanes
+      psteps.resize(plan->n_slices);
+      for (size_t g = 0; g < groups.size(); ++g) {
+        const Group& G = groups[g];
+        const bool has_next = g + 1 < groups.size();
+        const int np = has_next ? passes(groups[g + 1].src) : 0;
+        const int per = (np + G.n - 1) / G.n;
+        for (int i = 0; i < G.n; ++i) {
+          const OkpSlice& sl = slices[G.first + i];
+          OkpPatchStep st{};
+          const bool single = plan->patch_PH[G.src] == 16 && plan->patch_PW[G.src] == 16 && ntap[G.src] == 1;
+          const int ty = single ? 0 : taps[sl.tap_lo].dy - plan->patch_oy[G.src], tx = single ? 0 : taps[sl.tap_lo].dx - plan->patch_ox[G.src];
+          st.tap_bytes = (uint32_t)((ty * 18 + tx) * 128);
+          st.pad[0] = (uint8_t)tx;
+          st.pbuf = (uint8_t)(g & 1);
+          st.src = (uint8_t)G.src;
+          st.nx_k0 = (uint8_t)std::min(np, i * per); st.nx_k1 = (uint8_t)std::min(np, (i + 1) * per);
+          st.nx_src = (uint8_t)(has_next ? groups[g + 1].src : 0);
+          st.nx_c0b = (uint32_t)(has_next ? groups[g + 1].c0 * 2 : 0);
+          psteps[G.first + i] = st;
+        }
+      }
+      plan->patch_first_src = groups[0].src; plan->patch_first_np = passes(groups[0].src); plan->patch_first_c0b = (uint32_t)(groups[0].c0 * 2);
+    } else {
+      psteps.clear();
+    }
+  }
+
   // bias is read as float4 per 32-row block of a 256-row tile: pad to a multiple of 256
   const int bias_pad = (cout + 255) / 256 * 256;
   std::vector<float> bias_h(bias_pad, 0.f);
@@ -150,6 +212,10 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
     }
     ok = ok && !okp_check_hip(hipMemcpy(plan->bias_dev, bias_h.data(), sizeof(float) * bias_pad, hipMemcpyHostToDevice), "hipMemcpy(bias)");
     ok = ok && !okp_check_hip(hipMemcpy(plan->slices_dev, slices.data(), sizeof(OkpSlice) * slices.size(), hipMemcpyHostToDevice), "hipMemcpy(slices)");
+    if (ok && !psteps.empty()) {
+      ok = !okp_check_hip(hipMalloc((void**)&plan->patch_steps_dev, sizeof(OkpPatchStep) * psteps.size()), "hipMalloc(patch steps)");
+      ok = ok && !okp_check_hip(hipMemcpy(plan->patch_steps_dev, psteps.data(), sizeof(OkpPatchStep) * psteps.size(), hipMemcpyHostToDevice), "hipMemcpy(patch steps)");
+    }
   }
   if (!ok) { okp_conv_destroy(plan); return nullptr; }
   plan->w_bytes = (uint32_t)w_bytes;
@@ -162,6 +228,7 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
   if (plan->bias_dev) (void)hipFree(plan->bias_dev);
   if (plan->slices_dev) (void)hipFree(plan->slices_dev);
   if (plan->frag_dev) (void)hipFree(plan->frag_dev);
+  if (plan->patch_steps_dev) (void)hipFree(plan->patch_steps_dev);
   delete plan;
 }
 
@@ -177,6 +244,8 @@ int check_view(const char* name, const okp_tensor& t, int esz, bool required, in
   return OKP_OK;
 }
 }  // namespace
+
+static int select_tile(const okp_conv* plan, const okp_conv_args* a);
 
 extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, void* stream) {
   if (!plan || !a) { okp_set_error("okp_conv_forward: null plan/args"); return OKP_EINVAL; }
@@ -201,7 +270,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   }
   if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
   if (a->res.data && (a->res.h != a->out.h || a->res.w != a->out.w)) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
-  if (a->tile < 0 || a->tile > 12) { okp_set_error("okp_conv_forward: tile %d", a->tile); return OKP_EINVAL; }
+  if (a->tile < 0 || a->tile > 13) { okp_set_error("okp_conv_forward: tile %d", a->tile); return OKP_EINVAL; }
 
   OkpIgemmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -237,13 +306,28 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
     p.dw_w = a->dw_w_dev; p.dw_bias = a->dw_bias_dev; p.dw_out = a->dw_out.data; p.dw_res = a->dw_res.data;
     p.dw_out_pix_stride = a->dw_out.pix_stride; p.dw_res_pix_stride = a->dw_res.pix_stride;
   }
-  return okp_launch_igemm(plan, p, a->tile, (hipStream_t)stream);
+  return okp_launch_igemm(plan, p, a->tile ? a->tile : select_tile(plan, a), (hipStream_t)stream);
+}
+
+// Tile heuristic of a launch.  The patch-resident kernel (13) takes over from the 256x256 gather tile where a source has
+// several taps (3x3 convolutions: the patch is read once instead of once per tap) and the problem is made of whole
+// 16x16-pixel blocks written densely.
+static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
+  const int tile = okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
+  static const bool patch_on = [] { const char* e = getenv("OKP_PATCH"); return !(e && e[0] == '0'); }();   // OKP_PATCH=0: A/B against the gather tile
+  if (patch_on && tile == 6 && plan->patch_steps_dev && plan->n_taps > plan->n_src && a->n_classes <= 1 && !a->dw_w_dev && a->out_step == 1 &&
+      a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo && a->ho % 16 == 0 && a->wo % 16 == 0) {
+    bool ok = true;
+    for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s];
+    if (ok) return 13;
+  }
+  return tile;
 }
 
 extern "C" int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* a) {
   if (!plan || !a) return 0;
   if (a->tile) return a->tile;
-  return okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
+  return select_tile(plan, a);
 }
 
 extern "C" int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* a) {

@@ -1,0 +1,366 @@
+// Patch-resident implicit GEMM for the 3x3 convolutions of the pre-stage and the hourglass (bf16, 256 output channels).
+//
+// okp_igemm_kernel gathers the pixel operand of EVERY K-slice from L2: a 3x3 convolution moves each input line nine
+// times into LDS (32 KiB of pixels + 32 KiB of weights per slice and workgroup).  Timing ablations of that kernel
+// (OKP_ABL in okp_igemm_kernel.h, conv 256->256 at 64x64, N=64) gave 269 us complete, 185 us without the LDS-DMA and
+// 194 us without the MFMAs: the L2 -> LDS stream costs as much as the matrix work and the two overlap poorly.
+//
+// Here a workgroup owns 256 output channels x one 16x16-pixel block of ONE frame.  For each 64-channel chunk of a source
+// the block's input patch INCLUDING its halo (18x18 pixels x 128 bytes = 40.5 KiB) is copied to LDS once, by LDS-DMA,
+// while the previous chunk is being multiplied; the nine taps of the chunk are then nine K-steps whose pixel fragments
+// are read from that patch at a tap-dependent offset.  Per K-step the workgroup now streams 32 KiB of weights + 4.5 KiB
+// of pixels instead of 64 KiB.  A strided single-tap source (the projected 1x1 skip of `residual`) is a 16x16 patch with
+// a pixel step.  Out-of-image patch pixels get an out-of-range buffer offset: the LDS-DMA writes zeros (zero padding).
+//
+// LDS: weights ring 2 x 32 KiB | patch buffers 2 x 41 KiB | step table 4 KiB | bias 1 KiB  = 151 KiB, one workgroup
+// (8 waves, 4 x 2, wave tile 64 channels x 128 pixels on 16x16x32 MFMAs) per CU; the epilogue stages the bf16 tile in
+// the same LDS and writes whole 512-byte pixel rows.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "okp_igemm_kernel.h"
+
+#ifndef OKP_PPIPE
+#define OKP_PPIPE 1
+#endif
+#ifndef OKP_PABL
+#define OKP_PABL 0    // timing ablations (WRONG results): bit 0 = no weight DMA, bit 1 = no patch DMA, bit 2 = no MFMAs, bit 3 = DMA never waited for
+#endif
+
+namespace {
+
+constexpr int kWStage = 256 * 128;                 // one K-step of weights: 256 rows x 128 B
+constexpr int kPitch = 18;                         // patch row pitch in pixels (16-wide patches leave two columns unused)
+constexpr int kPatchBuf = 41 * 1024;               // 18 x 18 px x 128 B, rounded up to whole 1 KiB LDS-DMA blocks
+constexpr int kLdsPatch = 2 * kWStage;
+constexpr int kLdsSteps = kLdsPatch + 2 * kPatchBuf;
+constexpr int kLdsBias = kLdsSteps + 256 * (int)sizeof(OkpPatchStep);
+constexpr int kLdsTotal = kLdsBias + 1024;
+static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
+static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
+
+__global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
+  constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
+  __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
+  char* const steps_lds = smem + kLdsSteps;
+  char* const bias_lds = smem + kLdsBias;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wpx = wave & 1;
+  const int fr = lane & 15, fh = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g[0].data), 0, (int)p.g[0].bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g[1].data), 0, (int)p.g[1].bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
+
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (p.dbg) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  if (tid < p.n_steps) reinterpret_cast<u32x4*>(steps_lds)[tid] = reinterpret_cast<const u32x4*>(p.steps)[tid];
+  __syncthreads();
+
+  // weights loader: lane (row r0 = tid >> 3, position tid & 7) fetches the chunk the read-side swizzle expects there
+  const int r0 = tid >> 3;
+  const int wc = (tid & 7) ^ ((r0 >> 1) & 7);
+
+  for (int slot = blockIdx.x; slot < p.n_tiles; slot += gridDim.x) {
+    // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos)
+    const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
+    const int co_tile = tile % p.n_co_tiles;
+    const int px_tile = tile / p.n_co_tiles;
+    const int n = fastdiv(px_tile, p.div_tiles_frame);
+    const int trem = px_tile - n * p.tiles_y * p.tiles_x;
+    const int tyi = fastdiv(trem, p.div_tiles_x);
+    const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
+    const int co0 = co_tile * 256;
+
+    if (wave == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16, (int)((uint32_t)(co0 + lane * 4) * 4u), 0, 0, 0);
+
+    uint32_t wbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = co0 + r0 + i * 64;
+      wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)wc * 16u : kInvalidOff;
+    }
+
+    auto issue_w = [&](int t, int stage) {
+      if (OKP_PABL & 1) return;
+      const uint32_t wslice = (uint32_t)t * (uint32_t)p.cout_pad * 128u;
+      char* const wt = smem + stage * kWStage + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * 8192), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+    };
+    // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
+    auto issue_patch = [&](int src, uint32_t c0b, int k0, int k1, int buf) {
+      if (OKP_PABL & 2) return;
+      const int PW = src ? p.g[1].PW : p.g[0].PW, npx = src ? p.g[1].npx : p.g[0].npx;      // valid columns; rows x kPitch
+      const int H = src ? p.g[1].H : p.g[0].H, W = src ? p.g[1].W : p.g[0].W;
+      const int ps2 = (src ? p.g[1].pix_stride : p.g[0].pix_stride) * 2;
+      const int step = src ? p.g[1].step : p.g[0].step, cs = src ? p.g[1].conv_stride : p.g[0].conv_stride;
+      const int yb = cs * y0 + (src ? p.g[1].oy : p.g[0].oy), xb = cs * x0 + (src ? p.g[1].ox : p.g[0].ox);
+      for (int k = k0; k < k1; ++k) {
+        const int blk = k * 8 + wave;
+        if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
+        const int idx = blk * 8 + (lane >> 3);
+        const int i = idx / kPitch, j = idx - i * kPitch;
+        const int ch = (lane & 7) ^ ((j >> 1) & 7);             // swizzle by the patch COLUMN: the same for every tap row
+        const int ys = yb + i * step, xs = xb + j * step;
+        const bool ok = idx < npx && j < PW && ys >= 0 && ys < H && xs >= 0 && xs < W;
+        const uint32_t off = ok ? (uint32_t)((n * H + ys) * W + xs) * (uint32_t)ps2 + c0b + (uint32_t)ch * 16u : kInvalidOff;
+        char* const dst = smem + kLdsPatch + buf * kPatchBuf + blk * 1024;
+        if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+      }
+    };
+
+    f32x4 acc[TCO][TPX];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_patch(p.first_src, p.first_c0b, 0, p.first_np, 0);
+    issue_w(0, 0);
+
+    for (int t = 0; t < p.n_steps; ++t) {
+      const u32x4 sv = *reinterpret_cast<const u32x4*>(steps_lds + t * 16);
+      const uint32_t tap_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[0]);
+      const uint32_t nx_c0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[1]);
+      const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[2]);
+      const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_src = pk >> 24;
+      const int dxo = (__builtin_amdgcn_readfirstlane((int)sv[3]) >> 8) & 0xff;      // column offset of this step's tap inside the patch
+      const bool more = t + 1 < p.n_steps;
+
+      if (!(OKP_PABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my part of step t's weights (and of its patch) has landed
+      __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
+
+      const char* const wt = smem + (t & 1) * kWStage;
+      const char* const pbase = smem + kLdsPatch + pbuf * kPatchBuf;
+      // Fragment addresses: row index and swizzle of the weights depend on the lane only; a pixel fragment j of the
+      // wave is patch row (8 wpx + j + dy), columns fr + dx - with the swizzle keyed on the COLUMN its term is the same
+      // for all eight j, which are then reached by immediate offsets of one row pitch (kPitch * 128 bytes).
+      const char* const bb = pbase + tap_bytes + (uint32_t)((wpx * TPX * kPitch + fr) * 128);
+      const uint32_t bsw = (uint32_t)(((fr + dxo) >> 1) & 7);
+#if OKP_PPIPE
+      // Fragment pipeline: the pixel fragments are read two at a time, one pair ahead of the eight MFMAs that use
+      // them, and the second k-step's weight fragments during the first k-step - so the LDS reads of a wave run
+      // under its own MFMAs instead of in a burst after the barrier that all eight waves issue (and wait for) together.
+      auto lda = [&](int kk, int i) {
+        return *reinterpret_cast<const u32x4*>(wt + swz<128>((wco * TCO + i) * 16 + fr, 4 * kk + fh));
+      };
+      auto ldb = [&](int kk, int j) {
+        return *reinterpret_cast<const u32x4*>(bb + j * (kPitch * 128) + ((((uint32_t)(4 * kk + fh)) ^ bsw) << 4));
+      };
+      auto mma8 = [&](const u32x4 (&a)[TCO], const u32x4 (&bq)[2], auto s) {
+        constexpr int S = decltype(s)::value;
+        if (OKP_PABL & 4) {
+#pragma unroll
+          for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
+          asm volatile("" ::"v"(bq[0]), "v"(bq[1]));
+          return;
+        }
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[i][2 * S + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bq[h]), acc[i][2 * S + h], 0, 0, 0);
+      };
+      using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+      using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+      u32x4 a0[TCO], a1[TCO], bq0[2], bq1[2];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) a0[i] = lda(0, i);
+      bq0[0] = ldb(0, 0); bq0[1] = ldb(0, 1);
+      bq1[0] = ldb(0, 2); bq1[1] = ldb(0, 3);
+      if (more) issue_w(t + 1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a0, bq0, S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq0[0] = ldb(0, 4); bq0[1] = ldb(0, 5); a1[0] = lda(1, 0); a1[1] = lda(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a0, bq1, S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq1[0] = ldb(0, 6); bq1[1] = ldb(0, 7); a1[2] = lda(1, 2); a1[3] = lda(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a0, bq0, S2{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq0[0] = ldb(1, 0); bq0[1] = ldb(1, 1);
+      if (nx_k1 > nx_k0) issue_patch(nx_src, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a0, bq1, S3{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq1[0] = ldb(1, 2); bq1[1] = ldb(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a1, bq0, S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq0[0] = ldb(1, 4); bq0[1] = ldb(1, 5);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a1, bq1, S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      bq1[0] = ldb(1, 6); bq1[1] = ldb(1, 7);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(a1, bq0, S2{});
+      mma8(a1, bq1, S3{});
+#else
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4 a[TCO], b[TPX];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz<128>((wco * TCO + i) * 16 + fr, 4 * kk + fh));
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+          // patch pixel of tile row wpx*8 + j, column fr, shifted by the tap: the swizzle follows the patch row index
+          b[j] = *reinterpret_cast<const u32x4*>(bb + j * (kPitch * 128) + ((((uint32_t)(4 * kk + fh)) ^ bsw) << 4));
+        }
+        if (kk == 0 && more) issue_w(t + 1, (t + 1) & 1);
+        if (kk == 1 && nx_k1 > nx_k0) issue_patch(nx_src, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+        if (OKP_PABL & 4) {
+#pragma unroll
+          for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+          for (int j = 0; j < TPX; ++j) asm volatile("" ::"v"(b[j]));
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+          for (int j = 0; j < TPX; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+      }
+#endif
+    }
+    __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
+
+    // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) {
+      const int co_l = (wco * TCO + i) * 16 + 4 * fh;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + co_l * 4);
+#pragma unroll
+      for (int j = 0; j < TPX; ++j) {
+        const int prow = (wpx * TPX + j) * 16 + fr;
+        char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][j][e] + bv[e]);
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      }
+    }
+    __syncthreads();
+    constexpr int U = 256 * 32 / 512;              // 16-byte items (8 channels of one pixel) per thread
+    constexpr int UH = 4;                          // residual vectors in flight together
+    const bool relu = p.act == OKP_ACT_RELU;
+#pragma unroll 1
+    for (int ub = 0; ub < U; ub += UH) {
+      u32x4 rres[UH];
+      uint32_t ooff[UH];
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int it = tid + (ub + u) * 512;
+        const int q = it & 31, prow = it >> 5;
+        const int co = co0 + q * 8;
+        const uint32_t opix = (uint32_t)((n * p.H + y0 + (prow >> 4)) * p.W + x0 + (prow & 15));
+        ooff[u] = co < p.cout ? opix : kInvalidOff;
+      }
+      if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          const int q = (tid + (ub + u) * 512) & 31;
+          const int co = co0 + q * 8;
+          const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
+          rres[u] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int it = tid + (ub + u) * 512;
+        const int q = it & 31, prow = it >> 5;
+        u32x4 w = *reinterpret_cast<const u32x4*>(smem + prow * 512 + ((q ^ (prow & 7)) << 4));
+        if (ooff[u] == kInvalidOff) continue;
+        char* op = static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q * 8) * 2;
+        if (!p.res) {
+          if (relu) {
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            w = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, w), z));
+          }
+          *reinterpret_cast<u32x4*>(op) = w;
+        } else {
+          const bf16x8 s8 = __builtin_bit_cast(bf16x8, w), r8 = __builtin_bit_cast(bf16x8, rres[u]);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = (float)s8[e] + (float)r8[e];
+            if (relu) v = fmaxf(v, 0.f);
+            o[e] = (__bf16)v;
+          }
+          *reinterpret_cast<bf16x8*>(op) = o;
+        }
+      }
+    }
+    __syncthreads();                               // staging is free again: the next tile's LDS-DMA may overwrite it
+  }
+  if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    p.dbg[0] = __builtin_readcyclecounter() - clk0;
+    p.dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+}
+
+}  // namespace
+
+bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
+  if (!plan->patch_steps_dev || plan->dtype != OKP_BF16) return false;
+  if (p.n_classes != 1 || p.dw_w || p.out_step != 1 || p.OH != p.Ho || p.OW != p.Wo || p.out_oy || p.out_ox) return false;
+  if (p.Ho % 16 || p.Wo % 16) return false;
+  for (int s = 0; s < plan->n_src; ++s) {
+    // the patch of output block (y0, x0) starts at conv_stride * (y0, x0) + (oy, ox) in the source: the source must be
+    // the map the stride implies, or the zero padding at its lower/right edge would differ from the gather kernel's
+    if (p.src_pix_stride[s] < plan->cin[s]) return false;
+  }
+  return true;
+}
+
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStream_t stream) {
+  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
+  OkpPatchParams p;
+  std::memset(&p, 0, sizeof(p));
+  for (int s = 0; s < 2; ++s) {
+    const int ss = s < plan->n_src ? s : 0;
+    OkpPatchGeom& g = p.g[s];
+    g.data = q.src[ss]; g.bytes = q.src_bytes[ss]; g.H = q.srcH[ss]; g.W = q.srcW[ss]; g.pix_stride = q.src_pix_stride[ss];
+    g.PW = plan->patch_PW[ss]; g.npx = 18 * plan->patch_PH[ss];
+    g.oy = plan->patch_oy[ss]; g.ox = plan->patch_ox[ss]; g.step = plan->patch_step[ss]; g.conv_stride = plan->conv_stride[ss];
+  }
+  p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias;
+  p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
+  p.first_src = plan->patch_first_src; p.first_np = plan->patch_first_np; p.first_c0b = plan->patch_first_c0b;
+  p.N = q.N; p.H = q.Ho; p.W = q.Wo; p.tiles_y = q.Ho / 16; p.tiles_x = q.Wo / 16;
+  p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
+  p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
+  p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
+  p.n_co_tiles = q.cout_pad / 256;
+  p.n_tiles = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
+  const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
+  static unsigned long long* dbg = [] {
+    unsigned long long* d = nullptr;
+    const char* e = getenv("OKP_PCLK");
+    if (e && e[0] == '1') (void)hipMalloc((void**)&d, 16);
+    return d;
+  }();
+  p.dbg = dbg;
+  hipLaunchKernelGGL(okp_igemm_patch_kernel, grid, block, 0, stream, p);
+  if (dbg) {
+    unsigned long long h[2] = {0, 0};
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, dbg, 16, hipMemcpyDeviceToHost);
+    fprintf(stderr, "okp_igemm_patch: workgroup 0 ran %llu shader clocks in %.1f us -> %.3f GHz\n", h[0], h[1] / 100.0, h[1] ? h[0] / (h[1] * 10.0) : 0.0);
+  }
+  return okp_check_hip(hipGetLastError(), "okp_igemm_patch launch");
+}

@@ -70,6 +70,35 @@ struct OkpIgemmParams {
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 
+// okp_igemm_patch.hip: 256 x (16x16 px) tiles whose input patch (halo included) stays in LDS for all taps of a
+// 64-channel chunk; one step = one tap of one chunk = one 128-byte K-slice of the packed weights.
+struct OkpPatchStep {          // 16 bytes, built at plan creation
+  uint32_t tap_bytes;          // byte offset of this step's tap inside the patch: ((dy - oy) * 18 + (dx - ox)) * 128 (row pitch 18 px)
+  uint32_t nx_c0b;             // channel byte offset of the NEXT group's patch (prefetched during this group's steps)
+  uint8_t pbuf, nx_k0, nx_k1, nx_src;   // patch buffer of this step; passes [k0, k1) of the next patch issued in this step
+  uint8_t src, pad[3];         // source of this step's patch; pad[0] = dx - ox (the fragment swizzle is keyed on the patch column)
+};
+struct OkpPatchGeom {          // patch geometry of one source
+  const void* data; uint32_t bytes;
+  int32_t H, W, pix_stride;
+  int32_t PW, npx;             // valid patch columns; rows * 18 (pixels of the LDS image, pitch 18)
+  int32_t oy, ox;              // offset of patch pixel (0, 0) relative to conv_stride * (tile origin)
+  int32_t step, conv_stride;   // source pixels per patch pixel (conv stride for single-tap sources, else 1)
+};
+struct OkpPatchParams {
+  OkpPatchGeom g[2];
+  const void* weights; uint32_t w_bytes; int32_t cout_pad, cout;
+  const float* bias;
+  const OkpPatchStep* steps; int32_t n_steps;
+  int32_t first_src, first_np; uint32_t first_c0b;
+  int32_t N, H, W, tiles_y, tiles_x;
+  OkpFastDiv div_tiles_frame, div_tiles_x;
+  void* out; uint32_t out_bytes; int32_t out_pix_stride;
+  const void* res; uint32_t res_bytes; int32_t res_pix_stride;
+  int32_t act, n_co_tiles, n_tiles;
+  unsigned long long* dbg;     // OKP_PCLK=1: {shader clocks, 100 MHz ticks} of workgroup 0 (diagnostic)
+};
+
 struct OkpFireParams {
   const void* x; uint32_t x_bytes; int32_t H, W, x_ps;
   void* out; int32_t Ho, Wo, out_ps;
@@ -115,6 +144,10 @@ struct okp_conv {
   uint32_t w_bytes;
   float* bias_dev;
   OkpSlice* slices_dev;
+  // patch-resident kernel (okp_igemm_patch.hip): step table + per-source patch geometry, or patch_steps_dev == NULL
+  OkpPatchStep* patch_steps_dev;
+  int32_t patch_PW[2], patch_PH[2], patch_oy[2], patch_ox[2], patch_step[2];
+  int32_t patch_first_src, patch_first_np; uint32_t patch_first_c0b;
   void* frag_dev;          // 1x1 plans used by okp_fire_chain: weights re-laid in MFMA-fragment order (built on first use)
 };
 
@@ -127,4 +160,6 @@ int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hi
 int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_chain.hip: fragment-order weight copy of a 1x1 plan
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream);
+bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
 int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip

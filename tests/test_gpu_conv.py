@@ -303,3 +303,65 @@ def test_fire_chain_matches_module_by_module(c, h, w, n, count):
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) <= 0.03 * scale * max(1, count // 2) + 0.02, float((got - ref).abs().max())
     assert float((got - single).abs().max()) <= 0.02 * scale * max(1, count // 2) + 0.02
+
+
+@pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile"])
+def test_patch_resident_kernel_matches_gather_kernel(case):
+    """Tile 13 (okp_igemm_patch: input patch + halo resident in LDS) against torch AND bit-for-bit against tile 6 (same
+    K order, same MFMA shape => identical sums): zero padding on all four edges, residual read through a channel window,
+    the stride-2 single-tap second source, several channel chunks."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = _dev()
+    dtype = torch.bfloat16
+    rb = lambda v: v.bfloat16().float()
+    res = None
+    if case in ("conv3x3", "conv3x3_res_window", "two_chunks", "one_tile"):
+        n, h, w = (1, 16, 16) if case == "one_tile" else (3, 32, 48)
+        cin = 128 if case == "two_chunks" else 256
+        x = rb(_rand((n, cin, h, w), 21)); wt = rb(_rand((256, cin, 3, 3), 22) / np.sqrt(cin * 9)); b = _rand((256,), 23) * 0.1
+        ref = F.conv2d(x, wt, b, padding=1)
+        plan = ops.ConvPlan(dtype, [cin], [1], 256, conv_taps(wt.numpy()), b.numpy(), relu=True)
+        srcs = [ops.Act.from_nchw(x.to(dev), dtype)]
+        if case == "conv3x3_res_window":
+            r = rb(_rand((n, 320, h, w), 24))
+            ref = ref + r[:, 32:288]
+            res = ops.Act.from_nchw(r.to(dev), dtype).slice(32, 256)
+        ref = F.relu(ref)
+    elif case == "residual_s2_skip":
+        n, h, w = 2, 32, 32
+        t = rb(_rand((n, 256, h, w), 25)); x = rb(_rand((n, 128, 2 * h, 2 * w), 26))
+        w2 = rb(_rand((256, 256, 3, 3), 27) / np.sqrt(256 * 9)); ws = rb(_rand((256, 128, 1, 1), 28) / np.sqrt(128)); b = _rand((256,), 29) * 0.1
+        ref = F.relu(F.conv2d(t, w2, b, padding=1) + F.conv2d(x, ws, stride=2))
+        taps = conv_taps(w2.numpy()) + [(1, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))]
+        plan = ops.ConvPlan(dtype, [256, 128], [1, 2], 256, taps, b.numpy(), relu=True)
+        srcs = [ops.Act.from_nchw(t.to(dev), dtype), ops.Act.from_nchw(x.to(dev), dtype)]
+    else:
+        n, h, w = 2, 16, 32
+        a = rb(_rand((n, 256, h, w), 30)); c = rb(_rand((n, 256, h, w), 31))
+        wa = rb(_rand((256, 256, 1, 1), 32) / 16); wc = rb(_rand((256, 256, 1, 1), 33) / 16); b = _rand((256,), 34) * 0.1
+        ref = F.relu(F.conv2d(a, wa, b) + F.conv2d(c, wc))
+        taps = [(0, 0, 0, np.ascontiguousarray(wa.numpy()[:, :, 0, 0])), (1, 0, 0, np.ascontiguousarray(wc.numpy()[:, :, 0, 0]))]
+        plan = ops.ConvPlan(dtype, [256, 256], [1, 1], 256, taps, b.numpy(), relu=True)
+        srcs = [ops.Act.from_nchw(a.to(dev), dtype), ops.Act.from_nchw(c.to(dev), dtype)]
+    outs = {}
+    for tile in (6, 13):
+        big = ops.Act(torch.full((n, h, w, 288), -7.0, dtype=dtype, device=dev))
+        plan(srcs, big.slice(16, 256), h, w, res=res, tile=tile)
+        outs[tile] = big.t.float().cpu()
+        assert bool((outs[tile][..., :16] == -7.0).all()) and bool((outs[tile][..., 272:] == -7.0).all())   # neighbours untouched
+    got = outs[13][..., 16:272].permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= _tol(dtype, ref)
+    assert torch.equal(outs[13], outs[6])
+
+@pytest.mark.gpu
+def test_patch_resident_kernel_refuses_other_shapes():
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = _dev()
+    wt = _rand((256, 256, 3, 3), 35) * 0.01
+    plan = ops.ConvPlan(torch.bfloat16, [256], [1], 256, conv_taps(wt.numpy()), None, relu=False)
+    x = ops.Act(torch.zeros((1, 20, 16, 256), dtype=torch.bfloat16, device=dev))
+    out = ops.Act.empty(1, 20, 16, 256, torch.bfloat16, dev)
+    with pytest.raises(RuntimeError, match="tile 13"):
+        plan([x], out, 20, 16, tile=13)                      # height not a multiple of 16
