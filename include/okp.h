@@ -89,7 +89,9 @@ typedef struct okp_conv_args {
   okp_tensor out;                  /* out.h/out.w are the FULL output tensor's spatial size */
   int32_t out_step, out_oy, out_ox;/* sub-pixel placement (1,0,0 for ordinary convs) */
   okp_tensor res;                  /* optional residual, same spatial mapping as out; data==NULL if none */
-  int32_t tile;                    /* 0 = auto; 1 64x64, 2 128x128, 3 256x256 (32x32 MFMA); 4/5 half-slice rings; 6/7/8 = 256/128/64 on 16x16 MFMA */
+  int32_t tile;                    /* 0 = auto; 1 64x64, 2 128x128, 3 256x256 (32x32 MFMA); 4/5 half-slice rings; 6/7/8 = 256/128/64 on 16x16 MFMA;
+                                      9-12 experimental tiles; 13 = patch-resident 3x3 kernel (bf16, cout_pad % 256 == 0, whole 16x16-pixel
+                                      blocks, dense output; OKP_EINVAL where it does not apply) */
   /* Optional fused depth-wise branch (the fire-module tail, CornerNet_Squeeze.py:15-17,25-30): the same launch
    * also computes  dw_out[..., c] = act(dw_bias[c] + dw_res[..., c] + sum_{3x3 taps} dw_w[tap][c] * src[0][..., c])
    * for c in [0, cout) with the plan's conv_stride[0] and pad 1, so that `expand 1x1 || depth-wise 3x3` of one
@@ -106,7 +108,7 @@ typedef struct okp_conv_args {
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
-/* The tile code (1..8) the launch heuristic picks for these args when args->tile == 0. */
+/* The tile code (1..8, 13) the launch heuristic picks for these args when args->tile == 0. */
 int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* args);
 /* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
 int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
