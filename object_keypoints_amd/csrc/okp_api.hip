@@ -92,6 +92,47 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
     }
     ++t;
   }
+  // ---- patch geometries (okp_igemm_patch.hip): which window of its source every tap reads ----------------------------
+  // One geometry per source whose taps sit on one lattice (stride 1: the 3x3 window, 18x18 patch pixels for a 16x16 block;
+  // a single tap: 16x16 with the conv stride as pixel step); a strided multi-tap source is split into the residue classes
+  // of (dy, dx) modulo the stride - a stride-2 3x3 reads four interleaved sub-lattices of 17x17, 17x16, 16x17 and 16x16.
+  int tap_geom[OKP_MAX_TAPS] = {0}, tap_ty[OKP_MAX_TAPS] = {0}, tap_tx[OKP_MAX_TAPS] = {0};
+  bool patch_ok = dtype == OKP_BF16 && plan->cout_pad % 256 == 0;
+  plan->patch_n_geom = 0;
+  for (int sidx = 0; sidx < n_src && patch_ok; ++sidx) {
+    const int cs = conv_stride[sidx];
+    if (cin[sidx] % 64) { patch_ok = false; break; }
+    bool single = true; int first = -1;
+    for (int t = 0; t < n_taps; ++t) if (taps[t].src == sidx) {
+      if (first < 0) first = t;
+      single = single && taps[t].dy == taps[first].dy && taps[t].dx == taps[first].dx;
+    }
+    if (first < 0) { patch_ok = false; break; }
+    const int m = (cs == 1 || single) ? 1 : cs;                 // lattice classes per axis
+    auto cls = [&](int d) { return ((d % m) + m) % m; };
+    for (int cy = 0; cy < m && patch_ok; ++cy)
+      for (int cx = 0; cx < m && patch_ok; ++cx) {
+        int lo_y = 1 << 20, lo_x = 1 << 20, hi_y = -(1 << 20), hi_x = -(1 << 20), cnt = 0;
+        for (int t = 0; t < n_taps; ++t) if (taps[t].src == sidx && cls(taps[t].dy) == cy && cls(taps[t].dx) == cx) {
+          lo_y = std::min(lo_y, (int)taps[t].dy); hi_y = std::max(hi_y, (int)taps[t].dy);
+          lo_x = std::min(lo_x, (int)taps[t].dx); hi_x = std::max(hi_x, (int)taps[t].dx);
+          ++cnt;
+        }
+        if (!cnt) continue;
+        const int g = plan->patch_n_geom;
+        if (g >= OKP_PATCH_MAX_GEOM) { patch_ok = false; break; }
+        plan->patch_src[g] = sidx; plan->patch_step[g] = single ? cs : m;
+        plan->patch_oy[g] = lo_y; plan->patch_ox[g] = lo_x;
+        plan->patch_PH[g] = 16 + (hi_y - lo_y) / m; plan->patch_PW[g] = 16 + (hi_x - lo_x) / m;
+        if (plan->patch_PH[g] > 18 || plan->patch_PW[g] > 18) { patch_ok = false; break; }
+        for (int t = 0; t < n_taps; ++t) if (taps[t].src == sidx && cls(taps[t].dy) == cy && cls(taps[t].dx) == cx) {
+          tap_geom[t] = g; tap_ty[t] = (taps[t].dy - lo_y) / m; tap_tx[t] = (taps[t].dx - lo_x) / m;
+        }
+        ++plan->patch_n_geom;
+      }
+  }
+  if (!patch_ok) for (int t = 0; t < n_taps; ++t) tap_geom[t] = 0;
+
   // K order: channel chunk outermost, taps inside (any order of the K-slices computes the same sum).  The taps of one
   // 128-byte channel chunk then follow each other, so the lines one tap gathers are re-read by its neighbours within a
   // few slices - L2 hits - instead of a whole tap (4-8 slices of every CU of the XCD) later.  Measured with per-dispatch
@@ -104,7 +145,8 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
       const int ga = a.tap_lo / group_taps, gb = b.tap_lo / group_taps;
       if (ga != gb) return ga < gb;
       if (a.src != b.src) return a.src < b.src;
-      return a.c0_lo < b.c0_lo;
+      if (a.c0_lo != b.c0_lo) return a.c0_lo < b.c0_lo;
+      return tap_geom[a.tap_lo] < tap_geom[b.tap_lo];          // the taps of one patch geometry follow each other
     });
   }
   plan->n_slices = (int)slices.size();
@@ -132,62 +174,42 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
     }
   }
   // ---- step table of the patch-resident kernel (bf16, 256-channel tiles; okp_igemm_patch.hip) -----------------
-  // Eligible when every slice is 64 channels of ONE tap, the taps of a stride-1 source span at most 3x3 and a strided
-  // source has a single tap (the 1x1 skip of `residual`): the 16x16-pixel tile's input patch of a 64-channel chunk is
-  // loaded once and serves all its taps.
+  // Eligible when every slice is 64 channels of ONE tap: the 16x16-pixel tile's input patch of a 64-channel chunk and
+  // geometry is loaded once and serves all its taps (consecutive K-steps).
   std::vector<OkpPatchStep> psteps;
   {
-    bool ok = dtype == OKP_BF16 && plan->cout_pad % 256 == 0 && plan->n_slices <= 256;
-    int lo_y[2] = {1 << 20, 1 << 20}, lo_x[2] = {1 << 20, 1 << 20}, hi_y[2] = {-(1 << 20), -(1 << 20)}, hi_x[2] = {-(1 << 20), -(1 << 20)};
-    int ntap[2] = {0, 0};
-    for (int t = 0; t < n_taps; ++t) {
-      const int sidx = taps[t].src;
-      lo_y[sidx] = std::min(lo_y[sidx], (int)taps[t].dy); hi_y[sidx] = std::max(hi_y[sidx], (int)taps[t].dy);
-      lo_x[sidx] = std::min(lo_x[sidx], (int)taps[t].dx); hi_x[sidx] = std::max(hi_x[sidx], (int)taps[t].dx);
-      ++ntap[sidx];
-    }
-    for (int sidx = 0; sidx < n_src && ok; ++sidx) {
-      if (!ntap[sidx] || cin[sidx] % 64) { ok = false; break; }
-      const bool single = hi_y[sidx] == lo_y[sidx] && hi_x[sidx] == lo_x[sidx];
-      if (conv_stride[sidx] != 1 && !single) { ok = false; break; }
-      plan->patch_step[sidx] = single ? conv_stride[sidx] : 1;
-      plan->patch_PH[sidx] = 16 + (single ? 0 : hi_y[sidx] - lo_y[sidx]);
-      plan->patch_PW[sidx] = 16 + (single ? 0 : hi_x[sidx] - lo_x[sidx]);
-      plan->patch_oy[sidx] = lo_y[sidx]; plan->patch_ox[sidx] = lo_x[sidx];
-      if (plan->patch_PH[sidx] * plan->patch_PW[sidx] > 18 * 18) ok = false;
-    }
-    struct Group { int src, c0, first, n; };
+    bool ok = patch_ok && plan->n_slices <= 256;
+    struct Group { int geom, c0, first, n; };
     std::vector<Group> groups;
     for (int si = 0; si < plan->n_slices && ok; ++si) {
       const OkpSlice& sl = slices[si];
       if (sl.tap_lo != sl.tap_hi || sl.nvalid != 8 || sl.c0_hi != sl.c0_lo + 32 || sl.c0_lo % 64) { ok = false; break; }
-      if (groups.empty() || groups.back().src != sl.src || groups.back().c0 != sl.c0_lo) groups.push_back({(int)sl.src, sl.c0_lo, si, 0});
+      const int g = tap_geom[sl.tap_lo];
+      if (groups.empty() || groups.back().geom != g || groups.back().c0 != sl.c0_lo) groups.push_back({g, sl.c0_lo, si, 0});
       ++groups.back().n;
     }
     if (ok && !groups.empty()) {
-      auto passes = [&](int sidx) { return (plan->patch_PH[sidx] * 18 + 63) / 64; };   // rows of 18 pixels (the kernel's pitch); 64 px = 8 KiB per pass of 512 lanes
+      auto passes = [&](int g) { return (plan->patch_PH[g] * 18 + 63) / 64; };   // rows of 18 pixels (the kernel's pitch); 64 px = 8 KiB per pass of 512 lanes
       psteps.resize(plan->n_slices);
-      for (size_t g = 0; g < groups.size(); ++g) {
-        const Group& G = groups[g];
-        const bool has_next = g + 1 < groups.size();
-        const int np = has_next ? passes(groups[g + 1].src) : 0;
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group& G = groups[gi];
+        const bool has_next = gi + 1 < groups.size();
+        const int np = has_next ? passes(groups[gi + 1].geom) : 0;
         const int per = (np + G.n - 1) / G.n;
         for (int i = 0; i < G.n; ++i) {
           const OkpSlice& sl = slices[G.first + i];
           OkpPatchStep st{};
-          const bool single = plan->patch_PH[G.src] == 16 && plan->patch_PW[G.src] == 16 && ntap[G.src] == 1;
-          const int ty = single ? 0 : taps[sl.tap_lo].dy - plan->patch_oy[G.src], tx = single ? 0 : taps[sl.tap_lo].dx - plan->patch_ox[G.src];
-          st.tap_bytes = (uint32_t)((ty * 18 + tx) * 128);
-          st.pad[0] = (uint8_t)tx;
-          st.pbuf = (uint8_t)(g & 1);
-          st.src = (uint8_t)G.src;
+          st.tap_bytes = (uint32_t)((tap_ty[sl.tap_lo] * 18 + tap_tx[sl.tap_lo]) * 128);
+          st.tx = (uint8_t)tap_tx[sl.tap_lo];
+          st.pbuf = (uint8_t)(gi & 1);
+          st.geom = (uint8_t)G.geom;
           st.nx_k0 = (uint8_t)std::min(np, i * per); st.nx_k1 = (uint8_t)std::min(np, (i + 1) * per);
-          st.nx_src = (uint8_t)(has_next ? groups[g + 1].src : 0);
-          st.nx_c0b = (uint32_t)(has_next ? groups[g + 1].c0 * 2 : 0);
+          st.nx_geom = (uint8_t)(has_next ? groups[gi + 1].geom : 0);
+          st.nx_c0b = (uint32_t)(has_next ? groups[gi + 1].c0 * 2 : 0);
           psteps[G.first + i] = st;
         }
       }
-      plan->patch_first_src = groups[0].src; plan->patch_first_np = passes(groups[0].src); plan->patch_first_c0b = (uint32_t)(groups[0].c0 * 2);
+      plan->patch_first_geom = groups[0].geom; plan->patch_first_np = passes(groups[0].geom); plan->patch_first_c0b = (uint32_t)(groups[0].c0 * 2);
     } else {
       psteps.clear();
     }
@@ -315,7 +337,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
 static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
   const int tile = okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
   static const bool patch_on = [] { const char* e = getenv("OKP_PATCH"); return !(e && e[0] == '0'); }();   // OKP_PATCH=0: A/B against the gather tile
-  if (patch_on && tile == 6 && plan->patch_steps_dev && plan->n_taps > plan->n_src && a->n_classes <= 1 && !a->dw_w_dev && a->out_step == 1 &&
+  if (patch_on && tile == 6 && plan->patch_steps_dev && plan->n_taps > plan->patch_n_geom && a->n_classes <= 1 && !a->dw_w_dev && a->out_step == 1 &&
       a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo && a->ho % 16 == 0 && a->wo % 16 == 0) {
     bool ok = true;
     for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s];

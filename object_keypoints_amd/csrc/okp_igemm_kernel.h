@@ -24,9 +24,6 @@
 #ifndef OKP_XB
 #define OKP_XB 1
 #endif
-#ifndef OKP_PP
-#define OKP_PP 0
-#endif
 #ifndef OKP_ABL
 #define OKP_ABL 0     // timing ablations (WRONG results): 1 = no LDS-DMA in the main loop, 2 = no MFMAs, 3 = no fragment reads
 #endif
@@ -370,7 +367,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // fragment reads and the issue slots of the next LDS-DMA.  Without it every wave leaves the barrier with empty
   // fragment registers and the matrix cores idle until the first ds_reads return (all waves in lock step).
   constexpr bool XB = OKP_XB && (MT == 32 || WCO * WPX == 4);
-  constexpr bool PP = OKP_PP && MT == 16 && WCO * WPX == 8 && KB == 128;
   if constexpr (XB) {
     auto mma_half = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX], auto half) {     // first / second half of the rows
       constexpr int I0 = decltype(half)::value ? (TCO + 1) / 2 : 0;
@@ -425,52 +421,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       mma_step(fa[kk & 1], fb[kk & 1]);
     }
     mma_step(fa[L], fb[L]);
-  } else if (PP && wave >= WCO * WPX / 2) {
-    // Ping-pong (8-wave 16x16 tiles): waves 4..7 share their SIMDs with waves 0..3 and run HALF a ring step
-    // behind them - the MFMAs of a step's last k-step are issued after the barrier that opens the next step, from
-    // fragments read before it.  Out of the barrier one wave of every SIMD has MFMAs ready while the other reads its
-    // first fragments, and they keep alternating; in lock step both would read, then both would compute.
-    static_assert(!PP || KSTEPS == 2, "ping-pong loop is written for two k-steps per ring step");
-    int st_c = 0, st_i = NS - 1;
-    SliceMeta m = meta[sbase + (NS - 1 < T_ ? NS - 1 : 0) / HPS];
-    u32x4 a[TCO], b[TPX];
-    {
-      const bool more = NS - 1 < T_;
-      if (NS > 2 && NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      load_frag(st_c, 0, a, b);
-      if (more) issue_w(NS - 1, st_i);
-      mma_step(a, b);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frag(st_c, 1, a, b);
-      if (more) issue_x(NS - 1, m, st_i);
-      m = meta[sbase + (NS < T_ ? NS : T_ - 1) / HPS];
-      st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-      st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-    }
-    for (int t = 1; t < T_; ++t) {
-      const int nxt = t + NS - 1;
-      const bool more = nxt < T_;
-      __builtin_amdgcn_sched_barrier(0);
-      // my reads of the previous stage have returned (it is refilled after the barrier); step t has landed
-      if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(a, b);                              // last k-step of ring step t-1
-      __builtin_amdgcn_sched_barrier(0);           // one fragment set: the reads below reuse its registers
-      load_frag(st_c, 0, a, b);
-      if (more) issue_w(nxt, st_i);
-      mma_step(a, b);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frag(st_c, 1, a, b);
-      if (more) issue_x(nxt, m, st_i);
-      m = meta[sbase + (nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];
-      st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-      st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-    }
-    mma_step(a, b);
   } else {
     int st_c = 0, st_i = NS - 1;                   // stage being computed / stage being filled
     SliceMeta m = meta[sbase + (NS - 1 < T_ ? NS - 1 : 0) / HPS];

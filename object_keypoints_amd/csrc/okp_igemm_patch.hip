@@ -54,8 +54,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
   const int fr = lane & 15, fh = lane >> 4;
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g[0].data), 0, (int)p.g[0].bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g[1].data), 0, (int)p.g[1].bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
 
   unsigned long long clk0 = 0, rt0 = 0;
@@ -98,13 +96,13 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * 8192), 16, (int)(wbase[i] + wslice), 0, 0, 0);
     };
     // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
-    auto issue_patch = [&](int src, uint32_t c0b, int k0, int k1, int buf) {
+    auto issue_patch = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
       if (OKP_PABL & 2) return;
-      const int PW = src ? p.g[1].PW : p.g[0].PW, npx = src ? p.g[1].npx : p.g[0].npx;      // valid columns; rows x kPitch
-      const int H = src ? p.g[1].H : p.g[0].H, W = src ? p.g[1].W : p.g[0].W;
-      const int ps2 = (src ? p.g[1].pix_stride : p.g[0].pix_stride) * 2;
-      const int step = src ? p.g[1].step : p.g[0].step, cs = src ? p.g[1].conv_stride : p.g[0].conv_stride;
-      const int yb = cs * y0 + (src ? p.g[1].oy : p.g[0].oy), xb = cs * x0 + (src ? p.g[1].ox : p.g[0].ox);
+      const OkpPatchGeom& G = p.g[geom];                         // uniform index into the kernel arguments: scalar loads
+      const int PW = G.PW, npx = G.npx;                          // valid columns; rows x kPitch
+      const int H = G.H, W = G.W, ps2 = G.pix_stride * 2, step = G.step;
+      const int yb = G.conv_stride * y0 + G.oy, xb = G.conv_stride * x0 + G.ox;
+      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.data), 0, (int)G.bytes, 0x00020000);
       for (int k = k0; k < k1; ++k) {
         const int blk = k * 8 + wave;
         if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
@@ -115,8 +113,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         const bool ok = idx < npx && j < PW && ys >= 0 && ys < H && xs >= 0 && xs < W;
         const uint32_t off = ok ? (uint32_t)((n * H + ys) * W + xs) * (uint32_t)ps2 + c0b + (uint32_t)ch * 16u : kInvalidOff;
         char* const dst = smem + kLdsPatch + buf * kPatchBuf + blk * 1024;
-        if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
       }
     };
 
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 #pragma unroll
       for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_patch(p.first_src, p.first_c0b, 0, p.first_np, 0);
+    issue_patch(p.first_geom, p.first_c0b, 0, p.first_np, 0);
     issue_w(0, 0);
 
     for (int t = 0; t < p.n_steps; ++t) {
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const uint32_t tap_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[0]);
       const uint32_t nx_c0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[1]);
       const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[2]);
-      const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_src = pk >> 24;
+      const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
       const int dxo = (__builtin_amdgcn_readfirstlane((int)sv[3]) >> 8) & 0xff;      // column offset of this step's tap inside the patch
       const bool more = t + 1 < p.n_steps;
 
@@ -192,7 +189,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       mma8(a0, bq0, S2{});
       __builtin_amdgcn_sched_barrier(0);
       bq0[0] = ldb(1, 0); bq0[1] = ldb(1, 1);
-      if (nx_k1 > nx_k0) issue_patch(nx_src, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+      if (nx_k1 > nx_k0) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma8(a0, bq1, S3{});
       __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +217,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
           b[j] = *reinterpret_cast<const u32x4*>(bb + j * (kPitch * 128) + ((((uint32_t)(4 * kk + fh)) ^ bsw) << 4));
         }
         if (kk == 0 && more) issue_w(t + 1, (t + 1) & 1);
-        if (kk == 1 && nx_k1 > nx_k0) issue_patch(nx_src, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+        if (kk == 1 && nx_k1 > nx_k0) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
         if (OKP_PABL & 4) {
 #pragma unroll
           for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
@@ -331,16 +328,16 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
   OkpPatchParams p;
   std::memset(&p, 0, sizeof(p));
-  for (int s = 0; s < 2; ++s) {
-    const int ss = s < plan->n_src ? s : 0;
-    OkpPatchGeom& g = p.g[s];
+  for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
+    const int ss = plan->patch_src[gi];
+    OkpPatchGeom& g = p.g[gi];
     g.data = q.src[ss]; g.bytes = q.src_bytes[ss]; g.H = q.srcH[ss]; g.W = q.srcW[ss]; g.pix_stride = q.src_pix_stride[ss];
-    g.PW = plan->patch_PW[ss]; g.npx = 18 * plan->patch_PH[ss];
-    g.oy = plan->patch_oy[ss]; g.ox = plan->patch_ox[ss]; g.step = plan->patch_step[ss]; g.conv_stride = plan->conv_stride[ss];
+    g.PW = plan->patch_PW[gi]; g.npx = 18 * plan->patch_PH[gi];
+    g.oy = plan->patch_oy[gi]; g.ox = plan->patch_ox[gi]; g.step = plan->patch_step[gi]; g.conv_stride = plan->conv_stride[ss];
   }
   p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias;
   p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
-  p.first_src = plan->patch_first_src; p.first_np = plan->patch_first_np; p.first_c0b = plan->patch_first_c0b;
+  p.first_geom = plan->patch_first_geom; p.first_np = plan->patch_first_np; p.first_c0b = plan->patch_first_c0b;
   p.N = q.N; p.H = q.Ho; p.W = q.Wo; p.tiles_y = q.Ho / 16; p.tiles_x = q.Wo / 16;
   p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;

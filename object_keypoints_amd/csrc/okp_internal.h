@@ -75,22 +75,23 @@ struct OkpIgemmParams {
 struct OkpPatchStep {          // 16 bytes, built at plan creation
   uint32_t tap_bytes;          // byte offset of this step's tap inside the patch: ((dy - oy) * 18 + (dx - ox)) * 128 (row pitch 18 px)
   uint32_t nx_c0b;             // channel byte offset of the NEXT group's patch (prefetched during this group's steps)
-  uint8_t pbuf, nx_k0, nx_k1, nx_src;   // patch buffer of this step; passes [k0, k1) of the next patch issued in this step
-  uint8_t src, pad[3];         // source of this step's patch; pad[0] = dx - ox (the fragment swizzle is keyed on the patch column)
+  uint8_t pbuf, nx_k0, nx_k1, nx_geom;  // patch buffer of this step; passes [k0, k1) of the next patch (geometry nx_geom) issued in this step
+  uint8_t geom, tx, pad[2];    // geometry of this step's patch; tx = patch column offset of the tap (the fragment swizzle is keyed on the column)
 };
-struct OkpPatchGeom {          // patch geometry of one source
+#define OKP_PATCH_MAX_GEOM 6
+struct OkpPatchGeom {          // one patch geometry: a source + the sub-lattice / window its taps read (a stride-2 3x3 has four: the parity classes)
   const void* data; uint32_t bytes;
   int32_t H, W, pix_stride;
   int32_t PW, npx;             // valid patch columns; rows * 18 (pixels of the LDS image, pitch 18)
   int32_t oy, ox;              // offset of patch pixel (0, 0) relative to conv_stride * (tile origin)
-  int32_t step, conv_stride;   // source pixels per patch pixel (conv stride for single-tap sources, else 1)
+  int32_t step, conv_stride;   // source pixels per patch pixel (the conv stride for strided sources, else 1)
 };
 struct OkpPatchParams {
-  OkpPatchGeom g[2];
+  OkpPatchGeom g[OKP_PATCH_MAX_GEOM];
   const void* weights; uint32_t w_bytes; int32_t cout_pad, cout;
   const float* bias;
   const OkpPatchStep* steps; int32_t n_steps;
-  int32_t first_src, first_np; uint32_t first_c0b;
+  int32_t first_geom, first_np; uint32_t first_c0b;
   int32_t N, H, W, tiles_y, tiles_x;
   OkpFastDiv div_tiles_frame, div_tiles_x;
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
@@ -146,8 +147,9 @@ struct okp_conv {
   OkpSlice* slices_dev;
   // patch-resident kernel (okp_igemm_patch.hip): step table + per-source patch geometry, or patch_steps_dev == NULL
   OkpPatchStep* patch_steps_dev;
-  int32_t patch_PW[2], patch_PH[2], patch_oy[2], patch_ox[2], patch_step[2];
-  int32_t patch_first_src, patch_first_np; uint32_t patch_first_c0b;
+  int32_t patch_n_geom;
+  int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
+  int32_t patch_first_geom, patch_first_np; uint32_t patch_first_c0b;
   void* frag_dev;          // 1x1 plans used by okp_fire_chain: weights re-laid in MFMA-fragment order (built on first use)
 };
 

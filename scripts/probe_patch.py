@@ -1,18 +1,19 @@
 """Time one 3x3 convolution 256 -> 256 (bf16) with the gather tile (6) and the patch-resident kernel (13).
-usage: probe_patch.py [hw=64] [n=64] [res=0]"""
+usage: probe_patch.py [hw=64] [n=64] [res=0] [cin=256] [stride=1]   (hw = output size)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from object_keypoints_amd import ops
 from object_keypoints_amd.perception.backbone import conv_taps
-kw = dict(hw=64, n=64, res=0, cin=256)
+kw = dict(hw=64, n=64, res=0, cin=256, stride=1)
 for a in sys.argv[1:]:
     k, v = a.split("="); kw[k] = int(v)
 n, hw, cin = kw["n"], kw["hw"], kw["cin"]
 rng = np.random.default_rng(0)
 wt = (rng.standard_normal((256, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
-plan = ops.ConvPlan(torch.bfloat16, [cin], [1], 256, conv_taps(wt), np.zeros(256, np.float32), relu=True)
-x = ops.Act(torch.randn(n, hw, hw, cin, device="cuda").bfloat16())
+st = kw["stride"]
+plan = ops.ConvPlan(torch.bfloat16, [cin], [st], 256, conv_taps(wt), np.zeros(256, np.float32), relu=True)
+x = ops.Act(torch.randn(n, hw * st, hw * st, cin, device="cuda").bfloat16())
 r = ops.Act(torch.randn(n, hw, hw, 256, device="cuda").bfloat16()) if kw["res"] else None
 out = ops.Act.empty(n, hw, hw, 256, torch.bfloat16, x.t.device)
 for tile in (6, 13, 13, 6):

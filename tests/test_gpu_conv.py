@@ -305,11 +305,11 @@ def test_fire_chain_matches_module_by_module(c, h, w, n, count):
     assert float((got - single).abs().max()) <= 0.02 * scale * max(1, count // 2) + 0.02
 
 
-@pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile"])
+@pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile", "conv3x3_s2", "conv3x3_s2_odd_input"])
 def test_patch_resident_kernel_matches_gather_kernel(case):
     """Tile 13 (okp_igemm_patch: input patch + halo resident in LDS) against torch AND bit-for-bit against tile 6 (same
     K order, same MFMA shape => identical sums): zero padding on all four edges, residual read through a channel window,
-    the stride-2 single-tap second source, several channel chunks."""
+    the stride-2 single-tap second source, several channel chunks, stride-2 3x3 (parity-class patches)."""
     from object_keypoints_amd import ops
     from object_keypoints_amd.perception.backbone import conv_taps
     dev = _dev()
@@ -328,6 +328,16 @@ def test_patch_resident_kernel_matches_gather_kernel(case):
             ref = ref + r[:, 32:288]
             res = ops.Act.from_nchw(r.to(dev), dtype).slice(32, 256)
         ref = F.relu(ref)
+    elif case in ("conv3x3_s2", "conv3x3_s2_odd_input"):
+        # stride 2: four patch geometries (the parity classes of the taps), 17x17 ... 16x16 pixels with a pixel step of 2
+        n, h, w = 2, 32, 48
+        hi, wi = (2 * h, 2 * w) if case == "conv3x3_s2" else (2 * h - 1, 2 * w - 1)
+        cin = 256 if case == "conv3x3_s2" else 128
+        x = rb(_rand((n, cin, hi, wi), 36)); wt = rb(_rand((256, cin, 3, 3), 37) / np.sqrt(cin * 9)); b = _rand((256,), 38) * 0.1
+        ref = F.relu(F.conv2d(x, wt, b, stride=2, padding=1))
+        assert ref.shape[2:] == (h, w)
+        plan = ops.ConvPlan(dtype, [cin], [2], 256, conv_taps(wt.numpy()), b.numpy(), relu=True)
+        srcs = [ops.Act.from_nchw(x.to(dev), dtype)]
     elif case == "residual_s2_skip":
         n, h, w = 2, 32, 32
         t = rb(_rand((n, 256, h, w), 25)); x = rb(_rand((n, 128, 2 * h, 2 * w), 26))
