@@ -178,7 +178,7 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
   // geometry is loaded once and serves all its taps (consecutive K-steps).
   std::vector<OkpPatchStep> psteps;
   {
-    bool ok = patch_ok && plan->n_slices <= 256;
+    bool ok = patch_ok && plan->n_slices <= 256 && cin[0] <= 255 * 64 && (n_src < 2 || cin[1] <= 255 * 64);
     struct Group { int geom, c0, first, n; };
     std::vector<Group> groups;
     for (int si = 0; si < plan->n_slices && ok; ++si) {
@@ -201,6 +201,8 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
           OkpPatchStep st{};
           st.tap_bytes = (uint32_t)((tap_ty[sl.tap_lo] * 18 + tap_tx[sl.tap_lo]) * 128);
           st.tx = (uint8_t)tap_tx[sl.tap_lo];
+          st.c0q = (uint8_t)(G.c0 / 64);
+          st.grp_last = (uint8_t)(G.first + G.n - 1);
           st.pbuf = (uint8_t)(gi & 1);
           st.geom = (uint8_t)G.geom;
           st.nx_k0 = (uint8_t)std::min(np, i * per); st.nx_k1 = (uint8_t)std::min(np, (i + 1) * per);
@@ -209,7 +211,6 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
           psteps[G.first + i] = st;
         }
       }
-      plan->patch_first_geom = groups[0].geom; plan->patch_first_np = passes(groups[0].geom); plan->patch_first_c0b = (uint32_t)(groups[0].c0 * 2);
     } else {
       psteps.clear();
     }
@@ -337,8 +338,11 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
 static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
   const int tile = okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
   static const bool patch_on = [] { const char* e = getenv("OKP_PATCH"); return !(e && e[0] == '0'); }();   // OKP_PATCH=0: A/B against the gather tile
-  if (patch_on && tile == 6 && plan->patch_steps_dev && plan->n_taps > plan->patch_n_geom && a->n_classes <= 1 && !a->dw_w_dev && a->out_step == 1 &&
-      a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo && a->ho % 16 == 0 && a->wo % 16 == 0) {
+  const int ncls = a->n_classes > 1 ? a->n_classes : 1;
+  const bool dense1 = ncls == 1 && a->out_step == 1 && a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo;
+  const long patch_tiles = (long)ncls * a->n * (a->ho / 16) * (a->wo / 16) * (plan->cout_pad / 256);
+  if (patch_on && plan->patch_steps_dev && plan->n_taps > plan->patch_n_geom && !a->dw_w_dev && a->ho % 16 == 0 && a->wo % 16 == 0 &&
+      ((tile == 6 && dense1) || (ncls == 4 && patch_tiles >= 256))) {
     bool ok = true;
     for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s];
     if (ok) return 13;

@@ -26,6 +26,8 @@
 //    3 x 6 window), weights in registers for the duration of the phase.
 #include <cstring>
 
+#include <cstdlib>
+
 #include "okp_internal.h"
 
 namespace {
@@ -441,8 +443,10 @@ int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
   // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
   long best = -1;
+  static const int force_ih = [] { const char* e = getenv("OKP_FIRE2_IH"); return e ? atoi(e) : 0; }();   // experiment knob
   for (int ih = 1; ih <= p.Ho && ih <= MAXIH; ++ih)
     for (int iw = 1; iw <= p.Wo && iw <= 96; ++iw) {
+      if (force_ih && ih != force_ih && force_ih <= p.Ho) continue;
       const int sh = stride * (ih - 1) + 3, sw = stride * (iw - 1) + 3;
       if (sh * sw > SP || ih * iw > 16 * PBI) continue;
       const long ty = (p.Ho + ih - 1) / ih, tx = (p.Wo + iw - 1) / iw;

@@ -69,8 +69,11 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos)
     const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
-    const int co_tile = tile % p.n_co_tiles;
-    const int px_tile = tile / p.n_co_tiles;
+    const int cls = tile / p.tiles_per_class;                  // sub-pixel class (0 unless n_classes == 4)
+    const int tile_c = tile - cls * p.tiles_per_class;
+    const int t0 = cls * p.steps_per_class, t1 = t0 + p.steps_per_class;      // this class's K-steps
+    const int co_tile = tile_c % p.n_co_tiles;
+    const int px_tile = tile_c / p.n_co_tiles;
     const int n = fastdiv(px_tile, p.div_tiles_frame);
     const int trem = px_tile - n * p.tiles_y * p.tiles_x;
     const int tyi = fastdiv(trem, p.div_tiles_x);
@@ -123,17 +126,24 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 #pragma unroll
       for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_patch(p.first_geom, p.first_c0b, 0, p.first_np, 0);
-    issue_w(0, 0);
+    {                                              // the first patch of the class: geometry / chunk / buffer of step t0
+      const u32x4 s0 = *reinterpret_cast<const u32x4*>(steps_lds + t0 * 16);
+      const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0[3]);
+      const int g0 = w3 & 0xff;
+      issue_patch(g0, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g0].npx + 63) >> 6, __builtin_amdgcn_readfirstlane((int)s0[2]) & 0xff);
+    }
+    issue_w(t0, t0 & 1);
 
-    for (int t = 0; t < p.n_steps; ++t) {
+    for (int t = t0; t < t1; ++t) {
       const u32x4 sv = *reinterpret_cast<const u32x4*>(steps_lds + t * 16);
       const uint32_t tap_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[0]);
       const uint32_t nx_c0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[1]);
       const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[2]);
       const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
-      const int dxo = (__builtin_amdgcn_readfirstlane((int)sv[3]) >> 8) & 0xff;      // column offset of this step's tap inside the patch
-      const bool more = t + 1 < p.n_steps;
+      const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[3]);
+      const int dxo = (w3 >> 8) & 0xff;                            // column offset of this step's tap inside the patch
+      const bool more = t + 1 < t1;
+      const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
 
       if (!(OKP_PABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my part of step t's weights (and of its patch) has landed
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       mma8(a0, bq0, S2{});
       __builtin_amdgcn_sched_barrier(0);
       bq0[0] = ldb(1, 0); bq0[1] = ldb(1, 1);
-      if (nx_k1 > nx_k0) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+      if (next_patch) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma8(a0, bq1, S3{});
       __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
           b[j] = *reinterpret_cast<const u32x4*>(bb + j * (kPitch * 128) + ((((uint32_t)(4 * kk + fh)) ^ bsw) << 4));
         }
         if (kk == 0 && more) issue_w(t + 1, (t + 1) & 1);
-        if (kk == 1 && nx_k1 > nx_k0) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+        if (kk == 1 && next_patch) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
         if (OKP_PABL & 4) {
 #pragma unroll
           for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         const int it = tid + (ub + u) * 512;
         const int q = it & 31, prow = it >> 5;
         const int co = co0 + q * 8;
-        const uint32_t opix = (uint32_t)((n * p.H + y0 + (prow >> 4)) * p.W + x0 + (prow & 15));
+        const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
         ooff[u] = co < p.cout ? opix : kInvalidOff;
       }
       if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
   if (!plan->patch_steps_dev || plan->dtype != OKP_BF16) return false;
-  if (p.n_classes != 1 || p.dw_w || p.out_step != 1 || p.OH != p.Ho || p.OW != p.Wo || p.out_oy || p.out_ox) return false;
+  if ((p.n_classes != 1 && p.n_classes != 4) || p.dw_w) return false;     // (okp_conv_forward has checked that the output grid fits)
   if (p.Ho % 16 || p.Wo % 16) return false;
   for (int s = 0; s < plan->n_src; ++s) {
     // the patch of output block (y0, x0) starts at conv_stride * (y0, x0) + (oy, ox) in the source: the source must be
@@ -337,13 +347,15 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   }
   p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias;
   p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
-  p.first_geom = plan->patch_first_geom; p.first_np = plan->patch_first_np; p.first_c0b = plan->patch_first_c0b;
+  p.n_classes = q.n_classes; p.steps_per_class = plan->n_slices / q.n_classes;
+  p.OH = q.OH; p.OW = q.OW; p.out_step = q.out_step; p.out_oy = q.out_oy; p.out_ox = q.out_ox;
   p.N = q.N; p.H = q.Ho; p.W = q.Wo; p.tiles_y = q.Ho / 16; p.tiles_x = q.Wo / 16;
   p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
   p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
   p.n_co_tiles = q.cout_pad / 256;
-  p.n_tiles = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
+  p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
+  p.n_tiles = p.tiles_per_class * p.n_classes;
   const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
   static unsigned long long* dbg = [] {
     unsigned long long* d = nullptr;

@@ -76,7 +76,8 @@ struct OkpPatchStep {          // 16 bytes, built at plan creation
   uint32_t tap_bytes;          // byte offset of this step's tap inside the patch: ((dy - oy) * 18 + (dx - ox)) * 128 (row pitch 18 px)
   uint32_t nx_c0b;             // channel byte offset of the NEXT group's patch (prefetched during this group's steps)
   uint8_t pbuf, nx_k0, nx_k1, nx_geom;  // patch buffer of this step; passes [k0, k1) of the next patch (geometry nx_geom) issued in this step
-  uint8_t geom, tx, pad[2];    // geometry of this step's patch; tx = patch column offset of the tap (the fragment swizzle is keyed on the column)
+  uint8_t geom, tx, c0q, grp_last;   // geometry of this step's patch; tx = patch column offset of the tap (the fragment swizzle is keyed on
+                               // the column); c0q = first channel / 64 of the step's chunk; grp_last = last step of its (chunk, geometry) group
 };
 #define OKP_PATCH_MAX_GEOM 6
 struct OkpPatchGeom {          // one patch geometry: a source + the sub-lattice / window its taps read (a stride-2 3x3 has four: the parity classes)
@@ -91,8 +92,9 @@ struct OkpPatchParams {
   const void* weights; uint32_t w_bytes; int32_t cout_pad, cout;
   const float* bias;
   const OkpPatchStep* steps; int32_t n_steps;
-  int32_t first_geom, first_np; uint32_t first_c0b;
-  int32_t N, H, W, tiles_y, tiles_x;
+  int32_t N, H, W, tiles_y, tiles_x;            // H x W = GEMM pixel grid (Ho x Wo)
+  int32_t n_classes, steps_per_class, tiles_per_class;   // sub-pixel classes of a transposed convolution (1 otherwise)
+  int32_t OH, OW, out_step, out_oy, out_ox;     // GEMM pixel (y, x) of class c -> output pixel (y * out_step + out_oy + (c >> 1), x * out_step + out_ox + (c & 1))
   OkpFastDiv div_tiles_frame, div_tiles_x;
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
@@ -149,7 +151,6 @@ struct okp_conv {
   OkpPatchStep* patch_steps_dev;
   int32_t patch_n_geom;
   int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
-  int32_t patch_first_geom, patch_first_np; uint32_t patch_first_c0b;
   void* frag_dev;          // 1x1 plans used by okp_fire_chain: weights re-laid in MFMA-fragment order (built on first use)
 };
 

@@ -375,3 +375,32 @@ def test_patch_resident_kernel_refuses_other_shapes():
     out = ops.Act.empty(1, 20, 16, 256, torch.bfloat16, dev)
     with pytest.raises(RuntimeError, match="tile 13"):
         plan([x], out, 20, 16, tile=13)                      # height not a multiple of 16
+
+
+@pytest.mark.parametrize("h,w", [(32, 16), (16, 16)])
+def test_patch_resident_kernel_transposed_conv_classes(h, w):
+    """The 4x4/s2 transposed convolution + hourglass merge as four sub-pixel classes of the patch-resident kernel (each class
+    = 2x2 taps of the shared 18x18 patch, written at its output parity with `up1` added): against torch and bit-for-bit
+    against the gather tile."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    dev = _dev()
+    n, c = 2, 256
+    m = bb.unpool_merge(c).eval()
+    with torch.no_grad():
+        m.weight.copy_(_rand((c, c, 4, 4), 40) / np.sqrt(4 * c)); m.bias.copy_(_rand((c,), 41) * 0.1)
+    low = _rand((n, c, h, w), 42).bfloat16().float(); up1 = _rand((n, c, 2 * h, 2 * w), 43).bfloat16().float()
+    wq = m.weight.detach().bfloat16().float()
+    ref = up1 + F.conv_transpose2d(low, wq, m.bias.detach(), stride=2, padding=1)
+    la, ua = ops.Act.from_nchw(low.to(dev), torch.bfloat16), ops.Act.from_nchw(up1.to(dev), torch.bfloat16)
+    outs = {}
+    keep = bb.UNPOOL_TILE
+    try:
+        for tile in (6, 13):
+            bb.UNPOOL_TILE = tile
+            outs[tile] = m(la, ua).t.float().cpu()
+    finally:
+        bb.UNPOOL_TILE = keep
+    got = outs[13].permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= _tol(torch.bfloat16, ref)
+    assert torch.equal(outs[13], outs[6])
