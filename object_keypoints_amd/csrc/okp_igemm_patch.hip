@@ -9,8 +9,17 @@
 // the block's input patch INCLUDING its halo (18x18 pixels x 128 bytes = 40.5 KiB) is copied to LDS once, by LDS-DMA,
 // while the previous chunk is being multiplied; the nine taps of the chunk are then nine K-steps whose pixel fragments
 // are read from that patch at a tap-dependent offset.  Per K-step the workgroup now streams 32 KiB of weights + 4.5 KiB
-// of pixels instead of 64 KiB.  A strided single-tap source (the projected 1x1 skip of `residual`) is a 16x16 patch with
-// a pixel step.  Out-of-image patch pixels get an out-of-range buffer offset: the LDS-DMA writes zeros (zero padding).
+// of pixels instead of 64 KiB (4.7 instead of 8 LDS-DMA instructions per wave: each costs the SIMD ~70 clocks, whether or
+// not it is waited for).  Out-of-image patch pixels get an out-of-range buffer offset: the LDS-DMA writes zeros (padding).
+//
+// A patch is described by a GEOMETRY (OkpPatchGeom: source, origin, rows x columns, pixel step), a K-step by its tap's
+// offset inside the patch (OkpPatchStep, built at plan creation in okp_api.hip):
+//   * stride-1 3x3: one 18x18 geometry per source;
+//   * a strided single-tap source (the projected 1x1 skip of `residual`): 16x16 with the conv stride as pixel step;
+//   * stride-2 3x3: four geometries = the parity classes of (dy, dx), 17x17 / 17x16 / 16x17 / 16x16 with pixel step 2;
+//   * 4x4/s2 transposed convolution + merge add: four sub-pixel CLASSES (tile = class x block), each 2x2 taps of the same
+//     18x18 geometry, written at output pixel (2 y + cy, 2 x + cx) with `up1` as the residual.
+// K order and MFMA shape are those of the 256x256 gather tile (code 6), so the results are bit-identical to it.
 //
 // LDS: weights ring 2 x 32 KiB | patch buffers 2 x 41 KiB | step table 4 KiB | bias 1 KiB  = 151 KiB, one workgroup
 // (8 waves, 4 x 2, wave tile 64 channels x 128 pixels on 16x16x32 MFMAs) per CU; the epilogue stages the bf16 tile in
