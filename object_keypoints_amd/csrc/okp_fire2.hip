@@ -30,6 +30,10 @@
 
 #include "okp_internal.h"
 
+#ifndef OKP_FABL
+#define OKP_FABL 0     // timing ablations (WRONG results): 1 no x LDS-DMA, 2 no phase-1 MFMAs, 4 no phase-2a MFMAs, 8 no depth-wise FMAs, 16 no skip loads, 32 no stores
+#endif
+
 namespace {
 
 constexpr uint32_t kInvalid = 0x80000000u;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     }
   };
   auto issue_x = [&](int ks, int stage) {
+    if (OKP_FABL & 1) return;
 #pragma unroll
     for (int i = 0; i < NDM; ++i)
       if (UNI || i < nd)
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
         oo[iy] = ok ? oof : kInvalid;
         rr[iy] = u32x4{0u, 0u, 0u, 0u};
-        if (p.skip) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
+        if (p.skip && !(OKP_FABL & 16)) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
         xo += (uint32_t)(p.W * p.x_ps * 2);
         oof += (uint32_t)(p.Wo * p.out_ps * 2);
       }
@@ -255,7 +260,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       for (int pb = 0; pb < SP / 16; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[RES ? ks : ks % 3][b]),
+          if (OKP_FABL & 2) asm volatile("" ::"v"(a[pb]), "v"(w1f[RES ? ks : ks % 3][b]));
+          else acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[RES ? ks : ks % 3][b]),
                                                                acc[pb][b], 0, 0, 0);
     }
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         for (int r = 0; r < 4; ++r) {
           o_off[pb][r] = orr[r] == kInvalid ? kInvalid : ob + orr[r];
           r_raw[pb][r] = 0;
-          if (p.skip && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
+          if (p.skip && !(OKP_FABL & 16) && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
         }
       }
       f32x4 ac2[PBI][2];
@@ -327,7 +333,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_S + a_row[pb] + (((uint32_t)(4 * ks + qt) ^ a_key[pb]) << 4));
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              ac2[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, waf[b][ks]),
+              if (OKP_FABL & 4) asm volatile("" ::"v"(a), "v"(waf[b][ks]));
+              else ac2[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, waf[b][ks]),
                                                                    ac2[pb][b], 0, 0, 0);
           }
         }
@@ -341,7 +348,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             bf16x2 v;
             v[0] = (__bf16)fmaxf(ac2[pb][0][r] + (float)rv[0], 0.f);
             v[1] = (__bf16)fmaxf(ac2[pb][1][r] + (float)rv[1], 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)o_off[pb][r], 0, 0);
+            if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)o_off[pb][r], 0, 0);
+            else asm volatile("" ::"v"(v));
           }
         }
       }
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           }
 #pragma unroll
           for (int sr = 0; sr < STR * (MAXIH - 1) + 3; ++sr) {   // squeeze row sr is tap row dy of output row (sr - dy) / STR
-            if (sr < STR * (p.IH - 1) + 3) {
+            if (!(OKP_FABL & 8) && sr < STR * (p.IH - 1) + 3) {
               const int sp = sr * p.SW + STR * ixc + dx;
               const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
               f32x2 s2[4];
@@ -419,7 +427,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             pk[0] = (__bf16)lo; pk[1] = (__bf16)hi;
             o[e] = __builtin_bit_cast(uint32_t, pk);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
+          if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
+          else asm volatile("" ::"v"(o));
         }
       }
     }
