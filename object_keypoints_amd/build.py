@@ -45,12 +45,17 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    if _stale(obj, [src] + _deps()):
-        extra = [] if os.path.basename(src) in AGPR_FILES else VGPR_FORM
-        cmd = [HIPCC] + CFLAGS + extra + os.environ.get("OKP_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
+    extra = [] if os.path.basename(src) in AGPR_FILES else VGPR_FORM
+    flags = CFLAGS + extra + os.environ.get("OKP_EXTRA_CFLAGS", "").split()
+    stamp = obj + ".flags"                      # an object built with other flags (experiment switches) is stale
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    if not same_flags or _stale(obj, [src] + _deps()):
+        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags))
         return obj, True, r.stderr
     return obj, False, ""
 
