@@ -9,9 +9,11 @@
 // pointwise output kernel) the 384- and 96-channel intermediates make a round trip through HBM (201 + 50 MB written
 // and read per 64 frames against 134 MB of input); here they live in LDS.
 //
-// A workgroup (4 waves) owns 64 consecutive pixels.  Its x tile (64 x 512 B) is fetched once by LDS-DMA; per head,
-// GEMM 1 runs on 16x16x32 MFMAs with pixels as rows and wave w owning channels [32 w, 32 w + 32) of the head (weight
-// fragments streamed from the fragment-ordered copy of the plan, okp_ensure_frags), the result goes to LDS as bf16;
+// A workgroup (4 waves) serves ONE head for its tiles of 64 consecutive pixels; the three workgroups of a tile are
+// neighbours in the grid and share the tile's x lines in L2.  The x tile (64 x 512 B) is fetched by LDS-DMA;
+// GEMM 1 runs on 16x16x32 MFMAs with pixels as rows and wave w owning channels [32 w, 32 w + 32) of the head, its weight
+// fragments RESIDENT in registers for the whole launch (read once from the fragment-ordered copy of the plan,
+// okp_ensure_frags; streaming them per tile cost 216 KB of L2 traffic per 64 pixels), the result goes to LDS as bf16;
 // GEMM 2 (K = 128, 32 output channels) gives each wave one 16-pixel block; the last layer is a 32-term dot product per
 // (pixel, output) on the vector ALUs with pixels along the lanes, so the NCHW stores are contiguous.
 #include <cstring>
@@ -71,7 +73,21 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
     d_chunk[i] = (uint32_t)(((lin & 31) ^ (d_row[i] & 15)) << 4);      // the chunk the read-side swizzle expects there
   }
 
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+  // A workgroup serves ONE head (blockIdx.x % 3) for its tiles, so that head's GEMM-1 and GEMM-2 weight fragments stay in
+  // registers for the whole launch (64 + 8 VGPRs) instead of being re-streamed from L2 for every 64-pixel tile (216 KB
+  // per tile and workgroup, 885 MB per 64 frames); the three workgroups of a tile run side by side and share its x lines in L2.
+  const int h = blockIdx.x % 3;
+  auto frag1 = [&](int ks, int b) { return static_cast<const u32x4*>(p.w1)[(size_t)(((4 * h + w) * 2 + b) * KS1 + ks) * 64 + lane]; };
+  auto frag2 = [&](int kk, int b) { return static_cast<const u32x4*>(p.w2)[(size_t)((h * 2 + b) * (3 * KS2) + KS2 * h + kk) * 64 + lane]; };
+  u32x4 wf[KS1][2], wg[KS2][2];
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) { wf[ks][0] = frag1(ks, 0); wf[ks][1] = frag1(ks, 1); }
+#pragma unroll
+  for (int kk = 0; kk < KS2; ++kk) { wg[kk][0] = frag2(kk, 0); wg[kk][1] = frag2(kk, 1); }
+  const float b1a = p.b1[F * h + ch0], b1b = p.b1[F * h + ch0 + 1];
+  const float b2a = p.b2[F2 * h + 2 * l16], b2b = p.b2[F2 * h + 2 * l16 + 1];
+
+  for (int tile = blockIdx.x / 3; tile < p.n_tiles; tile += gridDim.x / 3) {
     const long pix0 = (long)tile * TP;
     __syncthreads();                                // the previous tile's readers of x / h2 are done; w3 is in LDS
 #pragma unroll
@@ -80,35 +96,24 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
       const uint32_t off = pix < p.n_pix ? (uint32_t)pix * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + OFF_X + (8 * w + i) * 1024), 16, (int)off, 0, 0, 0);
     }
-    // head 0's first weight fragments travel with the x tile
-    constexpr int PF = 4;
-    auto frag1 = [&](int h, int ks, int b) { return static_cast<const u32x4*>(p.w1)[(size_t)(((4 * h + w) * 2 + b) * KS1 + ks) * 64 + lane]; };
-    auto frag2 = [&](int h, int kk, int b) { return static_cast<const u32x4*>(p.w2)[(size_t)((h * 2 + b) * (3 * KS2) + KS2 * h + kk) * 64 + lane]; };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-#pragma unroll 1
-    for (int h = 0; h < 3; ++h) {
+    {
       // ---- GEMM 1: h1[64 px][128] = relu(W1_h x + b1_h) ------------------------------------------------------
       {
-        const float b0 = p.b1[F * h + ch0], b1 = p.b1[F * h + ch0 + 1];
         f32x4 acc[4][2];
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) { acc[pb][0] = f32x4{b0, b0, b0, b0}; acc[pb][1] = f32x4{b1, b1, b1, b1}; }
-        u32x4 wf[PF][2];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) { wf[i][0] = frag1(h, i, 0); wf[i][1] = frag1(h, i, 1); }
+        for (int pb = 0; pb < 4; ++pb) { acc[pb][0] = f32x4{b1a, b1a, b1a, b1a}; acc[pb][1] = f32x4{b1b, b1b, b1b, b1b}; }
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
           u32x4 a[4];
 #pragma unroll
           for (int pb = 0; pb < 4; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + OFF_X + xoff(16 * pb + l16, 4 * ks + q, CIN * 2));
-          const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
-          if (ks + PF < KS1) { wf[ks % PF][0] = frag1(h, ks + PF, 0); wf[ks % PF][1] = frag1(h, ks + PF, 1); }
 #pragma unroll
           for (int pb = 0; pb < 4; ++pb) {
-            acc[pb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc[pb][0], 0, 0, 0);
-            acc[pb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc[pb][1], 0, 0, 0);
+            acc[pb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, wf[ks][0]), acc[pb][0], 0, 0, 0);
+            acc[pb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, wf[ks][1]), acc[pb][1], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -124,13 +129,12 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
       __syncthreads();
       // ---- GEMM 2: h2[64 px][32] = relu(W2_h h1 + b2_h); wave w takes pixel block w ---------------------------------
       {
-        const float b0 = p.b2[F2 * h + 2 * l16], b1 = p.b2[F2 * h + 2 * l16 + 1];
-        f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+        f32x4 acc0 = {b2a, b2a, b2a, b2a}, acc1 = {b2b, b2b, b2b, b2b};
 #pragma unroll
         for (int kk = 0; kk < KS2; ++kk) {
           const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_H1 + xoff(16 * w + l16, 4 * kk + q, F * 2));
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, frag2(h, kk, 0)), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, frag2(h, kk, 1)), acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wg[kk][0]), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wg[kk][1]), acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -160,8 +164,6 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
           }
         }
       }
-      // (the next head's GEMM 1 writes h1 only: its readers, GEMM 2 above, are behind the barrier that follows GEMM 2;
-      //  h2 is rewritten after the next two barriers)
     }
   }
 }
@@ -194,7 +196,7 @@ extern "C" int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const o
   const long tiles = (p.n_pix + TP - 1) / TP;
   if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_heads_forward: too many pixels"); return OKP_EINVAL; }
   p.n_tiles = (int)tiles;
-  const int resident = 256 * 2;
-  hipLaunchKernelGGL(okp_heads_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(256), 0, (hipStream_t)stream, p);
+  const long groups = tiles < 170 ? tiles : 170;            // 3 x 170 = 510 workgroups: two per CU, whole head triples
+  hipLaunchKernelGGL(okp_heads_kernel, dim3((unsigned)(3 * groups)), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_heads launch");
 }
