@@ -35,7 +35,7 @@
 #define OKP_PPIPE 1
 #endif
 #ifndef OKP_PABL
-#define OKP_PABL 0    // timing ablations (WRONG results): bit 0 = no weight DMA, bit 1 = no patch DMA, bit 2 = no MFMAs, bit 3 = DMA never waited for
+#define OKP_PABL 0    // timing ablations (WRONG results): bit 0 = no weight DMA, bit 1 = no patch DMA, bit 2 = no MFMAs, bit 3 = DMA never waited for, bit 4 = no epilogue
 #endif
 
 namespace {
@@ -255,6 +255,13 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
 
     // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
+    if (OKP_PABL & 16) {
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) asm volatile("" ::"v"(acc[i][j]));
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
       const int co_l = (wco * TCO + i) * 16 + 4 * fh;
