@@ -30,6 +30,9 @@
 
 #include "okp_internal.h"
 
+#ifndef OKP_FIRE2_XCD
+#define OKP_FIRE2_XCD 1
+#endif
 #ifndef OKP_FABL
 #define OKP_FABL 0     // timing ablations (WRONG results): 1 no x LDS-DMA, 2 no phase-1 MFMAs, 4 no phase-2a MFMAs, 8 no depth-wise FMAs, 16 no skip loads, 32 no stores
 #endif
@@ -161,7 +164,12 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   const int m_sy = tid < p.SH * p.SW ? fastdiv(tid, p.div_sw) : (1 << 20);
   const int m_sx = tid - fastdiv(tid, p.div_sw) * p.SW;
 
-  auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+  auto tile_origin = [&](int slot, int& n, int& y0, int& x0) {
+    // XCD-aware order (as in okp_igemm_kernel): workgroups are dealt round-robin over the 8 XCDs, so slots with equal
+    // slot % 8 share an L2; give each XCD a contiguous range of tiles - vertically adjacent tiles (tile +- tiles_x) then
+    // find each other's halo rows in that L2 instead of fetching them into two.  Bijective for any tile count.
+    const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
+    const int tile = OKP_FIRE2_XCD ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3) : slot;
     n = fastdiv(tile, p.div_tiles_frame);
     const int trem = tile - n * p.tiles_y * p.tiles_x;
     const int ty = fastdiv(trem, p.div_tiles_x);
