@@ -76,7 +76,13 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
   // A workgroup serves ONE head (blockIdx.x % 3) for its tiles, so that head's GEMM-1 and GEMM-2 weight fragments stay in
   // registers for the whole launch (64 + 8 VGPRs) instead of being re-streamed from L2 for every 64-pixel tile (216 KB
   // per tile and workgroup, 885 MB per 64 frames); the three workgroups of a tile run side by side and share its x lines in L2.
-  const int h = blockIdx.x % 3;
+  // grid = 24 m workgroups: workgroup g runs on XCD g % 8 (round-robin dispatch); the three heads of a tile are given to
+  // workgroups g, g + 8, g + 16 of the same XCD, so the tile's x lines are fetched into ONE L2 instead of three.
+  // (Smaller grids, for fewer tiles than resident groups, use the plain g % 3 order.)
+  const bool xcd_order = gridDim.x % 24 == 0;
+  const int gm = blockIdx.x >> 3;
+  const int h = xcd_order ? gm % 3 : (int)(blockIdx.x % 3);
+  const int tile0 = xcd_order ? (gm / 3) * 8 + (int)(blockIdx.x & 7) : (int)(blockIdx.x / 3);
   auto frag1 = [&](int ks, int b) { return static_cast<const u32x4*>(p.w1)[(size_t)(((4 * h + w) * 2 + b) * KS1 + ks) * 64 + lane]; };
   auto frag2 = [&](int kk, int b) { return static_cast<const u32x4*>(p.w2)[(size_t)((h * 2 + b) * (3 * KS2) + KS2 * h + kk) * 64 + lane]; };
   u32x4 wf[KS1][2], wg[KS2][2];
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
   const float b1a = p.b1[F * h + ch0], b1b = p.b1[F * h + ch0 + 1];
   const float b2a = p.b2[F2 * h + 2 * l16], b2b = p.b2[F2 * h + 2 * l16 + 1];
 
-  for (int tile = blockIdx.x / 3; tile < p.n_tiles; tile += gridDim.x / 3) {
+  for (int tile = tile0; tile < p.n_tiles; tile += gridDim.x / 3) {
     const long pix0 = (long)tile * TP;
     __syncthreads();                                // the previous tile's readers of x / h2 are done; w3 is in LDS
 #pragma unroll
@@ -196,7 +202,7 @@ extern "C" int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const o
   const long tiles = (p.n_pix + TP - 1) / TP;
   if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_heads_forward: too many pixels"); return OKP_EINVAL; }
   p.n_tiles = (int)tiles;
-  const long groups = tiles < 170 ? tiles : 170;            // 3 x 170 = 510 workgroups: two per CU, whole head triples
+  const long groups = tiles < 168 ? tiles : 168;            // 3 x 168 = 504 = 24 x 21 workgroups: two per CU, whole head triples per XCD
   hipLaunchKernelGGL(okp_heads_kernel, dim3((unsigned)(3 * groups)), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_heads launch");
 }
