@@ -2,47 +2,105 @@
 """Benchmark of the keypoint-inference hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one batch of synthetic 511x511 frames already resident in
-HBM: frame packing -> CornerNet-Squeeze hourglass + heads (HIP implicit-GEMM convs) -> per-map
-peak-NMS -> per-peak depth lifting to 3D -> (N>1) ONE all-gather of the fixed-capacity 3D-keypoint
-tensor.  Workload = BASELINE.json configs[2]: batch 64 per GPU, bf16 activations/weights with fp32
-accumulation, K=3 maps (config/valve.json).  Frames shard across ranks (weak scaling, weights
-replicated); value = frames of all ranks / max-over-ranks time.
+N > 1 without a torchrun environment: this process never touches the GPU; it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` as a child (one rank
+per GPU over RCCL), relays rank 0's JSON line and exits with the child's code.  Under torchrun (WORLD_SIZE set)
+the process is a rank and runs the benchmark directly.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the bf16 256x256-tile implicit-GEMM
-instantiation, timed live with HIP events on the launch stream during the timed steps) and
-`cpu_baseline` (the oracle: torch-CPU fp32 restatement + NumPy post-processing on the host cores,
-N=1 only, bounded sample).
+One step = one pass of the hot path over one batch of synthetic 511x511 frames already resident in HBM:
+fp32 NCHW frames -> stem -> CornerNet-Squeeze hourglass + heads (HIP implicit-GEMM convs) -> per-map peak-NMS ->
+per-peak depth lifting to 3D -> object grouping -> (N>1) ONE all-gather of the fixed-capacity 3D-keypoint tensor.
+Workload = BASELINE.json configs[2]: batch 64 per GPU, bf16 activations/weights with fp32 accumulation, K=3 maps
+(config/valve.json).  Frames shard across ranks (weak scaling, weights replicated); value = frames of all ranks /
+max-over-ranks time.  Random-weight networks give flat heat maps, so the stages after the heads are measured on
+injected Gaussian-bump scenes (`synth.bump_scene`, 1-2 objects per frame, seed-indexed per global
+frame); the network itself runs in full on the frames in every step.
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (the patch-resident 3x3 implicit-GEMM kernel), timed
+live with HIP events on the launch stream during the timed steps; `cpu_baseline` = the oracle (torch-CPU fp32
+restatement + NumPy post-processing) on the host cores, N=1 only, bounded sample.  At N=1 the line also carries `fp32`
+(BASELINE configs[1] precision: the path that meets the 1e-3 heat-map bar) and `fp16` (configs[4] precision) objects,
+each {value, ms_per_step, roofline, heat_err_vs_oracle}; `heat_err_vs_oracle` is the measured |heat - oracle heat| on
+the cpu_baseline's frames for that precision.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 GFLOP_PER_FRAME = 74.565218304          # 37 282 609 152 MACs x 2 (SURVEY.md §8(d), deployed path, K=3)
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+ERR_FRAMES = 4                          # frames of the cpu_baseline sample on which every precision is compared with the oracle
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16", help="precision of the headline line")
+    ap.add_argument("--extra-dtypes", default="f32,f16", help="N=1: further precisions reported as extra objects ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (tests)")
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks (no GPU call happens in this process)
+# --------------------------------------------------------------------------------------------------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(args, argv, port):
+    child_args = [a for a in argv if a != "--spawn"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py")] + child_args
+
+
+def needs_launcher(args, environ):
+    return "WORLD_SIZE" not in environ and (args.gpus > 1 or args.spawn)
+
+
+def self_launch(args, argv, device_count, popen=subprocess.Popen, out=sys.stdout, err=sys.stderr):
+    """Start the ranks as a child process, relay rank 0's JSON line, return the exit code.  `device_count` is
+    torch.cuda.device_count() (counting devices does not initialise the GPU)."""
+    if device_count < args.gpus:
+        print(f"bench.py --gpus {args.gpus} needs {args.gpus} devices, {device_count} visible", file=err)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    proc = popen(launcher_command(args, argv, free_port()), stdout=subprocess.PIPE, text=True, env=env)
+    relayed = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            out.write(line)
+            out.flush()
+            relayed += 1
+        else:
+            err.write(line)
+    rc = proc.wait()
+    if rc == 0 and relayed != 1:
+        print(f"launcher: expected one JSON line from rank 0, got {relayed}", file=err)
+        return 3
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------
+# rank body
+# --------------------------------------------------------------------------------------------------
 
 class KernelTimer:
     """ops.LAUNCH_HOOK: brackets launches of ONE implicit-GEMM instantiation with HIP events recorded on
@@ -54,6 +112,7 @@ class KernelTimer:
         self.enabled = False
 
     def before(self, plan, tile, macs):
+        import torch
         if not self.enabled or (plan.dtype, tile) != self.key[:2] or (self.key[2] is not None and plan.n_src != self.key[2]):
             return None
         e0 = torch.cuda.Event(enable_timing=True)
@@ -72,26 +131,42 @@ class KernelTimer:
         return len(self.records), ms, flops
 
 
-def pmc_traffic(kernel_sig):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  bench.py cannot run the profiler on itself, so the number comes from profiles/ and is null if absent."""
+def committed_counters(kernel_sig):
+    """Counter figures of the dominant kernel from the committed PMC passes of this same command (bench.py cannot run
+    the profiler on itself): HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950) and, when present, MFMA-busy / LDS-wait fractions from the SQ
+    pass (profiles/r*_sq_counters.json).  Null when absent."""
     import glob
+    res = {"traffic": None, "traffic_source": None, "mfma_busy": None, "lds_wait": None, "hbm_GBps": None, "counter_source": None}
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        data = json.load(f)
-    for name, row in data.items():
-        if kernel_sig in name:
-            return (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6, os.path.basename(files[-1])
-    return None, None
+    if files:
+        with open(files[-1]) as f:
+            data = json.load(f)
+        for name, row in data.items():
+            if kernel_sig in name:
+                res["traffic"] = (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6
+                res["traffic_source"] = os.path.basename(files[-1])
+                break
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_sq_counters.json")))
+    if files:
+        with open(files[-1]) as f:
+            data = json.load(f)
+        for name, row in data.items():
+            if kernel_sig in name:
+                res["mfma_busy"] = row.get("mfma_busy_frac")
+                res["lds_wait"] = row.get("lds_wait_frac")
+                res["hbm_GBps"] = row.get("hbm_GBps")
+                res["counter_source"] = os.path.basename(files[-1])
+                break
+    return res
 
 
-def build_net(dtype):
+def build_net(dtype, heatmaps_out=3):
+    import numpy as np
+    import torch
     from object_keypoints_amd import synth
     from object_keypoints_amd.perception.models import KeypointNet
-    net = KeypointNet(features=128, heatmaps_out=3, compute_dtype=dtype)
+    net = KeypointNet(features=128, heatmaps_out=heatmaps_out, compute_dtype=dtype)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     vals = synth.fill_state_dict(shapes, seed=0)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in vals.items()})
@@ -111,7 +186,10 @@ def usable_cores():
 
 
 def cpu_baseline(seconds):
-    """The oracle (a port: torch-CPU fp32 restatement + NumPy post-processing) on the host cores."""
+    """The oracle (a port: torch-CPU fp32 restatement + NumPy post-processing) on the host cores.  Also returns the
+    oracle's heat maps of the sample frames: the checker for `heat_err_vs_oracle`."""
+    import numpy as np
+    import torch
     from oracle import net as onet
     from oracle import pipeline as op
     from object_keypoints_amd import synth
@@ -120,11 +198,13 @@ def cpu_baseline(seconds):
     net = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=3), seed=0)
     cam = op.eval_camera(os.path.join(REPO, "config", "calibration.yaml"))
     d2p = op.DetectionToPoint(); d2p.reset(cam)
-    x = torch.from_numpy(synth.frames(4, seed=1))
+    x = torch.from_numpy(synth.frames(ERR_FRAMES, seed=1))
+    keep = {}
 
     def step():
         heat, depth, _ = onet.deployed_forward(net, x)
         heat, depth = heat.numpy(), depth.numpy()
+        keep["heat"] = heat
         for n in range(heat.shape[0]):
             for k in range(heat.shape[1]):
                 idx = op.peak_indices(heat[n, k])[:64]
@@ -135,90 +215,165 @@ def cpu_baseline(seconds):
     frames, t0 = 0, time.perf_counter()
     while True:
         step()
-        frames += 4
+        frames += ERR_FRAMES
         el = time.perf_counter() - t0
-        if el >= seconds and frames >= 8:
+        if el >= seconds and frames >= 2 * ERR_FRAMES:
             break
-    return {"value": frames / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{frames} frames (batches of 4, 3x511x511 fp32): oracle torch-CPU forward + NumPy peak-NMS/centroid/depth lifting, {el:.1f} s"}
+    return ({"value": frames / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+             "sample": f"{frames} frames (batches of {ERR_FRAMES}, 3x511x511 fp32): oracle torch-CPU forward + NumPy peak-NMS/centroid/depth lifting, {el:.1f} s"},
+            keep["heat"])
 
 
-def main():
-    args = parse()
+TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32"}
+KERNEL_SIG = {"bf16": "okp_igemm_patch_kernel", "f16": "okp_igemm_patch_kernel", "f32": "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"}
+KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
+               "f32": "okp_igemm_kernel<f32,256x256,src1>"}
+
+
+def bump_maps(start, count, dev, keypoint_config=(1, 3)):
+    """Injected post-network maps for global frames start..start+count: 1-2 objects per frame."""
+    import numpy as np
+    import torch
+    from object_keypoints_amd import synth
+    scenes = [synth.bump_scene(list(keypoint_config), n_objects=1 + (start + i) % 2, seed=7, index=start + i) for i in range(count)]
+    to = lambda key: torch.from_numpy(np.stack([s[key] for s in scenes])).to(dev)
+    n_peaks = sum(sum(len(p) for p in o["points"]) for s in scenes for o in s["objects"])
+    return to("heat"), to("depth"), to("centers"), n_peaks
+
+
+def run_precision(name, ctx, steps, warmup):
+    """Timed steps of the hot path at one precision on this rank.  Returns (result dict, heat maps of the error sample)."""
+    import torch
     from object_keypoints_amd import distributed as dist_, ops
     from object_keypoints_amd.perception.pipeline import BatchedKeypointPipeline
+    dev, world, batch = ctx["dev"], ctx["world"], ctx["batch"]
+    dtype = getattr(torch, TORCH_DTYPES[name])
+    net = build_net(dtype).to(dev)
+    pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, ctx["camera"], capacity=64)
+    frames = ctx["frames"]
+    b_heat, b_depth, b_centers, n_peaks = ctx["bumps"]
+    # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile
+    timer = KernelTimer(dtype, 3 if name == "f32" else 13, 1 if name == "f32" else None)
+    ops.LAUNCH_HOOK = timer
+
+    def step():
+        net.deployed(frames)                                          # heat / depth / centre maps of the network (in full)
+        out = pipe.postprocess_device(b_heat, b_depth, b_centers)     # peaks -> 3D -> objects on the injected scenes
+        return out, dist_.all_gather_keypoints(out["points"])
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            out, gathered = step()
+        dist_.barrier(); torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, gathered = step()
+        dist_.barrier(); torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+        ops.LAUNCH_HOOK = None
+        elapsed = dist_.max_over_ranks(elapsed, dev)
+        assert gathered.shape[0] == batch * world
+        assert not bool(out["overflow"]), "peak / object capacity exceeded in the timed step"
+        assert int(out["count"].sum()) == n_peaks, (int(out["count"].sum()), n_peaks)     # every injected bump is one peak
+        sample_heat = net.deployed(ctx["err_frames"])[0].cpu().numpy() if ctx["err_frames"] is not None else None
+    value = batch * world * steps / elapsed
+    n_launch, k_ms, k_flops = timer.summary()
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[name]
+    ctr = committed_counters(KERNEL_SIG[name]) if name != "f16" else committed_counters("\0")
+    res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
+           "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[name], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": ctr["traffic"], "traffic_unit": "HBM bytes/launch",
+                        "traffic_source": ctr["traffic_source"], "mfma_busy": ctr["mfma_busy"], "lds_wait": ctr["lds_wait"],
+                        "hbm_GBps": ctr["hbm_GBps"], "counter_source": ctr["counter_source"],
+                        "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
+                        "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}}
+    del pipe, net
+    torch.cuda.empty_cache()
+    return res, sample_heat
+
+
+def heat_error(got, want):
+    import numpy as np
+    e = np.abs(got.astype(np.float64) - want.astype(np.float64)).ravel()
+    return {"max": float(e.max()), "mean": float(e.mean()), "p99": float(np.quantile(e, 0.99)), "frames": int(got.shape[0])}
+
+
+def workload_string(batch, name, world):
+    return (f"BASELINE configs[2]: batch={batch}/GPU synthetic 511x511 frames, {name} activations+weights, fp32 accumulate, "
+            "CornerNet-Squeeze K=3 (valve) random-init procedural weights; fp32 NCHW frames -> stem -> hourglass+heads; "
+            "peak-NMS -> depth lifting -> object grouping on injected bump scenes (SURVEY 8(d), 1-2 objects/frame)"
+            + (" -> all-gather of 3D keypoints" if world > 1 else ""))
+
+
+def rank_main(args):
+    import numpy as np
+    import torch
+    from object_keypoints_amd import distributed as dist_, synth
     from object_keypoints_amd.perception.utils import camera_utils as cu
     rank, local_rank, world = dist_.init()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    net = build_net(dtype).to(dev)
     params = cu.load_calibration_params(os.path.join(REPO, "config", "calibration.yaml"))
     camera = cu.FisheyeCamera(params["K"], params["D"], params["image_size"]).scale(511 / 720)
     camera = camera.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511)
-    pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, camera, capacity=64)
 
     # synthetic frames generated ON the device (seeded per global frame block): N x 3 x 511 x 511 fp32 ~N(0,1)
     start, _ = dist_.shard(args.batch * world, rank, world)
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + start)
     frames = torch.randn((args.batch, 3, 511, 511), generator=gen, device=dev, dtype=torch.float32)
+    with_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    ctx = {"dev": dev, "world": world, "batch": args.batch, "camera": camera, "frames": frames,
+           "bumps": bump_maps(start, args.batch, dev),
+           "err_frames": torch.from_numpy(synth.frames(ERR_FRAMES, seed=1)).to(dev) if with_cpu else None}
 
-    # dominant kernel: bf16 = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile
-    timer = KernelTimer(dtype, 13 if dtype == torch.bfloat16 else 3, None if dtype == torch.bfloat16 else 1)
-    ops.LAUNCH_HOOK = timer
-
-    def step():
-        out = pipe.forward_device(frames)
-        return dist_.all_gather_keypoints(out["points"])
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            gathered = step()
-        dist_.barrier(); torch.cuda.synchronize()
-        timer.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            gathered = step()
-        dist_.barrier(); torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        timer.enabled = False
-    elapsed = dist_.max_over_ranks(elapsed, dev)
-    assert gathered.shape[0] == args.batch * world
-
-    total_frames = args.batch * world * args.steps
-    value = total_frames / elapsed
-    n_launch, k_ms, k_flops = timer.summary()
-    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    peak = PEAK_TFLOPS[args.dtype]
-    traffic, traffic_src = pmc_traffic("okp_igemm_patch_kernel" if args.dtype == "bf16"
-                                       else "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E")
+    head, head_heat = run_precision(args.dtype, ctx, args.steps, args.warmup)
     result = {
         "metric": "frames/sec keypoint inference (511x511 -> heatmaps+3D)",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: batch={args.batch}/GPU synthetic 511x511 frames, {args.dtype} activations+weights, fp32 accumulate, "
-                               "CornerNet-Squeeze K=3 (valve) random-init procedural weights; fp32 NCHW frames -> stem -> hourglass+heads -> peak-NMS -> depth lifting -> object grouping"
-                               + (" -> all-gather of 3D keypoints" if world > 1 else ""),
+        "config": {"workload": workload_string(args.batch, args.dtype, world),
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
-        "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
-        "roofline": {"bound": "mfma", "kernel": "okp_igemm_patch_kernel<bf16,256co x 16x16px>" if args.dtype == "bf16" else "okp_igemm_kernel<f32,256x256,src1>", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
-                     "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
-                     "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None},
+        "conv_stack_tflops_per_gpu": head["conv_stack_tflops_per_gpu"],
+        "roofline": head["roofline"],
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    extra_heat = {}
+    if world == 1:
+        for name in [d for d in args.extra_dtypes.split(",") if d and d != args.dtype]:
+            # fp32 runs ~12x longer per step (157 TFLOP/s MFMA peak): fewer steps keep the default run within minutes
+            steps = max(3, args.steps // 10) if name == "f32" else max(5, args.steps // 2)
+            res, extra_heat[name] = run_precision(name, ctx, steps, min(args.warmup, 2))
+            res["workload"] = workload_string(args.batch, name, world)
+            result[{"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[name]] = res
+    if with_cpu:
+        result["cpu_baseline"], oracle_heat = cpu_baseline(args.cpu_seconds)
+        result["heat_err_vs_oracle"] = heat_error(head_heat, oracle_heat)
+        for name, h in extra_heat.items():
+            result[{"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[name]]["heat_err_vs_oracle"] = heat_error(h, oracle_heat)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if needs_launcher(args, os.environ):
+        import torch                                      # device_count() only: no HIP initialisation in the parent
+        return self_launch(args, argv, torch.cuda.device_count())
+    rank_main(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

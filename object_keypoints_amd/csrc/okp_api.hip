@@ -230,6 +230,22 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
       std::vector<uint16_t> h(n_el);
       for (size_t i = 0; i < n_el; ++i) h[i] = f32_to_bf16_rne(packed[i]);
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, h.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+      // 1x1 plans consumed by the resident kernels (okp_fire2, okp_fire_chain, okp_heads) also get their weights in MFMA-fragment
+      // order: lane (j = l & 15, q = l >> 4) of wave w, block b, k-step ks holds the 16 bytes of channel 32 w + 2 j + b at K offset
+      // 32 ks + 8 q, so that one wave load is 1 KiB contiguous.  Built here, synchronously, so that a plan is immutable after
+      // creation (no lazy allocation inside a launch: safe under hipGraph capture and with several host threads / streams).
+      if (ok && n_taps == 1 && n_src == 1 && cin[0] % 32 == 0 && cout % 32 == 0) {
+        const int ksteps = cin[0] / 32, n_waves = cout / 32;
+        const size_t n16 = (size_t)n_waves * 2 * ksteps * 64;               // 16-byte units
+        std::vector<uint16_t> fr(n16 * 8);
+        for (size_t i = 0; i < n16; ++i) {
+          const int lane = (int)(i & 63), ks = (int)((i >> 6) % ksteps), b = (int)(((i >> 6) / ksteps) & 1), w = (int)((i >> 6) / ksteps / 2);
+          const int ch = 32 * w + 2 * (lane & 15) + b, q = lane >> 4;
+          std::memcpy(&fr[i * 8], &h[(((size_t)(ks >> 1) * plan->cout_pad + ch) * 8 + (ks & 1) * 4 + q) * 8], 16);
+        }
+        ok = !okp_check_hip(hipMalloc(&plan->frag_dev, n16 * 16), "hipMalloc(fragment-order weights)");
+        ok = ok && !okp_check_hip(hipMemcpy(plan->frag_dev, fr.data(), n16 * 16, hipMemcpyHostToDevice), "hipMemcpy(fragment-order weights)");
+      }
     } else {
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, packed.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
     }

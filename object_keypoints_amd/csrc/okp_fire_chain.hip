@@ -246,32 +246,11 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
 
 }  // namespace
 
-namespace {
-// packed [slice][cout_pad][128 B] -> fragment order: lane (j = l & 15, q = l >> 4) of wave w, block b, k-step ks holds
-// the 16 bytes of channel 32 w + 2 j + b at K offset 32 ks + 8 q
-__global__ void okp_frag_relayout_kernel(const u32x4* __restrict__ packed, int cout_pad, int ksteps, int n_waves, u32x4* __restrict__ out) {
-  const int total = n_waves * 2 * ksteps * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int lane = i & 63, ks = (i >> 6) % ksteps, b = ((i >> 6) / ksteps) & 1, w = (i >> 6) / ksteps / 2;
-    const int ch = 32 * w + 2 * (lane & 15) + b, q = lane >> 4;
-    out[i] = packed[((size_t)(ks >> 1) * cout_pad + ch) * 8 + (ks & 1) * 4 + q];
-  }
-}
-
-}  // namespace
-
-int okp_ensure_frags(const okp_conv* cplan, hipStream_t stream) {
-  okp_conv* plan = const_cast<okp_conv*>(cplan);          // a cache inside the plan, not a change of its meaning
+// The fragment-order weight copy of a 1x1 plan is built by okp_conv_create (okp_api.hip); a launch only checks that it exists.
+int okp_ensure_frags(const okp_conv* plan, hipStream_t) {
   if (plan->frag_dev) return OKP_OK;
-  const int ksteps = plan->cin[0] / 32, n_waves = plan->cout / 32;
-  const size_t bytes = (size_t)n_waves * 2 * ksteps * 64 * 16;
-  void* buf = nullptr;
-  if (int e = okp_check_hip(hipMalloc(&buf, bytes), "okp_fire_chain_forward: hipMalloc(fragments)")) return e;
-  hipLaunchKernelGGL(okp_frag_relayout_kernel, dim3(64), dim3(256), 0, stream, static_cast<const u32x4*>(plan->weights_dev), plan->cout_pad, ksteps, n_waves,
-                     static_cast<u32x4*>(buf));
-  if (int e = okp_check_hip(hipGetLastError(), "okp_frag_relayout launch")) { (void)hipFree(buf); return e; }
-  plan->frag_dev = buf;          // same stream as the consumer: ordered
-  return OKP_OK;
+  okp_set_error("plan has no fragment-order weights (needs a single-tap, single-source 16-bit plan with cin %% 32 == 0 and cout %% 32 == 0)");
+  return OKP_EINVAL;
 }
 
 

@@ -151,7 +151,7 @@ struct okp_conv {
   OkpPatchStep* patch_steps_dev;
   int32_t patch_n_geom;
   int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
-  void* frag_dev;          // 1x1 plans used by okp_fire_chain: weights re-laid in MFMA-fragment order (built on first use)
+  void* frag_dev;          // single-tap 16-bit plans: weights re-laid in MFMA-fragment order (built by okp_conv_create; NULL otherwise)
 };
 
 void okp_set_error(const char* fmt, ...);

@@ -105,6 +105,12 @@ __global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* 
     }
   }
   if (tid == 0) count[map] = running;
+  // unused slots are defined output (zeros): callers hand over uninitialised buffers, and bit-reproducibility checks
+  // compare whole tensors
+  for (int j = min(running, cap) + tid; j < cap; j += kNmsThreads) {
+    my_yx[j * 2 + 0] = 0; my_yx[j * 2 + 1] = 0;
+    my_xyc[j * 3 + 0] = 0.f; my_xyc[j * 3 + 1] = 0.f; my_xyc[j * 3 + 2] = 0.f;
+  }
 }
 
 __global__ __launch_bounds__(256) void okp_nms_maxpool_kernel(const float* __restrict__ x, int H, int W, int size,
@@ -154,13 +160,17 @@ extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_
   const int R = (int)(rmax < h ? rmax : h);
   if (n_maps == 0) return OKP_OK;
   const size_t lds = (size_t)(2 * R + 12) * w * sizeof(float);
-  static std::atomic<bool> attr_set{false};          // idempotent attribute: a race only repeats the call
-  if (!attr_set.load(std::memory_order_acquire)) {
+  // the attribute is per device: one bit per device id (idempotent, so a race only repeats the call)
+  static std::atomic<unsigned long long> attr_set{0ull};
+  int dev = 0;
+  if (int e = okp_check_hip(hipGetDevice(&dev), "okp_peak_nms: hipGetDevice")) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     if (int e = okp_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(okp_peak_nms_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))),
                               "okp_peak_nms: hipFuncSetAttribute"))
       return e;
-    attr_set.store(true, std::memory_order_release);
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(okp_peak_nms_kernel, dim3(n_maps), dim3(kNmsThreads), lds, (hipStream_t)stream, heat, h, w, R, cap, count, yx, xyc);
   return okp_check_hip(hipGetLastError(), "okp_peak_nms launch");

@@ -40,17 +40,31 @@ def shard(total, rank, world):
     return start, base + (1 if rank < extra else 0)
 
 
-def all_gather_keypoints(points):
-    """points: [frames_local, K, cap, 4] (same shape on every rank) -> [world*frames_local, K, cap, 4],
-    ordered by rank, i.e. by global frame index for contiguous shards.  One collective, no padding logic:
-    the tensor is fixed-capacity by construction (NaN rows mark unused peak slots)."""
+def all_gather_keypoints(points, total_frames=None):
+    """points: [frames_local, K, cap, 4] -> [total, K, cap, 4], ordered by rank, i.e. by global frame index for the
+    contiguous blocks of `shard`.  ONE collective.  `all_gather_into_tensor` needs the same shape on every rank:
+    with `total_frames` given (the global frame count the blocks were cut from with `shard`) and not divisible by the
+    world size, every rank pads its block with NaN rows (NaN = unused slot, as inside the payload) to the largest block
+    and the padding rows are dropped after the gather; without it the blocks must be equal (checked)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return points
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     points = points.contiguous()
-    out = torch.empty((world * points.shape[0],) + tuple(points.shape[1:]), dtype=points.dtype, device=points.device)
+    if total_frames is None:
+        total_frames = world * points.shape[0]
+    counts = [shard(total_frames, r, world)[1] for r in range(world)]
+    if points.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {points.shape[0]} frames, shard({total_frames}, {rank}, {world}) says {counts[rank]}; "
+                         "pass total_frames for uneven blocks")
+    biggest = max(counts)
+    if points.shape[0] < biggest:
+        pad = torch.full((biggest - points.shape[0],) + tuple(points.shape[1:]), float("nan"), dtype=points.dtype, device=points.device)
+        points = torch.cat([points, pad])
+    out = torch.empty((world * biggest,) + tuple(points.shape[1:]), dtype=points.dtype, device=points.device)
     dist.all_gather_into_tensor(out, points)
-    return out
+    if min(counts) == biggest:
+        return out
+    return torch.cat([out[r * biggest:r * biggest + c] for r, c in enumerate(counts)])
 
 
 def barrier():

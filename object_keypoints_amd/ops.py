@@ -383,9 +383,10 @@ def peak_nms(heat, cap=64):
         raise OkpError("heat must be float32 [N,K,H,W]")
     heat = heat.contiguous()
     n, k, h, w = heat.shape
-    count = torch.zeros((n, k), dtype=torch.int32, device=heat.device)
-    yx = torch.zeros((n, k, cap, 2), dtype=torch.int32, device=heat.device)
-    xyc = torch.zeros((n, k, cap, 3), dtype=torch.float32, device=heat.device)
+    # no fill kernels: okp_peak_nms writes every count and defines the unused slots of yx / xyc (zeros) itself
+    count = torch.empty((n, k), dtype=torch.int32, device=heat.device)
+    yx = torch.empty((n, k, cap, 2), dtype=torch.int32, device=heat.device)
+    xyc = torch.empty((n, k, cap, 3), dtype=torch.float32, device=heat.device)
     _lib.check(_lib.lib().okp_peak_nms(heat.data_ptr(), n * k, h, w, cap, count.data_ptr(), yx.data_ptr(), xyc.data_ptr(), stream_handle()), "okp_peak_nms")
     return count, yx, xyc
 

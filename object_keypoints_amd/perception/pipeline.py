@@ -27,6 +27,17 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _is_torchscript_archive(path):
+    """A TorchScript file is a zip archive with a `<name>/constants.pkl` and `<name>/code/` entries; a torch.save'd
+    checkpoint is a zip without them (or a legacy pickle)."""
+    import zipfile
+    if not zipfile.is_zipfile(path):
+        return False
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+    return any(n.endswith("/constants.pkl") for n in names) and any("/code/" in n for n in names)
+
+
 def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
     """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
     TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet."""
@@ -34,10 +45,10 @@ def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
     if isinstance(model, models.KeypointNet):
         return model.to(device).eval()
     if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
-        try:
+        if _is_torchscript_archive(model):                   # scripts/package_model.py:40-42 saves a torch.jit.trace
             sd = torch.jit.load(model, map_location="cpu").state_dict()
-        except Exception:
-            sd = torch.load(model, map_location="cpu")
+        else:                                                # torch.save'd state_dict or Lightning checkpoint: tensors only
+            sd = torch.load(model, map_location="cpu", weights_only=True)
             if isinstance(sd, dict) and "state_dict" in sd:
                 sd = sd["state_dict"]
     else:
@@ -103,7 +114,9 @@ class KeypointExtractionComponent:
     name = "keypoints"
     PROBABILITY_CUTOFF = 0.1
 
-    def __init__(self, keypoint_config, prediction_size, bandwidth=1.0, capacity=DEFAULT_PEAK_CAPACITY):
+    def __init__(self, keypoint_config, prediction_size, bandwidth=1.0, capacity=None):
+        """capacity: peak slots per map; None (default) = one per pixel, i.e. no cap, like the reference
+        (pipeline.py:73 keeps every peak).  The batched pipeline passes its fixed capacity explicitly."""
         self.keypoint_config = [1] + keypoint_config['keypoint_config']     # centre map first
         self.n_keypoints = sum(self.keypoint_config)
         self.prediction_size = prediction_size
@@ -115,14 +128,14 @@ class KeypointExtractionComponent:
             frames = torch.from_numpy(np.ascontiguousarray(frames.astype(np.float32)))
         frames = frames.to(_device(), torch.float32)
         assert frames.shape[1] == len(self.keypoint_config)
-        return ops.peak_nms(frames, cap=self.capacity)
+        return ops.peak_nms(frames, cap=self.capacity or frames.shape[2] * frames.shape[3])
 
     def __call__(self, frames):
         count, _, xyc = self.extract_device(frames)
         count, xyc = count.cpu().numpy(), xyc.cpu().numpy()
-        if int(count.max(initial=0)) > self.capacity:
+        if self.capacity is not None and int(count.max(initial=0)) > self.capacity:
             raise OkpError(f"a heat map has {int(count.max())} peaks, above the capacity {self.capacity}; "
-                           "raise `capacity` (the reference has no cap)")
+                           "raise `capacity` or leave it None (the reference has no cap)")
         keypoints, confidence = [], []
         for n in range(count.shape[0]):
             kp, cf = [], []
@@ -179,6 +192,8 @@ class ObjectExtraction:
                         points = points[confidences.argmax(axis=0)][None]
                     else:
                         from sklearn import cluster
+                        # the reference passes no n_init (pipeline.py:146) under its pinned scikit-learn 0.24.1, whose default is
+                        # 10 restarts; newer releases changed the default ('auto' -> 1 for init='random' from 1.4), so it is spelled out
                         clusterer = cluster.KMeans(init='random', n_clusters=self.keypoint_config[i], n_init=10)
                         points = clusterer.fit(points).cluster_centers_
                 obj['heatmap_points'][i] = points
@@ -290,12 +305,62 @@ class AssociationComponent:
         return out
 
 
+# Graph capture runs without the hourglass' side streams unless this is set: see CapturedStep and DESIGN.md §6.
+GRAPH_SIDE_STREAMS = False
+
+
+def _live_plans(net):
+    """Every device plan object currently cached by the modules of `net` (ConvPlan / StemPlan / tuples of them)."""
+    found = []
+
+    def walk(v):
+        if isinstance(v, (tuple, list)):
+            for e in v:
+                walk(e)
+        elif isinstance(v, (ops.ConvPlan, ops.StemPlan)) or isinstance(v, torch.Tensor):
+            found.append(v)
+
+    for m in net.modules():
+        for v in getattr(m, "_plans", {}).values():
+            walk(v)
+    return found
+
+
+class CapturedStep:
+    """A captured hipGraph of BatchedKeypointPipeline.forward_device plus everything its kernel nodes point at.
+
+    The graph holds raw device pointers to the plans' packed weights: this object keeps those plan objects alive (a
+    load_state_dict() or .to() on the network clears the modules' plan caches, which would otherwise free them under
+    the graph), and replay() refuses to run once the network's plans are no longer the captured ones - the graph would
+    silently compute with the old weights."""
+
+    def __init__(self, net, graph, static_in, static_out):
+        self.net, self.graph, self.static_in, self.static_out = net, graph, static_in, static_out
+        self._pinned = _live_plans(net)
+
+    def stale(self):
+        now = _live_plans(self.net)
+        return len(now) != len(self._pinned) or any(a is not b for a, b in zip(now, self._pinned))
+
+    def replay(self, frames=None):
+        if self.stale():
+            raise OkpError("the network's weights / plans changed after capture(): capture the step again")
+        if frames is not None:
+            self.static_in.copy_(frames)
+        self.graph.replay()
+        return self.static_out
+
+    def __iter__(self):                      # graph, static_in, static_out = pipe.capture(x)
+        return iter((self, self.static_in, self.static_out))
+
+
 class BatchedKeypointPipeline:
     """Frames -> heat/depth/centre maps -> peaks -> per-peak 3D points for a whole batch, device-resident.
 
     forward_device(frames) returns device tensors
         heat [N,K,H,W], depth [N,K,H,W], centers [N,K-1,2,H,W],
-        count [N,K] int32, xyc [N,K,cap,3] fp32 (x, y, confidence), points [N,K,cap,4] fp64 (X, Y, Z, confidence)
+        count [N,K] int32, xyc [N,K,cap,3] fp32 (x, y, confidence), points [N,K,cap,4] fp64 (X, Y, Z, confidence),
+        overflow (0-d bool: some map exceeded `capacity` peaks or `max_objects` centres - results are truncated)
     `points` is the fixed-capacity payload that is all-gathered across ranks (object_keypoints_amd.distributed).
     objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points.
     """
@@ -318,25 +383,22 @@ class BatchedKeypointPipeline:
         return self.postprocess_device(heat, depth, centers)
 
     def capture(self, frames):
-        """Capture forward_device for this frame shape into a hipGraph (HIP stream capture through torch): the ~160
+        """Capture forward_device for this frame shape into a hipGraph (HIP stream capture through torch): the ~75
         launches of a step become one graph launch, which removes the host launch cost that dominates small
-        batches (batch 8: 2.7 -> 2.2 ms per step).  Returns (graph, static_input, static_outputs); replay with
-        static_input.copy_(new_frames); graph.replay()."""
+        batches (batch 8: 2.7 -> 2.2 ms per step).  Returns a CapturedStep; it also unpacks as
+        (step, static_input, static_outputs): replay with step.replay(new_frames) or static_input.copy_(...); step.replay()."""
         static_in = frames.clone()
         for _ in range(2):                                   # warm-up: plans, allocator pools, kernel attributes
             self.forward_device(static_in)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        # The hourglass' side streams are switched off while capturing: with them, replays of the captured graph were
-        # observed to differ intermittently from the eager result at batch 64 (scripts/probe_determinism.py; eager
-        # runs with side streams are bit-reproducible), i.e. the forked branches are not safely ordered by the graph.
-        keep, ops.SIDE_STREAMS = ops.SIDE_STREAMS, False
+        keep, ops.SIDE_STREAMS = ops.SIDE_STREAMS, ops.SIDE_STREAMS and GRAPH_SIDE_STREAMS
         try:
             with torch.cuda.graph(graph):
                 static_out = self.forward_device(static_in)
         finally:
             ops.SIDE_STREAMS = keep
-        return graph, static_in, static_out
+        return CapturedStep(self.net, graph, static_in, static_out)
 
     def postprocess_device(self, heat, depth, centers):
         """Peaks, per-peak 3D points and the object grouping from (post-sigmoid) heat, depth and centre maps, all on
@@ -346,6 +408,10 @@ class BatchedKeypointPipeline:
         out = {"heat": heat, "depth": depth, "centers": centers, "count": count, "yx": yx, "xyc": xyc, "points": points}
         out.update(ops.group_objects(count, xyc, centers, self.config['keypoint_config'], max_obj=self.max_objects,
                                      max_sel=self.max_per_type))
+        # The reference has no capacity (pipeline.py:73 keeps every peak); the fixed-capacity tensors do.  `overflow` is a
+        # device-side flag (no sync here): a map with more peaks than `capacity`, or more centre peaks than `max_objects`,
+        # means `points` / the grouping are truncated - callers check it (objects() raises, bench.py asserts).
+        out["overflow"] = (count > self.capacity).any() | (count[:, 0] > self.max_objects).any()
         return out
 
     def objects(self, out, n):

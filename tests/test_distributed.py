@@ -23,15 +23,19 @@ def _worker(rank, world, port, total, q):
     pts = torch.full((count, 3, 4, 4), float("nan"), dtype=torch.float64)
     for i in range(count):
         pts[i, :, :2, :] = float(start + i)
-    gathered = d.all_gather_keypoints(pts)
+    gathered = d.all_gather_keypoints(pts, total_frames=total)
     slowest = d.max_over_ranks(float(rank + 1), torch.device("cpu"))
     d.barrier()
     q.put((rank, start, count, gathered.numpy(), slowest))
 
 
-def test_allgather_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("total", [8, 7])          # 7 frames on 2 ranks: blocks of 4 and 3 (padded for the collective, trimmed after)
+def test_allgather_world2_gloo(total):
     from object_keypoints_amd import distributed as d
-    total, world = 8, 2
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -213,3 +213,46 @@ def test_product_camera_project_reproduces_reference_known_answers():
     pts = np.concatenate([kp.mean(axis=0)[None], kp])
     np.testing.assert_allclose(left.project(pts, np.eye(4)), np.array(known["points_left_distinct"]), atol=1e-6)
     np.testing.assert_allclose(right.project(pts, p["T_RL"]), np.array(known["points_right_distinct"]), atol=1e-6)
+
+
+def test_bench_launcher_starts_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus N` without a torchrun environment must start its own ranks (the driver's 8-GPU command),
+    never touch the GPU in the parent, relay rank 0's JSON line and return the child's exit code."""
+    import io
+    import bench
+
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    args = bench.parse(argv)
+    assert bench.needs_launcher(args, {}) and not bench.needs_launcher(args, {"WORLD_SIZE": "8"})
+    assert not bench.needs_launcher(bench.parse(["--gpus", "1"]), {}) and bench.needs_launcher(bench.parse(["--gpus", "1", "--spawn"]), {})
+    cmd = bench.launcher_command(args, argv, 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-6:] == argv and cmd[-7].endswith("bench.py")
+
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, stdout=None, text=None, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('W0000 torchrun chatter\n{"metric": "frames/sec", "value": 1.0}\n')
+
+        def wait(self):
+            return seen.get("rc", 0)
+
+    out, err = io.StringIO(), io.StringIO()
+    assert bench.self_launch(args, argv, device_count=8, popen=FakeProc, out=out, err=err) == 0
+    assert out.getvalue() == '{"metric": "frames/sec", "value": 1.0}\n' and "chatter" in err.getvalue()
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "--spawn" not in seen["cmd"]
+    seen["rc"] = 5                                                     # a failing rank fails the launcher
+    assert bench.self_launch(args, argv, device_count=8, popen=FakeProc, out=io.StringIO(), err=io.StringIO()) == 5
+    err = io.StringIO()                                                # fewer devices than ranks: clean refusal, nothing started
+    seen.clear()
+    assert bench.self_launch(args, argv, device_count=1, popen=FakeProc, out=io.StringIO(), err=err) == 2
+    assert "needs 8 devices, 1 visible" in err.getvalue() and not seen
+
+
+def test_capacity_default_is_uncapped_like_the_reference():
+    from object_keypoints_amd.perception.pipeline import KeypointExtractionComponent
+    comp = KeypointExtractionComponent({"keypoint_config": [1, 3]}, [64, 64])
+    assert comp.capacity is None and comp.keypoint_config == [1, 1, 3]
