@@ -22,9 +22,8 @@ CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path
           "-Wall", "-Wno-unused-function"]
 # keep MFMA accumulators in arch VGPRs: with 256-thread workgroups hipcc otherwise allocates them as
 # AGPRs and copies all of them to and from VGPRs around every K-step (v_accvgpr_write/read x 128).
-# okp_igemm_w4.hip is the exception: its 256 accumulators per lane only fit the AGPR file.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-AGPR_FILES = {"okp_igemm_w4.hip"}
+AGPR_FILES = set()
 
 
 def _sources():

@@ -33,6 +33,9 @@
 #ifndef OKP_FIRE2_XCD
 #define OKP_FIRE2_XCD 1
 #endif
+#ifndef OKP_F2DBG
+#define OKP_F2DBG 0    // race hunting: 1 trailing barrier per tile, 2 no cross-tile prefetch, 8 every counted wait is vmcnt(0)
+#endif
 #ifndef OKP_FABL
 #define OKP_FABL 0     // timing ablations (WRONG results): 1 no x LDS-DMA, 2 no phase-1 MFMAs, 4 no phase-2a MFMAs, 8 no depth-wise FMAs, 16 no skip loads, 32 no stores
 #endif
@@ -216,6 +219,12 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   for (; tile < p.n_tiles; tile += gridDim.x) {
     int n, y0, x0;
     tile_origin(tile, n, y0, x0);
+    if ((OKP_F2DBG & 2) && tile != (int)blockIdx.x) {
+      __syncthreads();
+      tile_setup(tile);
+#pragma unroll
+      for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+    }
     // opaque copies: the per-(block, register) pixel arithmetic below is tile-invariant, and hoisting ~100 such
     // values out of the tile loop costs more registers than recomputing them (a multiply-high each)
     int qt = q, tidt = tid;
@@ -254,9 +263,17 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       // ks == 0: everything older (the previous tile's stores, the prefetched steps and weight sets) must be done,
       // because loads and stores share the counter.  Later: ring steps ks+1, ks+2 may stay in flight (nd LDS-DMA each)
       // and, when the squeeze weights are streamed, the weight set of step ks+1 issued between them.
-      if (ks == 0) wait_vm(0);
+      // WAR on the ring: the barrier below frees stage (ks-1) % NST for the LDS-DMA issued right behind it, so every
+      // wave's fragment reads of step ks-1 must have RETURNED before it arrives.  The k-loop is fully unrolled, and
+      // s_barrier orders memory operations only: without the pin, hipcc sinks step ks-1's MFMAs (and the lgkmcnt wait in
+      // front of them) below this barrier, the reads are still queued in the LDS pipe (8 waves x 8 ds_read_b128) when the
+      // refill of their stage lands, and the squeeze tile picks up the next k-chunk's bytes - at N=64 (several tiles per
+      // workgroup, loaded memory system) that happened in most launches (round-1 bug; scripts/probe_fire2_race.py).
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0 || (OKP_F2DBG & 8)) wait_vm(0);
       else if (ks >= (RES ? NST - 1 : 2))
         wait_vm((ks + 1 < KS1 ? nd + (RES ? 0 : 2) : 0) + (ks + 2 < KS1 ? nd : 0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if constexpr (!RES) { if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % 3]); }
       if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         if (!prefetched) {
           prefetched = true;
           const int next = tile + gridDim.x;
-          if (next < p.n_tiles) {
+          if (next < p.n_tiles && !(OKP_F2DBG & 2)) {
             tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
             if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
 #pragma unroll
@@ -441,6 +458,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
+    if (OKP_F2DBG & 1) __syncthreads();
   }
 }
 
@@ -494,4 +512,40 @@ int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t
   else if (cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<384, 256, 2>), grid, block, 0, stream, p);
   else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d stride %d", cin, mid, stride); return OKP_EINVAL; }
   return okp_check_hip(hipGetLastError(), "okp_fire2 launch");
+}
+
+extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const float* dw_w_dev, const float* dw_bias_dev,
+                                const okp_fire_args* a, void* stream) {
+  if (!squeeze || !expand || !dw_w_dev || !dw_bias_dev || !a || !a->x.data || !a->out.data) { okp_set_error("okp_fire_forward: null argument"); return OKP_EINVAL; }
+  if (squeeze->dtype != OKP_BF16 || expand->dtype != OKP_BF16) { okp_set_error("okp_fire_forward: the fused fire kernel is bf16 only"); return OKP_EINVAL; }
+  if (squeeze->n_taps != 1 || expand->n_taps != 1 || squeeze->n_src != 1 || expand->n_src != 1) { okp_set_error("okp_fire_forward: squeeze/expand must be single-tap 1x1 plans"); return OKP_EINVAL; }
+  const int cin = squeeze->cin[0], mid = squeeze->cout, half = expand->cout;
+  if (expand->cin[0] != mid || half != mid) { okp_set_error("okp_fire_forward: expects expand cin == squeeze cout == half (sr = 2)"); return OKP_EINVAL; }
+  if (cin % 64 || mid % 64 || mid > 256) { okp_set_error("okp_fire_forward: cin %d / mid %d must be multiples of 64, mid <= 256", cin, mid); return OKP_EINVAL; }
+  if (a->stride != 1 && a->stride != 2) { okp_set_error("okp_fire_forward: stride %d", a->stride); return OKP_EINVAL; }
+  if (a->skip && (a->stride != 1 || cin != 2 * half)) { okp_set_error("okp_fire_forward: skip needs stride 1 and cin == cout"); return OKP_EINVAL; }
+  const int ho = (a->x.h - 1) / a->stride + 1, wo = (a->x.w - 1) / a->stride + 1;
+  if (a->out.h != ho || a->out.w != wo) { okp_set_error("okp_fire_forward: out is %dx%d, expected %dx%d", a->out.h, a->out.w, ho, wo); return OKP_EINVAL; }
+  if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||
+      ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) { okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL; }
+  if (a->x.bytes <= 0 || a->x.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: x spans %lld bytes; views must be < 2 GiB", (long long)a->x.bytes); return OKP_EINVAL; }
+  if (!okp_fire2_supported(cin, mid, half, a->stride)) {
+    okp_set_error("okp_fire_forward: no one-launch kernel for %d -> %d -> %d at stride %d; run the squeeze plan and the fused tail "
+                  "(okp_conv_forward with dw_*) instead", cin, mid, 2 * half, a->stride);
+    return OKP_EINVAL;
+  }
+  {
+    if (a->out.bytes <= 0 || a->out.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: out spans %lld bytes; views must be < 2 GiB", (long long)a->out.bytes); return OKP_EINVAL; }
+    OkpFire2Params q;
+    memset(&q, 0, sizeof(q));
+    q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
+    q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.Ho = ho; q.Wo = wo; q.out_ps = a->out.pix_stride;
+    q.N = a->n; q.skip = a->skip;
+    if (int e = okp_ensure_frags(squeeze, (hipStream_t)stream)) return e;
+    if (int e = okp_ensure_frags(expand, (hipStream_t)stream)) return e;
+    q.w1 = squeeze->frag_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
+    q.wa = expand->frag_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
+    q.wd = dw_w_dev; q.bd = dw_bias_dev;
+    return okp_launch_fire2(q, cin, mid, a->stride, (hipStream_t)stream);
+  }
 }

@@ -6,14 +6,8 @@ namespace {
 template <typename T>
 int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
-    case 12: return launch_cfg<T, 128, 256, 2, 4, 3, 128, 16>(plan, p, stream); // 128x256, 3-deep ring (two slices in flight)
-    case 11: return launch_cfg<T, 256, 128, 4, 2, 3, 128, 16>(plan, p, stream); // 256x128, 3-deep ring
-    case 10:
-    case 9: return okp_launch_igemm_w4(plan, p, tile, stream);                  // separate TU (AGPR accumulators)
     case 8: return launch_cfg<T, 64, 64, 2, 2, 4, 128, 16>(plan, p, stream);   // 64x64 on 16x16 MFMA tiles
-    case 7: return launch_cfg<T, 128, 128, 2, 2, 2, 128, 16>(plan, p, stream); // 128x128 on 16x16 MFMA tiles
     case 6: return launch_cfg<T, 256, 256, 4, 2, 2, 128, 16>(plan, p, stream); // 256x256 on 16x16 MFMA tiles
-    case 5: return launch_cfg<T, 256, 256, 4, 2, 4, 64>(plan, p, stream);     // 256x256, 4-deep ring of 64-byte steps
     case 4: return launch_cfg<T, 128, 256, 2, 2, 3, 64>(plan, p, stream);     // 2 workgroups per CU, half-slice ring
     case 3: return launch_cfg<T, 256, 256, 4, 2, 2, 128>(plan, p, stream);
     case 2: return launch_cfg<T, 128, 128, 2, 2, 2, 128>(plan, p, stream);

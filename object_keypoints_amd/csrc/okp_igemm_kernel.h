@@ -428,8 +428,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       const int nxt = t + NS - 1;
       const bool more = nxt < T_;
       // steps t+1 .. t+NS-2 may stay in flight; in the tail fewer were issued, so drain completely
-      if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (lgkmcnt(0): this wave's fragment reads of step t-1 have returned before the barrier frees their stage)
+      if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if constexpr (MT == 16) {
         // 16x16 tiles: a k-step's fragments are 12 registers x 4, so only ONE set is live (the second set would spill

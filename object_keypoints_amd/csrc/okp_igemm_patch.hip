@@ -154,7 +154,9 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const bool more = t + 1 < t1;
       const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
 
-      if (!(OKP_PABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my part of step t's weights (and of its patch) has landed
+      // my part of step t's weights (and of its patch) has landed, and my fragment reads of step t-1 have returned (the
+      // barrier frees their stage / patch buffer for the next LDS-DMA)
+      if (!(OKP_PABL & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
 
       const char* const wt = smem + (t & 1) * kWStage;

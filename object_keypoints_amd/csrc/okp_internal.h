@@ -102,16 +102,6 @@ struct OkpPatchParams {
   unsigned long long* dbg;     // OKP_PCLK=1: {shader clocks, 100 MHz ticks} of workgroup 0 (diagnostic)
 };
 
-struct OkpFireParams {
-  const void* x; uint32_t x_bytes; int32_t H, W, x_ps;
-  void* out; int32_t Ho, Wo, out_ps;
-  int32_t N, stride, skip, cin, mid, half;
-  const void* w1; uint32_t w1_bytes; int32_t w1_cout_pad; const float* b1;
-  const void* wa; uint32_t wa_bytes; int32_t wa_cout_pad; const float* ba;
-  const float* wd; const float* bd;
-  int32_t SH, SW, IH, IW, FR, tiles_y, tiles_x;
-};
-
 struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 128 -> 256, stride 1
   const void* x; uint32_t x_bytes; int32_t H, W, x_ps;
   void* out; uint32_t out_bytes; int32_t Ho, Wo, out_ps;    // Ho x Wo = ceil(H / stride) x ceil(W / stride)
@@ -165,4 +155,3 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
 int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
-int okp_launch_igemm_w4(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // okp_igemm_w4.hip

@@ -196,8 +196,6 @@ SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurren
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64
 FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "8"))    # 4x4 maps: two launches are faster (25 vs 20 us)
-FUSE_FIRE_ALL = os.environ.get("OKP_FUSE_FIRE_ALL", "0") == "1"   # tests / experiments: also route the other configurations through the first-generation one-launch kernel
-                        # (okp_fire.hip: correct, but slower than squeeze + fused tail at every level)
 
 
 _FIRE2_CONFIGS = {1: {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)},      # stride -> (cin, mid) instances of okp_fire2.hip
@@ -206,8 +204,6 @@ FUSE_FIRE_S2 = os.environ.get("OKP_FUSE_FIRE_S2", "1") == "1"
 
 
 def fire_fusable(inp_dim, mid, stride, h, w):
-    if FUSE_FIRE_ALL:
-        return inp_dim % 64 == 0 and mid % 64 == 0 and mid <= 256
     if stride == 2 and not FUSE_FIRE_S2:
         return False
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW

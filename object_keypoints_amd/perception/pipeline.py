@@ -305,8 +305,11 @@ class AssociationComponent:
         return out
 
 
-# Graph capture runs without the hourglass' side streams unless this is set: see CapturedStep and DESIGN.md §6.
-GRAPH_SIDE_STREAMS = False
+# Graph capture keeps the hourglass' forked side streams (fork / join by events captures as graph edges).  Round 1 captured
+# without them because replays differed from the eager step at batch 64; the cause was a WAR race inside okp_fire2_kernel
+# (fixed in round 2, see its phase-1 comment), not the graph: replays are bit-equal to the eager step either way
+# (tests/test_gpu_bench_shapes.py::test_graph_replay_equals_eager_at_batch64).  False = capture the branches serially.
+GRAPH_SIDE_STREAMS = True
 
 
 def _live_plans(net):

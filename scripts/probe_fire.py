@@ -11,7 +11,7 @@ for a in sys.argv[1:]:
 m = bb.fire_module(kw["cin"], kw["cin"]).eval()
 x = ops.Act(torch.randn(kw["n"], kw["hw"], kw["hw"], kw["cin"], device="cuda").bfloat16())
 for fuse in (False, True, True, False):
-    ops.FUSE_FIRE = fuse; ops.FUSE_FIRE_ALL = fuse; ops.FUSE_FIRE_MIN_HW = 0
+    ops.FUSE_FIRE = fuse; ops.FUSE_FIRE_MIN_HW = 0
     for _ in range(3): y = m(x)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,7 +25,7 @@ def _rand(shape, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 8])
 @pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
     (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
     (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
@@ -34,8 +34,6 @@ def _rand(shape, seed):
     (3, 1, 8, 16, 1, 5, 5),         # one partial slice per tap
 ])
 def test_conv_matches_torch(dtype, tile, k, stride, cin, cout, n, h, w):
-    if tile >= 9 and dtype == torch.float32:
-        pytest.skip("4-wave AGPR tiles are bf16 only")
     from object_keypoints_amd import ops
     from object_keypoints_amd.perception.backbone import conv_taps, conv_out_size
     dev = _dev()
@@ -131,11 +129,10 @@ def test_bad_arguments_are_reported():
 @pytest.mark.parametrize("cin,cout,h,w,stride,n", [
     (256, 256, 16, 16, 1, 3),      # skip, strips of full rows
     (256, 256, 64, 64, 1, 1),      # skip, 2-D tiles with halo
-    (256, 384, 32, 32, 2, 2),      # stride 2, mid 192 (partial 128-channel chunk)
-    (384, 512, 8, 8, 2, 3),        # stride 2 to 4x4, mid 256
-    (512, 512, 4, 4, 1, 7),        # several whole frames per workgroup
+    (384, 512, 8, 8, 2, 3),        # stride 2 to 4x4, <384,256>
+    (512, 512, 4, 4, 1, 7),        # 4x4 maps (the network leaves these to two launches / the chain kernel)
     (384, 384, 13, 9, 1, 2),       # odd sizes
-    (384, 256, 16, 16, 1, 2),      # no skip (cin != cout)
+    (384, 256, 16, 16, 1, 2),      # no skip (cin != cout), <384,128>
     (256, 256, 33, 21, 1, 2),      # streaming kernel (okp_fire2): odd sizes, partial tiles on both axes
     (256, 256, 7, 5, 1, 3),        # streaming kernel: one small tile per frame
     (256, 256, 32, 32, 1, 4),      # streaming kernel: the 32x32 hourglass level
@@ -161,13 +158,13 @@ def test_fused_fire_module_matches_oracle(cin, cout, h, w, stride, n):
     with torch.no_grad():
         ref = o(x)
     xa = ops.Act.from_nchw(x.to(dev), torch.bfloat16)
-    ops.FUSE_FIRE_ALL = True
+    keep_hw, ops.FUSE_FIRE_MIN_HW = ops.FUSE_FIRE_MIN_HW, 0
     try:
         l0 = ops.COUNTERS["launches"]
         got = m(xa).to_nchw().cpu()
         assert ops.COUNTERS["launches"] - l0 == 1
     finally:
-        ops.FUSE_FIRE_ALL = False
+        ops.FUSE_FIRE_MIN_HW = keep_hw
     keep, ops.FUSE_FIRE = ops.FUSE_FIRE, False
     try:
         l0 = ops.COUNTERS["launches"]
@@ -198,11 +195,9 @@ def test_streaming_fire_without_skip():
     x = _rand((2, 256, 19, 23), 32).bfloat16().float()
     with torch.no_grad():
         ref = o(x)
-    ops.FUSE_FIRE_ALL = True
-    try:
-        got = m(ops.Act.from_nchw(x.to(dev), torch.bfloat16)).to_nchw().cpu()
-    finally:
-        ops.FUSE_FIRE_ALL = False
+    l0 = ops.COUNTERS["launches"]
+    got = m(ops.Act.from_nchw(x.to(dev), torch.bfloat16)).to_nchw().cpu()
+    assert ops.COUNTERS["launches"] - l0 == 1
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 0.03 * scale + 0.02
 
