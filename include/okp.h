@@ -11,7 +11,7 @@
  *   - Every `*_dev` / `void* x` argument is a DEVICE pointer (HBM) owned by the caller.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Launch
  *     functions only enqueue work: no allocation, no synchronisation, graph-capturable.
- *   - Activations are NHWC ("channels-last"), element type `dtype` (OKP_F32 / OKP_BF16),
+ *   - Activations are NHWC ("channels-last"), element type `dtype` (OKP_F32 / OKP_BF16 / OKP_F16),
  *     addressed as  base + (pixel * pix_stride + channel) elements, so a tensor argument
  *     may be a channel slice of a wider tensor (that is how concat / split are free).
  *   - Return value: 0 on success, negative OKP_E* otherwise; okp_last_error() gives text.
@@ -29,7 +29,7 @@ extern "C" {
 
 #define OKP_ABI_VERSION 1
 
-enum { OKP_F32 = 0, OKP_BF16 = 1 };
+enum { OKP_F32 = 0, OKP_BF16 = 1, OKP_F16 = 2 };   /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]) */
 enum { OKP_ACT_NONE = 0, OKP_ACT_RELU = 1, OKP_ACT_SIGMOID = 2 };
 enum {
   OKP_OK = 0,
@@ -183,7 +183,8 @@ int okp_preprocess_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int3
  * out: NHWC bf16 view of size ((h-1)/2+1) x ((w-1)/2+1), >= 128 channels, 64-byte aligned pixels.
  * ---------------------------------------------------------------------------------- */
 typedef struct okp_stem okp_stem;
-okp_stem* okp_stem_create(const float* w_host, const float* bias_host);
+okp_stem* okp_stem_create(const float* w_host, const float* bias_host);                       /* bf16 */
+okp_stem* okp_stem_create_dtype(int dtype, const float* w_host, const float* bias_host);    /* OKP_BF16 or OKP_F16 */
 void okp_stem_destroy(okp_stem* stem);
 int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream);
 /* Same layer straight from the reference's input layout, fp32 NCHW frames (n,3,h,w): the bf16 rounding and the zero

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 
 LIB_PATH = os.environ.get("OKP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_hip.so")   # OKP_LIB: A/B builds
 
-OKP_F32, OKP_BF16 = 0, 1
+OKP_F32, OKP_BF16, OKP_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 HEAD_MAX_OUT = 32
 
@@ -71,6 +71,7 @@ SIGNATURES = [
     ("okp_preprocess_u8", c_int, [c_int, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                   POINTER(c_float), POINTER(c_float), c_void_p, c_int32, c_void_p]),
     ("okp_stem_create", c_void_p, [POINTER(c_float), POINTER(c_float)]),
+    ("okp_stem_create_dtype", c_void_p, [c_int, POINTER(c_float), POINTER(c_float)]),
     ("okp_stem_destroy", None, [c_void_p]),
     ("okp_stem_forward", c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),
     ("okp_stem_forward_nchw", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(okp_tensor), c_void_p]),

@@ -20,7 +20,16 @@ inline uint16_t f32_to_bf16_rne(float f) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// IEEE half, round to nearest even (overflow -> inf, subnormals kept): the host compiler's own conversion
+inline uint16_t f32_to_f16_rne(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
 }  // namespace
+
+uint16_t okp_f32_to_16(int dtype, float f) { return dtype == OKP_BF16 ? f32_to_bf16_rne(f) : f32_to_f16_rne(f); }
 
 void okp_set_error(const char* fmt, ...) {
   va_list ap;
@@ -53,12 +62,12 @@ extern "C" int okp_device_arch(int dev, char* buf, int buflen) {
 
 extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
                                      int32_t n_taps, const okp_tap* taps, const float* bias, int act) {
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
   if (n_src < 1 || n_src > 2 || !cin || !conv_stride || !taps) { okp_set_error("okp_conv_create: bad sources"); return nullptr; }
   if (n_taps < 1 || n_taps > OKP_MAX_TAPS) { okp_set_error("okp_conv_create: n_taps %d not in [1,%d]", n_taps, OKP_MAX_TAPS); return nullptr; }
   if (cout < 8 || cout % 8) { okp_set_error("okp_conv_create: cout %d must be a positive multiple of 8", cout); return nullptr; }
   if (act != OKP_ACT_NONE && act != OKP_ACT_RELU) { okp_set_error("okp_conv_create: activation %d unsupported here", act); return nullptr; }
-  const int esz = dtype == OKP_BF16 ? 2 : 4;
+  const int esz = okp_esz(dtype);
   const int KE = 128 / esz;            // elements per K-slice
   for (int s = 0; s < n_src; ++s) {
     if (cin[s] < 1 || (cin[s] * esz) % 16) { okp_set_error("okp_conv_create: cin[%d]=%d is not a multiple of 16 bytes", s, cin[s]); return nullptr; }
@@ -97,7 +106,7 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
   // a single tap: 16x16 with the conv stride as pixel step); a strided multi-tap source is split into the residue classes
   // of (dy, dx) modulo the stride - a stride-2 3x3 reads four interleaved sub-lattices of 17x17, 17x16, 16x17 and 16x16.
   int tap_geom[OKP_MAX_TAPS] = {0}, tap_ty[OKP_MAX_TAPS] = {0}, tap_tx[OKP_MAX_TAPS] = {0};
-  bool patch_ok = dtype == OKP_BF16 && plan->cout_pad % 256 == 0;
+  bool patch_ok = okp_is16(dtype) && plan->cout_pad % 256 == 0;
   plan->patch_n_geom = 0;
   for (int sidx = 0; sidx < n_src && patch_ok; ++sidx) {
     const int cs = conv_stride[sidx];
@@ -226,9 +235,10 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
   ok = ok && !okp_check_hip(hipMalloc((void**)&plan->bias_dev, sizeof(float) * bias_pad), "hipMalloc(bias)");
   ok = ok && !okp_check_hip(hipMalloc((void**)&plan->slices_dev, sizeof(OkpSlice) * slices.size()), "hipMalloc(slices)");
   if (ok) {
-    if (dtype == OKP_BF16) {
+    if (okp_is16(dtype)) {
       std::vector<uint16_t> h(n_el);
-      for (size_t i = 0; i < n_el; ++i) h[i] = f32_to_bf16_rne(packed[i]);
+      if (dtype == OKP_BF16) for (size_t i = 0; i < n_el; ++i) h[i] = f32_to_bf16_rne(packed[i]);
+      else for (size_t i = 0; i < n_el; ++i) h[i] = f32_to_f16_rne(packed[i]);
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, h.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
       // 1x1 plans consumed by the resident kernels (okp_fire2, okp_fire_chain, okp_heads) also get their weights in MFMA-fragment
       // order: lane (j = l & 15, q = l >> 4) of wave w, block b, k-step ks holds the 16 bytes of channel 32 w + 2 j + b at K offset
@@ -288,7 +298,7 @@ static int select_tile(const okp_conv* plan, const okp_conv_args* a);
 
 extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, void* stream) {
   if (!plan || !a) { okp_set_error("okp_conv_forward: null plan/args"); return OKP_EINVAL; }
-  const int esz = plan->dtype == OKP_BF16 ? 2 : 4;
+  const int esz = okp_esz(plan->dtype);
   if (a->n < 1 || a->ho < 1 || a->wo < 1) { okp_set_error("okp_conv_forward: empty problem n=%d ho=%d wo=%d", a->n, a->ho, a->wo); return OKP_EINVAL; }
   if ((long)a->n * a->ho * a->wo >= 0x7FFFFFFFl) { okp_set_error("okp_conv_forward: too many output pixels"); return OKP_EINVAL; }
   for (int s = 0; s < plan->n_src; ++s) {

@@ -1,4 +1,4 @@
-// Streaming one-launch fire module for the stride-1 configurations (bf16, gfx950).  At the two high-resolution
+// Streaming one-launch fire module (bf16 / fp16, gfx950).  At the two high-resolution
 // hourglass levels (256 -> 128 -> 256) the unfused module (squeeze launch + expand/depth-wise launch) is bound by
 // HBM traffic: x read twice (GEMM input + skip), the squeeze tensor written and re-read.  Here x is read once (+halo,
 // mostly L2 hits) and the output written once; the squeeze tile never leaves LDS.
@@ -44,7 +44,6 @@ namespace {
 
 constexpr uint32_t kInvalid = 0x80000000u;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SP = 128;                          // squeeze-tile rows in LDS
@@ -78,7 +77,7 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
   }
 }
 
-template <int CIN, int MID, int STR>
+template <typename T, int CIN, int MID, int STR>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
   static_assert(STR == 1 || STR == 2, "stride of both branches");
   constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           if (OKP_FABL & 2) asm volatile("" ::"v"(a[pb]), "v"(w1f[RES ? ks : ks % 3][b]));
-          else acc[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, w1f[RES ? ks : ks % 3][b]),
-                                                               acc[pb][b], 0, 0, 0);
+          else acc[pb][b] = H16<T>::mfma16(a[pb], w1f[RES ? ks : ks % 3][b], acc[pb][b]);
     }
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     u32x4 waf[2][KS2];
@@ -307,10 +305,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = (mq[pb >> 1] >> (16 * (pb & 1) + r)) & 1u;
-          bf16x2 v;
-          v[0] = (__bf16)(ok ? acc[pb][0][r] : 0.f);
-          v[1] = (__bf16)(ok ? acc[pb][1][r] : 0.f);
-          *reinterpret_cast<bf16x2*>(smem + s_dst[r] + pb * 16 * (MID * 2)) = v;
+          *reinterpret_cast<uint32_t*>(smem + s_dst[r] + pb * 16 * (MID * 2)) = okp_pack2<T>(ok ? acc[pb][0][r] : 0.f, ok ? acc[pb][1][r] : 0.f);
         }
       }
     }
@@ -359,8 +354,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
             for (int b = 0; b < 2; ++b)
               if (OKP_FABL & 4) asm volatile("" ::"v"(a), "v"(waf[b][ks]));
-              else ac2[pb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, waf[b][ks]),
-                                                                   ac2[pb][b], 0, 0, 0);
+              else ac2[pb][b] = H16<T>::mfma16(a, waf[b][ks], ac2[pb][b]);
           }
         }
       }
@@ -369,11 +363,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         if (16 * pb < p.IP) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bf16x2 rv = __builtin_bit_cast(bf16x2, r_raw[pb][r]);
-            bf16x2 v;
-            v[0] = (__bf16)fmaxf(ac2[pb][0][r] + (float)rv[0], 0.f);
-            v[1] = (__bf16)fmaxf(ac2[pb][1][r] + (float)rv[1], 0.f);
-            if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)o_off[pb][r], 0, 0);
+            const uint32_t v = okp_pack2<T>(fmaxf(ac2[pb][0][r] + H16<T>::lo(r_raw[pb][r]), 0.f), fmaxf(ac2[pb][1][r] + H16<T>::hi(r_raw[pb][r]), 0.f));
+            if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, (int)o_off[pb][r], 0, 0);
             else asm volatile("" ::"v"(v));
           }
         }
@@ -429,7 +420,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
               const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
               f32x2 s2[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) s2[e] = f32x2{__builtin_bit_cast(float, sv[e] << 16), __builtin_bit_cast(float, sv[e] & 0xffff0000u)};
+              for (int e = 0; e < 4; ++e) s2[e] = f32x2{H16<T>::lo(sv[e]), H16<T>::hi(sv[e])};
 #pragma unroll
               for (int dy = 0; dy < 3; ++dy) {
                 const int iy = (sr - dy) / STR;
@@ -446,11 +437,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           u32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float lo = fmaxf(v[iy][e][0] + __builtin_bit_cast(float, rr[iy][e] << 16), 0.f);
-            const float hi = fmaxf(v[iy][e][1] + __builtin_bit_cast(float, rr[iy][e] & 0xffff0000u), 0.f);
-            bf16x2 pk;
-            pk[0] = (__bf16)lo; pk[1] = (__bf16)hi;
-            o[e] = __builtin_bit_cast(uint32_t, pk);
+            const float lo = fmaxf(v[iy][e][0] + H16<T>::lo(rr[iy][e]), 0.f);
+            const float hi = fmaxf(v[iy][e][1] + H16<T>::hi(rr[iy][e]), 0.f);
+            o[e] = okp_pack2<T>(lo, hi);
           }
           if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
           else asm volatile("" ::"v"(o));
@@ -474,7 +463,8 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride) {
   return stride == 2 && ((cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 384 && mid == 256));
 }
 
-int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream) {
+template <typename T>
+static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream) {
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
   // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
   long best = -1;
@@ -501,23 +491,28 @@ int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t
   const int resident = 256 * (mid == 128 ? 2 : 1);
   const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block((unsigned)(2 * mid));
   if (stride == 1) {
-    if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128, 1>), grid, block, 0, stream, p);
-    else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192, 1>), grid, block, 0, stream, p);
-    else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<512, 256, 1>), grid, block, 0, stream, p);
-    else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<384, 128, 1>), grid, block, 0, stream, p);
-    else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<512, 192, 1>), grid, block, 0, stream, p);
+    if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 1>), grid, block, 0, stream, p);
+    else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 1>), grid, block, 0, stream, p);
+    else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 256, 1>), grid, block, 0, stream, p);
+    else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 128, 1>), grid, block, 0, stream, p);
+    else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 192, 1>), grid, block, 0, stream, p);
     else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d", cin, mid); return OKP_EINVAL; }
-  } else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<256, 128, 2>), grid, block, 0, stream, p);
-  else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<384, 192, 2>), grid, block, 0, stream, p);
-  else if (cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<384, 256, 2>), grid, block, 0, stream, p);
+  } else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 2>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 2>), grid, block, 0, stream, p);
+  else if (cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 256, 2>), grid, block, 0, stream, p);
   else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d stride %d", cin, mid, stride); return OKP_EINVAL; }
   return okp_check_hip(hipGetLastError(), "okp_fire2 launch");
+}
+
+int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream) {
+  if (dtype == OKP_BF16) return launch_fire2_t<__bf16>(p, cin, mid, stride, stream);
+  return launch_fire2_t<_Float16>(p, cin, mid, stride, stream);
 }
 
 extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const float* dw_w_dev, const float* dw_bias_dev,
                                 const okp_fire_args* a, void* stream) {
   if (!squeeze || !expand || !dw_w_dev || !dw_bias_dev || !a || !a->x.data || !a->out.data) { okp_set_error("okp_fire_forward: null argument"); return OKP_EINVAL; }
-  if (squeeze->dtype != OKP_BF16 || expand->dtype != OKP_BF16) { okp_set_error("okp_fire_forward: the fused fire kernel is bf16 only"); return OKP_EINVAL; }
+  if (!okp_is16(squeeze->dtype) || expand->dtype != squeeze->dtype) { okp_set_error("okp_fire_forward: the fused fire kernel takes bf16 or fp16 plans of one type"); return OKP_EINVAL; }
   if (squeeze->n_taps != 1 || expand->n_taps != 1 || squeeze->n_src != 1 || expand->n_src != 1) { okp_set_error("okp_fire_forward: squeeze/expand must be single-tap 1x1 plans"); return OKP_EINVAL; }
   const int cin = squeeze->cin[0], mid = squeeze->cout, half = expand->cout;
   if (expand->cin[0] != mid || half != mid) { okp_set_error("okp_fire_forward: expects expand cin == squeeze cout == half (sr = 2)"); return OKP_EINVAL; }
@@ -546,6 +541,6 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.w1 = squeeze->frag_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
     q.wa = expand->frag_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
     q.wd = dw_w_dev; q.bd = dw_bias_dev;
-    return okp_launch_fire2(q, cin, mid, a->stride, (hipStream_t)stream);
+    return okp_launch_fire2(squeeze->dtype, q, cin, mid, a->stride, (hipStream_t)stream);
   }
 }

@@ -21,7 +21,6 @@
 
 namespace {
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int CIN, int PXB>
@@ -52,9 +51,11 @@ struct ChainCfg {
 template <int KEY>
 __device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & KEY)) << 4); }
 
-template <int CIN, int PXB>
+template <typename T, int CIN, int PXB>
 __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kernel(const OkpFireChainParams p) {
   using C = ChainCfg<CIN, PXB>;
+  using x2_t = typename H16<T>::x2;
+  using x8_t = typename H16<T>::x8;
   constexpr int MID = C::MID, NT = C::NT, KS1 = C::KS1, KS2 = C::KS2, XROW = C::XROW, SROW = C::SROW, NPX = C::NPX;
   constexpr int XK = C::XKEY, SK = C::SKEY;
   constexpr int PF = 8;                                // weight fragments in flight ahead of the MFMAs
@@ -140,8 +141,8 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
-          acc0[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc0[pb], 0, 0, 0);
-          acc1[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc1[pb], 0, 0, 0);
+          acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
+          acc1[pb] = H16<T>::mfma16(a[pb], f1, acc1[pb]);
         }
       }
       // accumulator register r of block pb is pixel 16 pb + 4 q + r; the channel pair is one dword of the squeeze tile's interior
@@ -151,10 +152,10 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         for (int r = 0; r < 4; ++r) {
           const int px = 16 * pb + 4 * q + r;
           if (px < HW) {
-            bf16x2 v;
-            v[0] = (__bf16)acc0[pb][r]; v[1] = (__bf16)acc1[pb][r];
+            x2_t v;
+            v[0] = (T)acc0[pb][r]; v[1] = (T)acc1[pb][r];
             const int row = srow(px);
-            *reinterpret_cast<bf16x2*>(smem + C::OFF_S + xoff<SK>(row, (ch0 * 2) >> 4, SROW) + ((ch0 * 2) & 15)) = v;
+            *reinterpret_cast<x2_t*>(smem + C::OFF_S + xoff<SK>(row, (ch0 * 2) >> 4, SROW) + ((ch0 * 2) & 15)) = v;
           }
         }
     }
@@ -183,8 +184,8 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         if (ks + PF2 < KS2) { wf[ks % PF2][0] = frag(wa_lane, KS2, ks + PF2, 0); wf[ks % PF2][1] = frag(wa_lane, KS2, ks + PF2, 1); }
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
-          acc0[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f0), acc0[pb], 0, 0, 0);
-          acc1[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, f1), acc1[pb], 0, 0, 0);
+          acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
+          acc1[pb] = H16<T>::mfma16(a[pb], f1, acc1[pb]);
         }
       }
 #pragma unroll
@@ -193,12 +194,12 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         for (int r = 0; r < 4; ++r) {
           const int px = 16 * pb + 4 * q + r;
           const uint32_t o = xoff<XK>(px, (ch0 * 2) >> 4, XROW) + ((ch0 * 2) & 15);
-          const bf16x2 xv = *reinterpret_cast<const bf16x2*>(xc + o);
-          bf16x2 v;
-          v[0] = (__bf16)fmaxf(acc0[pb][r] + (float)xv[0], 0.f);
-          v[1] = (__bf16)fmaxf(acc1[pb][r] + (float)xv[1], 0.f);
-          if (px >= HW) { v[0] = (__bf16)0.f; v[1] = (__bf16)0.f; }
-          *reinterpret_cast<bf16x2*>(xn + o) = v;
+          const x2_t xv = *reinterpret_cast<const x2_t*>(xc + o);
+          x2_t v;
+          v[0] = (T)fmaxf(acc0[pb][r] + (float)xv[0], 0.f);
+          v[1] = (T)fmaxf(acc1[pb][r] + (float)xv[1], 0.f);
+          if (px >= HW) { v[0] = (T)0.f; v[1] = (T)0.f; }
+          *reinterpret_cast<x2_t*>(xn + o) = v;
         }
     }
 
@@ -216,17 +217,17 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int row = (py + t / 3) * SW + pxx + t % 3;         // (py + 1 + dy) * SW + pxx + 1 + dx with dy, dx in -1..1
-        const bf16x8 sv = *reinterpret_cast<const bf16x8*>(smem + C::OFF_S + xoff<SK>(row, cg, SROW));
+        const x8_t sv = *reinterpret_cast<const x8_t*>(smem + C::OFF_S + xoff<SK>(row, cg, SROW));
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8), w1 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = fmaf((float)sv[e], w0[e], v[e]); v[4 + e] = fmaf((float)sv[4 + e], w1[e], v[4 + e]); }
       }
       const uint32_t o = xoff<XK>(dpx, (MID * 2) / 16 + cg, XROW);
-      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xc + o);
-      bf16x8 out;
+      const x8_t xv = *reinterpret_cast<const x8_t*>(xc + o);
+      x8_t out;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) out[e] = (__bf16)(dpx < HW ? fmaxf(v[e] + (float)xv[e], 0.f) : 0.f);
-      *reinterpret_cast<bf16x8*>(xn + o) = out;
+      for (int e = 0; e < 8; ++e) out[e] = (T)(dpx < HW ? fmaxf(v[e] + (float)xv[e], 0.f) : 0.f);
+      *reinterpret_cast<x8_t*>(xn + o) = out;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next module's constants have landed (this wave's share)
     __syncthreads();
@@ -266,8 +267,8 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
   for (int m = 0; m < n_modules; ++m) {
     okp_conv *sq = squeeze[m], *ex = expand[m];
     if (!sq || !ex || !dw_w_dev[m] || !dw_bias_dev[m]) { okp_set_error("okp_fire_chain_forward: null module %d", m); return OKP_EINVAL; }
-    if (sq->dtype != OKP_BF16 || ex->dtype != OKP_BF16 || sq->n_taps != 1 || ex->n_taps != 1 || sq->n_src != 1 || ex->n_src != 1) {
-      okp_set_error("okp_fire_chain_forward: module %d: bf16 single-tap 1x1 plans expected", m); return OKP_EINVAL;
+    if (!okp_is16(sq->dtype) || ex->dtype != sq->dtype || sq->dtype != squeeze[0]->dtype || sq->n_taps != 1 || ex->n_taps != 1 || sq->n_src != 1 || ex->n_src != 1) {
+      okp_set_error("okp_fire_chain_forward: module %d: bf16 / fp16 single-tap 1x1 plans of one type expected", m); return OKP_EINVAL;
     }
     if (m == 0) cin = sq->cin[0];
     if (sq->cin[0] != cin || sq->cout * 2 != cin || ex->cin[0] != sq->cout || ex->cout != sq->cout) {
@@ -293,8 +294,16 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
     okp_set_error("okp_fire_chain_forward: views too small for %d frames", n); return OKP_EINVAL;
   }
   p.n_modules = n_modules; p.x = x->data; p.out = out->data; p.x_ps = x->pix_stride; p.out_ps = out->pix_stride; p.H = x->h; p.W = x->w;
-  if (cin == 512) hipLaunchKernelGGL((okp_fire_chain_kernel<512, 1>), dim3(n), dim3(ChainCfg<512, 1>::NT), 0, (hipStream_t)stream, p);
-  else if (small) hipLaunchKernelGGL((okp_fire_chain_kernel<384, 1>), dim3(n), dim3(ChainCfg<384, 1>::NT), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((okp_fire_chain_kernel<384, 4>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
+  const bool bf = squeeze[0]->dtype == OKP_BF16;
+  if (cin == 512) {
+    if (bf) hipLaunchKernelGGL((okp_fire_chain_kernel<__bf16, 512, 1>), dim3(n), dim3(ChainCfg<512, 1>::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((okp_fire_chain_kernel<_Float16, 512, 1>), dim3(n), dim3(ChainCfg<512, 1>::NT), 0, (hipStream_t)stream, p);
+  } else if (small) {
+    if (bf) hipLaunchKernelGGL((okp_fire_chain_kernel<__bf16, 384, 1>), dim3(n), dim3(ChainCfg<384, 1>::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((okp_fire_chain_kernel<_Float16, 384, 1>), dim3(n), dim3(ChainCfg<384, 1>::NT), 0, (hipStream_t)stream, p);
+  } else {
+    if (bf) hipLaunchKernelGGL((okp_fire_chain_kernel<__bf16, 384, 4>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((okp_fire_chain_kernel<_Float16, 384, 4>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
+  }
   return okp_check_hip(hipGetLastError(), "okp_fire_chain launch");
 }

@@ -22,7 +22,6 @@
 
 namespace {
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr uint32_t kInvalid = 0x80000000u;
 
@@ -53,6 +52,7 @@ struct HeadsParams {
 
 __device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & 15)) << 4); }
 
+template <typename T>
 __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,18 +118,17 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
           for (int pb = 0; pb < 4; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + OFF_X + xoff(16 * pb + l16, 4 * ks + q, CIN * 2));
 #pragma unroll
           for (int pb = 0; pb < 4; ++pb) {
-            acc[pb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, wf[ks][0]), acc[pb][0], 0, 0, 0);
-            acc[pb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pb]), __builtin_bit_cast(bf16x8, wf[ks][1]), acc[pb][1], 0, 0, 0);
+            acc[pb][0] = H16<T>::mfma16(a[pb], wf[ks][0], acc[pb][0]);
+            acc[pb][1] = H16<T>::mfma16(a[pb], wf[ks][1], acc[pb][1]);
           }
         }
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            bf16x2 v;
-            v[0] = (__bf16)fmaxf(acc[pb][0][r], 0.f); v[1] = (__bf16)fmaxf(acc[pb][1][r], 0.f);
+            const uint32_t v = okp_pack2<T>(fmaxf(acc[pb][0][r], 0.f), fmaxf(acc[pb][1][r], 0.f));
             const int px = 16 * pb + 4 * q + r;
-            *reinterpret_cast<bf16x2*>(smem + OFF_H1 + xoff(px, (ch0 * 2) >> 4, F * 2) + ((ch0 * 2) & 15)) = v;
+            *reinterpret_cast<uint32_t*>(smem + OFF_H1 + xoff(px, (ch0 * 2) >> 4, F * 2) + ((ch0 * 2) & 15)) = v;
           }
       }
       __syncthreads();
@@ -139,15 +138,15 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
 #pragma unroll
         for (int kk = 0; kk < KS2; ++kk) {
           const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_H1 + xoff(16 * w + l16, 4 * kk + q, F * 2));
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wg[kk][0]), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wg[kk][1]), acc1, 0, 0, 0);
+          acc0 = H16<T>::mfma16(a, wg[kk][0], acc0);
+          acc1 = H16<T>::mfma16(a, wg[kk][1], acc1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int px = 16 * w + 4 * q + r;
           // rounded to bf16 like the stored activation of the unfused path, kept as fp32 for the dot products
-          h2[px * H2_PITCH + 2 * l16] = (float)(__bf16)fmaxf(acc0[r], 0.f);
-          h2[px * H2_PITCH + 2 * l16 + 1] = (float)(__bf16)fmaxf(acc1[r], 0.f);
+          h2[px * H2_PITCH + 2 * l16] = (float)(T)fmaxf(acc0[r], 0.f);
+          h2[px * H2_PITCH + 2 * l16 + 1] = (float)(T)fmaxf(acc1[r], 0.f);
         }
       }
       __syncthreads();
@@ -178,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
 
 extern "C" int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const okp_head_out_args* a, const okp_tensor* x, void* stream) {
   if (!l1 || !l2 || !a || !x || !x->data || !a->w_dev || !a->bias_dev) { okp_set_error("okp_heads_forward: null argument"); return OKP_EINVAL; }
-  if (l1->dtype != OKP_BF16 || l2->dtype != OKP_BF16 || l1->n_taps != 1 || l2->n_taps != 1 || l1->cin[0] != CIN || l1->cout != 3 * F ||
+  if (!okp_is16(l1->dtype) || l2->dtype != l1->dtype || l1->n_taps != 1 || l2->n_taps != 1 || l1->cin[0] != CIN || l1->cout != 3 * F ||
       l2->cin[0] != 3 * F || l2->cout != 3 * F2) {
-    okp_set_error("okp_heads_forward: expects bf16 1x1 plans 256 -> 384 and 384 -> 96 (three heads of 128 features)"); return OKP_EINVAL;
+    okp_set_error("okp_heads_forward: expects bf16 / fp16 1x1 plans 256 -> 384 and 384 -> 96 (three heads of 128 features)"); return OKP_EINVAL;
   }
   if (a->n_out < 1 || a->n_out > OKP_HEAD_MAX_OUT) { okp_set_error("okp_heads_forward: n_out %d out of range", a->n_out); return OKP_EINVAL; }
   if (a->n < 1 || a->h < 1 || a->w < 1) return OKP_OK;
@@ -203,6 +202,7 @@ extern "C" int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const o
   if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_heads_forward: too many pixels"); return OKP_EINVAL; }
   p.n_tiles = (int)tiles;
   const long groups = tiles < 168 ? tiles : 168;            // 3 x 168 = 504 = 24 x 21 workgroups: two per CU, whole head triples per XCD
-  hipLaunchKernelGGL(okp_heads_kernel, dim3((unsigned)(3 * groups)), dim3(256), 0, (hipStream_t)stream, p);
+  if (l1->dtype == OKP_BF16) hipLaunchKernelGGL(okp_heads_kernel<__bf16>, dim3((unsigned)(3 * groups)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(okp_heads_kernel<_Float16>, dim3((unsigned)(3 * groups)), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_heads launch");
 }

@@ -20,16 +20,17 @@ int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStre
 int okp_select_tile(int dtype, int cout_pad, long P) {
   // Fill the 256 CUs first; only then grow the tile (bigger tiles re-read less from L2).
   auto tiles = [&](int b) { return ((P + b - 1) / b) * ((cout_pad + b - 1) / b); };
-  // bf16 256x256 tiles run on 16x16x32 MFMAs (same FLOPs per LDS byte as 32x32x16, measured 4-7 % faster: the
+  // 16-bit 256x256 tiles run on 16x16x32 MFMAs (same FLOPs per LDS byte as 32x32x16, measured 4-7 % faster: the
   // shorter MFMA gives the scheduler twice as many slots to hide the fragment reads in); fp32 keeps 32x32x2
-  if (tiles(256) >= 256 && cout_pad >= 192) return dtype == OKP_BF16 ? 6 : 3;
+  if (tiles(256) >= 256 && cout_pad >= 192) return okp_is16(dtype) ? 6 : 3;
   if (tiles(128) >= 256) return 2;
-  return dtype == OKP_BF16 ? 8 : 1;             // 64x64: the 16x16 variant measured 2-5 % faster, 128x128: no difference
+  return okp_is16(dtype) ? 8 : 1;             // 64x64: the 16x16 variant measured 2-5 % faster, 128x128: no difference
 }
 
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
   if (tile == 13) return okp_launch_igemm_patch(plan, p, stream);       // patch-resident 3x3 kernel (okp_igemm_patch.hip)
   if (tile == 0) tile = okp_select_tile(plan->dtype, p.cout_pad, (long)p.N * p.Ho * p.Wo);
   if (plan->dtype == OKP_BF16) return launch_tile<__bf16>(plan, p, tile, stream);
+  if (plan->dtype == OKP_F16) return launch_tile<_Float16>(plan, p, tile, stream);
   return launch_tile<float>(plan, p, tile, stream);
 }

@@ -1,4 +1,4 @@
-// Tap-list implicit-GEMM convolution for gfx950 (MI355X), fp32 and bf16.
+// Tap-list implicit-GEMM convolution for gfx950 (MI355X): fp32, bf16 and fp16 activations / weights, fp32 accumulation.
 //
 //   D[co][pixel] = sum over K-slices  Wslice[co][128 B of K] . Xslice[pixel][128 B of K]
 //
@@ -27,9 +27,6 @@
 #ifndef OKP_ABL
 #define OKP_ABL 0     // timing ablations (WRONG results): 1 = no LDS-DMA in the main loop, 2 = no MFMAs, 3 = no fragment reads
 #endif
-#ifndef OKP_DS
-#define OKP_DS 0      // direct-store epilogue of the 256x256 16x16-MFMA tile: correct, measured 3-4 % SLOWER than the LDS transposition
-#endif             // (dword stores, 4x the store instructions of the 16-byte path): kept as a compile-time experiment
 
 namespace {
 
@@ -51,18 +48,22 @@ template <> struct Mma<float, 32> {
 };
 template <> struct Mma<__bf16, 32> {
   using acc_t = f32x16;
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { c = H16<__bf16>::mfma32(a, b, c); }
+};
+template <> struct Mma<_Float16, 32> {
+  using acc_t = f32x16;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { c = H16<_Float16>::mfma32(a, b, c); }
 };
 // 16x16 MFMA tiles: lane l supplies row l&15 and the 16-byte chunk (l>>4) of a 64-byte K group, so one k-step covers
-// 32 bf16 (or 16 fp32) of K.  Same FLOP per cycle as the 32x32 forms; the chip holds a higher clock on this shape
+// 32 bf16 / fp16 (or 16 fp32) of K.  Same FLOP per cycle as the 32x32 forms; the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md, DVFS give-back item 7), which is why it exists as a variant here.
 template <> struct Mma<__bf16, 16> {
   using acc_t = f32x4;
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<__bf16>::mfma16(a, b, c); }
+};
+template <> struct Mma<_Float16, 16> {
+  using acc_t = f32x4;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) { c = H16<_Float16>::mfma16(a, b, c); }
 };
 template <> struct Mma<float, 16> {
   using acc_t = f32x4;
@@ -91,20 +92,26 @@ template <> struct Io<float> {
     *reinterpret_cast<f32x4*>(p + 16) = b;
   }
 };
-template <> struct Io<__bf16> {
+template <typename T> struct Io16 {
+  using x8 = typename H16<T>::x8;
   static constexpr int kBytes8 = 16;
   static __device__ __forceinline__ void add8(float (&v)[8], const char* p) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+    const x8 a = *reinterpret_cast<const x8*>(p);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
   }
   static __device__ __forceinline__ void store8(const float (&v)[8], char* p) {
-    bf16x8 a;
+    x8 a;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[e];
-    *reinterpret_cast<bf16x8*>(p) = a;
+    for (int e = 0; e < 8; ++e) a[e] = (T)v[e];
+    *reinterpret_cast<x8*>(p) = a;
   }
 };
+template <> struct Io<__bf16> : Io16<__bf16> {};
+template <> struct Io<_Float16> : Io16<_Float16> {};
+// vector types of the element type (fp32 never uses the 16-bit ones; they only have to name a type)
+template <typename T> struct Vt { using x4 = typename H16<T>::x4; using x8 = typename H16<T>::x8; };
+template <> struct Vt<float> { using x4 = bf16x4; using x8 = bf16x8; };
 
 __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
@@ -153,12 +160,8 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
   static_assert(BPX * BCO * ESZ / PASSES <= LDS_BYTES, "epilogue staging must fit");
   constexpr int PX_PER_PASS = BPX / PASSES;
-  // DS (direct store, the bf16 256x256 16x16-MFMA tile): PIXELS are the MFMA rows and channels the columns, with the
-  // weight rows of every 32-channel group interleaved in LDS (row 16 b + j = channel 2 j + b, done by the LDS-DMA's
-  // source addressing).  A lane's accumulators of blocks 2 u, 2 u + 1 are then two ADJACENT channels of one pixel:
-  // the epilogue packs them into one dword and 16 lanes write one 64-byte line straight from registers - no LDS
-  // transposition, no barriers, and the stores drain while the next tile's gather runs.
-  constexpr bool DS = OKP_DS && ESZ == 2 && MT == 16 && BCO == 256 && WCO == 4 && TCO == 4;
+  using x4_t = typename Vt<T>::x4;                 // 4 / 8 elements of the 16-bit types (unused for fp32)
+  using x8_t = typename Vt<T>::x8;
   constexpr int PITCH = BCO * ESZ;
 
   // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
 #pragma unroll
   for (int i = 0; i < WROWS; ++i) {
     const int wrow = r0 + i * RPP;                            // LDS row of the weight tile
-    const int co = co0 + (DS ? (wrow & ~31) + 2 * (wrow & 15) + ((wrow >> 4) & 1) : wrow);
+    const int co = co0 + wrow;
     wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)c * 16u : kInvalidOff;
   }
   uint32_t xbase[NSRC][XROWS];
@@ -342,8 +345,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     for (int i = 0; i < TCO; ++i)
 #pragma unroll
       for (int j = 0; j < TPX; ++j) {
-        if constexpr (DS) Mma<T, MT>::run(b[j], a[i], acc[i][j]);      // pixels = rows, channels = columns
-        else Mma<T, MT>::run(a[i], b[j], acc[i][j]);
+        Mma<T, MT>::run(a[i], b[j], acc[i][j]);
       }
   };
 
@@ -471,60 +473,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // 256x256 tile fits the ring's LDS, so all waves stage at once and the tile leaves in ONE pass; the residual is
   // added after the read-back (bf16 + residual in fp32, ReLU, one more rounding).
   const bool dense_out = p.out_step == 1 && p.OH == p.Ho && p.OW == p.Wo;   // output pixel index == GEMM pixel index
-  if constexpr (DS) {
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (int)p.res_bytes, 0x00020000);
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    // this lane's channel pairs: blocks (0,1) -> pair 0, (2,3) -> pair 1; accumulator register r of pixel block j is
-    // pixel row 16 j + 4 fh + r
-    float bz[2][2];
-    uint32_t ch_b[2];                                  // byte offset of the pair inside a pixel, or invalid beyond cout
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int cl = wco * 64 + 32 * u + 2 * fr;
-      // straight from HBM/L2 (padded to the tile): a wave that runs ahead into the next tile re-fills bias_lds
-      bz[u][0] = p.bias[co0 + cl];
-      bz[u][1] = p.bias[co0 + cl + 1];
-      ch_b[u] = co0 + cl < p.cout ? (uint32_t)(co0 + cl) * 2u : kInvalidOff;
-    }
-    const bool relu = p.act == OKP_ACT_RELU;
-#pragma unroll
-    for (int j = 0; j < TPX; ++j) {
-      uint32_t ob[4], rv[4][2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pix = px0 + (wpx * TPX + j) * 16 + 4 * fh + r;
-        uint32_t opix = (uint32_t)pix;
-        if (!dense_out) {
-          const int pp = pix < P ? pix : 0;
-          const int n = fastdiv(pp, p.div_howo);
-          const int rem = pp - n * HoWo;
-          const int ho = fastdiv(rem, p.div_wo);
-          const int wo = rem - ho * p.Wo;
-          opix = (uint32_t)((n * p.OH + (ho * p.out_step + out_oy)) * p.OW + (wo * p.out_step + out_ox));
-        }
-        ob[r] = pix < P ? opix : kInvalidOff;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          rv[r][u] = 0u;
-          if (p.res) rv[r][u] = __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)((ob[r] | ch_b[u]) & kInvalidOff ? kInvalidOff : ob[r] * (uint32_t)(p.res_pix_stride * 2) + ch_b[u]), 0, 0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          float v0 = acc[2 * u][j][r] + bz[u][0], v1 = acc[2 * u + 1][j][r] + bz[u][1];
-          v0 += __builtin_bit_cast(float, rv[r][u] << 16);
-          v1 += __builtin_bit_cast(float, rv[r][u] & 0xffff0000u);
-          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          bf16x2 o;
-          o[0] = (__bf16)v0; o[1] = (__bf16)v1;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), rs_o,
-                                                (int)((ob[r] | ch_b[u]) & kInvalidOff ? kInvalidOff : ob[r] * (uint32_t)(p.out_pix_stride * 2) + ch_b[u]), 0, 0);
-        }
-    }
-  } else {
+  {
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     if (PASSES == 1 || wpx == pass) {
@@ -540,10 +489,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
             const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * MT + fr;
             char* dst = smem + prow * PITCH + ((((co_l * ESZ) >> 4) ^ (prow & 7)) << 4) + ((co_l * ESZ) & 15);
             if constexpr (ESZ == 2) {
-              bf16x4 o;
+              x4_t o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][j][4 * g + e] + bv[e]);
-              *reinterpret_cast<bf16x4*>(dst) = o;
+              for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][4 * g + e] + bv[e]);
+              *reinterpret_cast<x4_t*>(dst) = o;
             } else {
               f32x4 v;
 #pragma unroll
@@ -616,10 +565,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
             opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
           }
           char* op = static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ;
-          if (!p.res && ESZ == 2) {                // no residual: ReLU on the packed bf16 words, store as read
+          if (!p.res && ESZ == 2) {                // no residual: ReLU on the packed 16-bit words, store as read
             u32x4 w = raw[u][0];
             if (p.act == OKP_ACT_RELU) {
-              // bf16 read as int16 keeps the sign and the order of positive values: max(x, 0) clears negatives
+              // bf16 / fp16 read as int16 keep the sign and the order of positive values: max(x, 0) clears negatives
               // (one v_pk_max_i16 per register instead of unpack / compare / select)
               typedef short s16x8 __attribute__((ext_vector_type(8)));
               const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -629,7 +578,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
           } else {
             float v[8];
             if constexpr (ESZ == 2) {
-              const bf16x8 s8 = __builtin_bit_cast(bf16x8, raw[u][0]);
+              const x8_t s8 = __builtin_bit_cast(x8_t, raw[u][0]);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (float)s8[e];
             } else {
@@ -639,7 +588,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
             }
             if (p.res) {
               if constexpr (ESZ == 2) {
-                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rres[u0 + u][0]);
+                const x8_t r8 = __builtin_bit_cast(x8_t, rres[u0 + u][0]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
               } else {
@@ -660,7 +609,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     }  // ub
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
-  }  // !DS
+  }
 
   // ---- optional fused depth-wise 3x3 branch over the same pixels / channel range (fire-module tail) -------
   // A thread owns one 16-byte channel group (its 9 x VN weights live in registers) and SEG consecutive pixels,
@@ -693,7 +642,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       };
       auto to_f = [&](const u32x4& raw, float (&x)[VN]) {
         if constexpr (ESZ == 2) {
-          const bf16x8 xv = __builtin_bit_cast(bf16x8, raw);
+          const x8_t xv = __builtin_bit_cast(x8_t, raw);
 #pragma unroll
           for (int e = 0; e < VN; ++e) x[e] = (float)xv[e];
         } else {
@@ -716,10 +665,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         }
         char* op = static_cast<char*>(p.dw_out) + (opix * p.dw_out_pix_stride + ch) * ESZ;
         if constexpr (ESZ == 2) {
-          bf16x8 o;
+          x8_t o;
 #pragma unroll
-          for (int e = 0; e < VN; ++e) o[e] = (__bf16)v[e];
-          *reinterpret_cast<bf16x8*>(op) = o;
+          for (int e = 0; e < VN; ++e) o[e] = (T)v[e];
+          *reinterpret_cast<x8_t*>(op) = o;
         } else {
           f32x4 o = {v[0], v[1], v[2], v[3]};
           *reinterpret_cast<f32x4*>(op) = o;

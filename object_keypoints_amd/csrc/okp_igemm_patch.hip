@@ -1,4 +1,4 @@
-// Patch-resident implicit GEMM for the 3x3 convolutions of the pre-stage and the hourglass (bf16, 256 output channels).
+// Patch-resident implicit GEMM for the 3x3 convolutions of the pre-stage and the hourglass (bf16 / fp16, 256 output channels).
 //
 // okp_igemm_kernel gathers the pixel operand of EVERY K-slice from L2: a 3x3 convolution moves each input line nine
 // times into LDS (32 KiB of pixels + 32 KiB of weights per slice and workgroup).  Timing ablations of that kernel
@@ -50,7 +50,10 @@ constexpr int kLdsTotal = kLdsBias + 1024;
 static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
 static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
 
+template <typename T>
 __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
+  using x4_t = typename H16<T>::x4;
+  using x8_t = typename H16<T>::x8;
   constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
   __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
   char* const steps_lds = smem + kLdsSteps;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
           for (int h = 0; h < 2; ++h)
-            acc[i][2 * S + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bq[h]), acc[i][2 * S + h], 0, 0, 0);
+            acc[i][2 * S + h] = H16<T>::mfma16(a[i], bq[h], acc[i][2 * S + h]);
       };
       using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
       using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
           for (int j = 0; j < TPX; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = H16<T>::mfma16(a[i], b[j], acc[i][j]);
       }
 #endif
     }
@@ -272,10 +275,10 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       for (int j = 0; j < TPX; ++j) {
         const int prow = (wpx * TPX + j) * 16 + fr;
         char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
-        bf16x4 o;
+        x4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][j][e] + bv[e]);
-        *reinterpret_cast<bf16x4*>(dst) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][e] + bv[e]);
+        *reinterpret_cast<x4_t*>(dst) = o;
       }
     }
     __syncthreads();
@@ -318,15 +321,15 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
           }
           *reinterpret_cast<u32x4*>(op) = w;
         } else {
-          const bf16x8 s8 = __builtin_bit_cast(bf16x8, w), r8 = __builtin_bit_cast(bf16x8, rres[u]);
-          bf16x8 o;
+          const x8_t s8 = __builtin_bit_cast(x8_t, w), r8 = __builtin_bit_cast(x8_t, rres[u]);
+          x8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float v = (float)s8[e] + (float)r8[e];
             if (relu) v = fmaxf(v, 0.f);
-            o[e] = (__bf16)v;
+            o[e] = (T)v;
           }
-          *reinterpret_cast<bf16x8*>(op) = o;
+          *reinterpret_cast<x8_t*>(op) = o;
         }
       }
     }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 }  // namespace
 
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
-  if (!plan->patch_steps_dev || plan->dtype != OKP_BF16) return false;
+  if (!plan->patch_steps_dev || !okp_is16(plan->dtype)) return false;
   if ((p.n_classes != 1 && p.n_classes != 4) || p.dw_w) return false;     // (okp_conv_forward has checked that the output grid fits)
   if (p.Ho % 16 || p.Wo % 16) return false;
   for (int s = 0; s < plan->n_src; ++s) {
@@ -382,7 +385,8 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
     return d;
   }();
   p.dbg = dbg;
-  hipLaunchKernelGGL(okp_igemm_patch_kernel, grid, block, 0, stream, p);
+  if (plan->dtype == OKP_BF16) hipLaunchKernelGGL(okp_igemm_patch_kernel<__bf16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(okp_igemm_patch_kernel<_Float16>, grid, block, 0, stream, p);
   if (dbg) {
     unsigned long long h[2] = {0, 0};
     (void)hipStreamSynchronize(stream);

@@ -10,8 +10,66 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// The two 16-bit activation / weight types (OKP_BF16, OKP_F16).  Both feed the same MFMA shapes at the same rate
+// (16x16x32 and 32x32x16, fp32 accumulate); everything that differs between them - the builtin, the vector types and the
+// conversions - is behind this trait, so that the 16-bit kernels are written once and instantiated for both.
+template <typename T> struct H16;
+template <> struct H16<__bf16> {
+  using x2 = bf16x2; using x4 = bf16x4; using x8 = bf16x8;
+  static constexpr int kDtype = OKP_BF16;
+  // (the host pass of hipcc parses the kernels too: the builtins exist for the device only)
+  static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#else
+    return c;
+#endif
+  }
+  static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#else
+    return c;
+#endif
+  }
+  // the two elements of a packed dword as fp32 (bf16 is the upper half of an fp32: one shift / one mask)
+  static __device__ __forceinline__ float lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+};
+template <> struct H16<_Float16> {
+  using x2 = f16x2; using x4 = f16x4; using x8 = f16x8;
+  static constexpr int kDtype = OKP_F16;
+  static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    return c;
+#endif
+  }
+  static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    return c;
+#endif
+  }
+  static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
+  static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
+};
+template <typename T> __device__ __forceinline__ uint32_t okp_pack2(float a, float b) {     // two fp32 -> one packed dword (RNE)
+  typename H16<T>::x2 v;
+  v[0] = (T)a; v[1] = (T)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+inline int okp_esz(int dtype) { return dtype == OKP_F32 ? 4 : 2; }
+inline bool okp_is16(int dtype) { return dtype == OKP_BF16 || dtype == OKP_F16; }
 
 // One K-slice of the implicit GEMM = 128 bytes of K per row (64 bf16 / 32 fp32):
 // chunks 0-3 (64 B) come from tap_lo at channel c0_lo, chunks 4-7 from tap_hi at c0_hi.
@@ -145,6 +203,7 @@ struct okp_conv {
 };
 
 void okp_set_error(const char* fmt, ...);
+uint16_t okp_f32_to_16(int dtype, float f);          // host: fp32 -> bf16 / fp16 bits, round to nearest even
 int okp_check_hip(hipError_t e, const char* what);
 
 // launchers implemented in the .hip files
@@ -152,6 +211,6 @@ int okp_select_tile(int dtype, int cout_pad, long pixels);
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);
 int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_chain.hip: fragment-order weight copy of a 1x1 plan
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
-int okp_launch_fire2(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream);
+int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
 int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);

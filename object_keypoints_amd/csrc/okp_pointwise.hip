@@ -18,20 +18,25 @@ template <> struct Vec<float> {
     *reinterpret_cast<f32x4*>(p) = a;
   }
 };
-template <> struct Vec<__bf16> {
+template <typename T> struct Vec16 {
+  using x8 = typename H16<T>::x8;
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const char* p, float (&v)[8]) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+    const x8 a = *reinterpret_cast<const x8*>(p);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
   }
   static __device__ __forceinline__ void store(char* p, const float (&v)[8]) {
-    bf16x8 a;
+    x8 a;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[e];
-    *reinterpret_cast<bf16x8*>(p) = a;
+    for (int e = 0; e < 8; ++e) a[e] = (T)v[e];
+    *reinterpret_cast<x8*>(p) = a;
   }
 };
+template <> struct Vec<__bf16> : Vec16<__bf16> {};
+template <> struct Vec<_Float16> : Vec16<_Float16> {};
+template <typename T> struct X8 { using t = typename H16<T>::x8; };
+template <> struct X8<float> { using t = bf16x8; };          // never used for fp32; only has to name a type
 
 struct DwParams {
   const void* src; uint32_t src_bytes; int32_t H, W, src_ps;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void okp_dwconv3x3_kernel(const DwParams p) {
   };
   auto to_f = [&](const u32x4& raw, float (&x)[VN]) {
     if constexpr (ESZ == 2) {
-      const bf16x8 xv = __builtin_bit_cast(bf16x8, raw);
+      const typename X8<T>::t xv = __builtin_bit_cast(typename X8<T>::t, raw);
 #pragma unroll
       for (int e = 0; e < VN; ++e) x[e] = (float)xv[e];
     } else {
@@ -327,9 +332,9 @@ extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t co
                                      const float* w_dev, const float* bias_dev, const okp_tensor* res,
                                      const okp_tensor* out, int act, void* stream) {
   if (!src || !out || !src->data || !out->data || !w_dev || !bias_dev) { okp_set_error("okp_dwconv3x3_forward: null argument"); return OKP_EINVAL; }
-  const int esz = dtype == OKP_BF16 ? 2 : 4;
+  const int esz = okp_esz(dtype);
   const int vn = 16 / esz;
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_dwconv3x3_forward: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_dwconv3x3_forward: bad dtype %d", dtype); return OKP_EINVAL; }
   if (conv_stride != 1 && conv_stride != 2) { okp_set_error("okp_dwconv3x3_forward: stride %d unsupported", conv_stride); return OKP_EINVAL; }
   if (c <= 0 || c % vn) { okp_set_error("okp_dwconv3x3_forward: channels %d not a multiple of %d", c, vn); return OKP_EINVAL; }
   if (src->pix_stride % vn || out->pix_stride % vn || (res && res->data && res->pix_stride % vn)) {
@@ -349,17 +354,19 @@ extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t co
   const long groups = ((long)n * ho * wo + (long)pl * 8 - 1) / ((long)pl * 8);
   const int grid = (int)(groups < 1 ? 1 : (groups > 256L * 16 ? 256L * 16 : groups));
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<__bf16>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
+  else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<_Float16>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
   else hipLaunchKernelGGL(okp_dwconv3x3_kernel<float>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_dwconv3x3 launch");
 }
 
 extern "C" int okp_pack_frames(int dtype, const float* frames, int32_t n, int32_t h, int32_t w, void* out, int32_t out_w, void* stream) {
   if (!frames || !out) { okp_set_error("okp_pack_frames: null argument"); return OKP_EINVAL; }
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_pack_frames: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_pack_frames: bad dtype %d", dtype); return OKP_EINVAL; }
   if (out_w < w + 6) { okp_set_error("okp_pack_frames: out_w %d < w+6", out_w); return OKP_EINVAL; }
   const long total = (long)n * (h + 6) * out_w;
   const int grid = grid_for(total, 256);
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (__bf16*)out, h + 6, out_w);
+  else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_pack_frames_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (_Float16*)out, h + 6, out_w);
   else hipLaunchKernelGGL(okp_pack_frames_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, (float*)out, h + 6, out_w);
   return okp_check_hip(hipGetLastError(), "okp_pack_frames launch");
 }
@@ -367,13 +374,14 @@ extern "C" int okp_pack_frames(int dtype, const float* frames, int32_t n, int32_
 extern "C" int okp_pack_frames_u8(int dtype, const uint8_t* frames, int32_t n, int32_t h, int32_t w, const float* mean3, const float* std3,
                                   void* out, int32_t out_w, void* stream) {
   if (!frames || !out || !mean3 || !std3) { okp_set_error("okp_pack_frames_u8: null argument"); return OKP_EINVAL; }
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_pack_frames_u8: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_pack_frames_u8: bad dtype %d", dtype); return OKP_EINVAL; }
   if (out_w < w + 6) { okp_set_error("okp_pack_frames_u8: out_w %d < w+6", out_w); return OKP_EINVAL; }
   NormParams np;
   for (int c = 0; c < 3; ++c) { np.mean[c] = mean3[c]; np.stdv[c] = std3[c]; }
   const long total = (long)n * (h + 6) * out_w;
   const int grid = grid_for(total, 256);
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_pack_frames_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (__bf16*)out, h + 6, out_w);
+  else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_pack_frames_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (_Float16*)out, h + 6, out_w);
   else hipLaunchKernelGGL(okp_pack_frames_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, h, w, np, (float*)out, h + 6, out_w);
   return okp_check_hip(hipGetLastError(), "okp_pack_frames_u8 launch");
 }
@@ -382,7 +390,7 @@ extern "C" int okp_preprocess_u8(int dtype, const uint8_t* frames, int32_t n, in
                                  int32_t crop_y, int32_t crop_x, int32_t h, int32_t w, const float* mean3, const float* std3,
                                  void* out, int32_t out_w, void* stream) {
   if (!frames || !out || !mean3 || !std3) { okp_set_error("okp_preprocess_u8: null argument"); return OKP_EINVAL; }
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_preprocess_u8: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_preprocess_u8: bad dtype %d", dtype); return OKP_EINVAL; }
   if (n < 1 || src_h < 1 || src_w < 1 || resized_h < 1 || resized_w < 1 || h < 1 || w < 1 || crop_y < 0 || crop_x < 0 ||
       crop_y + h > resized_h || crop_x + w > resized_w) {
     okp_set_error("okp_preprocess_u8: crop %dx%d at (%d,%d) does not fit the resized frame %dx%d", h, w, crop_y, crop_x, resized_h, resized_w);
@@ -397,15 +405,16 @@ extern "C" int okp_preprocess_u8(int dtype, const uint8_t* frames, int32_t n, in
   const long total = (long)n * (h + 6) * out_w;
   const int grid = grid_for(total, 256);
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_preprocess_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, rp, (__bf16*)out, h + 6, out_w);
+  else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_preprocess_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, rp, (_Float16*)out, h + 6, out_w);
   else hipLaunchKernelGGL(okp_preprocess_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, n, rp, (float*)out, h + 6, out_w);
   return okp_check_hip(hipGetLastError(), "okp_preprocess_u8 launch");
 }
 
 extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void* stream) {
   if (!a || !a->src.data || !a->w_dev || !a->bias_dev) { okp_set_error("okp_head_out_forward: null argument"); return OKP_EINVAL; }
-  if (dtype != OKP_F32 && dtype != OKP_BF16) { okp_set_error("okp_head_out_forward: bad dtype %d", dtype); return OKP_EINVAL; }
+  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_head_out_forward: bad dtype %d", dtype); return OKP_EINVAL; }
   if (a->n_out < 1 || a->n_out > OKP_HEAD_MAX_OUT) { okp_set_error("okp_head_out_forward: n_out %d out of range", a->n_out); return OKP_EINVAL; }
-  const int vn = dtype == OKP_BF16 ? 8 : 4;
+  const int vn = okp_is16(dtype) ? 8 : 4;
   if (a->src.pix_stride % vn) { okp_set_error("okp_head_out_forward: pixel stride must be a multiple of %d", vn); return OKP_EINVAL; }
   HeadParams p;
   p.src = a->src.data; p.src_ps = a->src.pix_stride;
@@ -418,6 +427,7 @@ extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void*
   const long total = (long)p.N * p.HW;
   const int grid = grid_for(total, 256);
   if (dtype == OKP_BF16) hipLaunchKernelGGL(okp_head_out_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_head_out_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(okp_head_out_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_head_out launch");
 }

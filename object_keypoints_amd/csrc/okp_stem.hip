@@ -53,7 +53,6 @@ struct StemParams {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
@@ -61,7 +60,7 @@ __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
 
 // NCHW = true: the patch is read straight from the caller's fp32 NCHW frames (zero padding by range checks), rounded to
 // bf16 and written to LDS by the threads themselves - the packing pass (okp_pack_frames) and its 138 MB round trip go away.
-template <bool NCHW>
+template <typename T, bool NCHW>
 __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
   const int tid = threadIdx.x;
@@ -143,10 +142,9 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
       for (int i = 0; i < PPT; ++i) {
         const int idx = tid + 256 * i;
         if (idx < PATCH_BYTES / 8) {
-          typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-          bf16x4v o;
-          o[0] = (__bf16)pv[i][0]; o[1] = (__bf16)pv[i][1]; o[2] = (__bf16)pv[i][2]; o[3] = (__bf16)0.f;
-          *reinterpret_cast<bf16x4v*>(smem + buf * PATCH_BYTES + idx * 8) = o;
+          typename H16<T>::x4 o;
+          o[0] = (T)pv[i][0]; o[1] = (T)pv[i][1]; o[2] = (T)pv[i][2]; o[3] = (T)0.f;
+          *reinterpret_cast<typename H16<T>::x4*>(smem + buf * PATCH_BYTES + idx * 8) = o;
         }
       }
     }
@@ -185,8 +183,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[r][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pf[r]), __builtin_bit_cast(bf16x8, wa[b][s]),
-                                                                acc[r][b], 0, 0, 0);
+            acc[r][b] = H16<T>::mfma32(pf[r], wa[b][s], acc[r][b]);
       }
       if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next patch has landed, older stores have drained
       // ReLU, round to bf16, channel pair -> one dword; a half-wave writes 128 contiguous bytes of one pixel.
@@ -200,11 +197,9 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
-            bf16x2 v;
-            v[0] = (__bf16)fmaxf(acc[r][0][e], 0.f);
-            v[1] = (__bf16)fmaxf(acc[r][1][e], 0.f);
+            const uint32_t v = okp_pack2<T>(fmaxf(acc[r][0][e], 0.f), fmaxf(acc[r][1][e], 0.f));
             if (full || ox0 + i0 + 4 * h < p.Wo)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps2), 0);
+              __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps2), 0);
           }
         }
       }
@@ -220,19 +215,16 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
 struct okp_stem {
   void* wfrag_dev;
   float* bias_dev;
+  int dtype;
 };
 
 // w: HOST fp32 [128][3][7][7] (BatchNorm folded), bias: HOST fp32 [128]
-extern "C" okp_stem* okp_stem_create(const float* w, const float* bias) {
+extern "C" okp_stem* okp_stem_create(const float* w, const float* bias) { return okp_stem_create_dtype(OKP_BF16, w, bias); }
+
+extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const float* bias) {
   if (!w || !bias) { okp_set_error("okp_stem_create: null argument"); return nullptr; }
+  if (!okp_is16(dtype)) { okp_set_error("okp_stem_create: the stem kernel computes in bf16 or fp16 (dtype %d)", dtype); return nullptr; }
   std::vector<uint16_t> frag((size_t)2 * 2 * KSTEPS * 64 * 8, 0);
-  auto bf16_rne = [](float f) -> uint16_t {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-  };
   for (int wc = 0; wc < 2; ++wc)
     for (int b = 0; b < 2; ++b)
       for (int s = 0; s < KSTEPS; ++s)
@@ -243,10 +235,10 @@ extern "C" okp_stem* okp_stem_create(const float* w, const float* bias) {
           uint16_t* dst = &frag[((((size_t)wc * 2 + b) * KSTEPS + s) * 64 + lane) * 8];
           for (int e = 0; e < 8; ++e) {
             const int kx = kx0 + 2 * h + e / 4, c = e % 4;
-            dst[e] = (kx < 7 && c < 3) ? bf16_rne(w[((co * 3 + c) * 7 + ky) * 7 + kx]) : 0;
+            dst[e] = (kx < 7 && c < 3) ? okp_f32_to_16(dtype, w[((co * 3 + c) * 7 + ky) * 7 + kx]) : 0;
           }
         }
-  okp_stem* st = new okp_stem{nullptr, nullptr};
+  okp_stem* st = new okp_stem{nullptr, nullptr, dtype};
   if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMemcpy(st->wfrag_dev, frag.data(), frag.size() * 2, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
@@ -294,7 +286,8 @@ extern "C" int okp_stem_forward(const okp_stem* st, int32_t n, int32_t h, int32_
   p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   const int resident = 256 * 2;        // two workgroups per CU: one computes while the other's stores drain
   const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  hipLaunchKernelGGL(okp_stem_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (st->dtype == OKP_BF16) hipLaunchKernelGGL((okp_stem_kernel<__bf16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((okp_stem_kernel<_Float16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
 }
 
@@ -322,6 +315,7 @@ extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, i
   p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   const int resident = 256 * 2;
   const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  hipLaunchKernelGGL(okp_stem_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (st->dtype == OKP_BF16) hipLaunchKernelGGL((okp_stem_kernel<__bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((okp_stem_kernel<_Float16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
 }

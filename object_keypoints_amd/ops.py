@@ -10,16 +10,17 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import OKP_BF16, OKP_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, OkpError
+from ._lib import OKP_BF16, OKP_F16, OKP_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, OkpError
 
-_DTYPES = {torch.float32: OKP_F32, torch.bfloat16: OKP_BF16}
+_DTYPES = {torch.float32: OKP_F32, torch.bfloat16: OKP_BF16, torch.float16: OKP_F16}
+HALF_DTYPES = (torch.bfloat16, torch.float16)     # 16-bit activations / weights, fp32 accumulate: the MFMA throughput precisions
 
 
 def okp_dtype(torch_dtype):
     try:
         return _DTYPES[torch_dtype]
     except KeyError:
-        raise OkpError(f"unsupported activation dtype {torch_dtype}; use torch.float32 or torch.bfloat16")
+        raise OkpError(f"unsupported activation dtype {torch_dtype}; use torch.float32, torch.bfloat16 or torch.float16")
 
 
 def stream_handle():
@@ -243,15 +244,18 @@ def pack_frames(frames, dtype):
 
 
 class StemPlan:
-    """The bf16 7x7/s2 stem (okp_stem_*): w [128,3,7,7] and bias [128] with BatchNorm folded (host fp32)."""
+    """The 16-bit (bf16 / fp16) 7x7/s2 stem (okp_stem_*): w [128,3,7,7] and bias [128] with BatchNorm folded (host fp32)."""
 
-    def __init__(self, w, bias):
+    def __init__(self, w, bias, dtype=torch.bfloat16):
         w = np.ascontiguousarray(w, dtype=np.float32)
         b = np.ascontiguousarray(bias, dtype=np.float32)
         if w.shape != (128, 3, 7, 7) or b.shape != (128,):
             raise OkpError("the stem kernel is 7x7, 3 -> 128 channels")
+        if dtype not in HALF_DTYPES:
+            raise OkpError("the stem kernel computes in bfloat16 or float16")
+        self.dtype = dtype
         L = _lib.lib()
-        self._h = L.okp_stem_create(w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        self._h = L.okp_stem_create_dtype(okp_dtype(dtype), w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         if not self._h:
             raise OkpError("okp_stem_create: " + L.okp_last_error().decode())
 
@@ -266,8 +270,8 @@ class StemPlan:
     def from_nchw(self, frames, out):
         """frames: fp32 NCHW [N,3,H,W] on the device (the reference's input layout); no packing pass."""
         require_cuda(frames, "frames")
-        if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3 or out.dtype != torch.bfloat16:
-            raise OkpError("frames must be float32 [N,3,H,W] and the output bf16")
+        if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3 or out.dtype != self.dtype:
+            raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's 16-bit type")
         frames = frames.contiguous()
         n, _, h, w = frames.shape
         ov = out.view()
@@ -276,8 +280,8 @@ class StemPlan:
         COUNTERS["launches"] += 1
 
     def __call__(self, packed, out):
-        if packed.orig_hw is None or packed.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
-            raise OkpError("stem input must be the bf16 output of ops.pack_frames")
+        if packed.orig_hw is None or packed.dtype != self.dtype or out.dtype != self.dtype:
+            raise OkpError("stem input must be the output of ops.pack_frames in the plan's 16-bit type")
         h, w = packed.orig_hw
         pv, ov = packed.view(), out.view()
         _lib.check(_lib.lib().okp_stem_forward(self._h, packed.n, h, w, ctypes.byref(pv), ctypes.byref(ov), stream_handle()), "okp_stem_forward")

@@ -96,8 +96,8 @@ class convolution(_HipModule):
         if self.inp_dim == 3:
             if self.k != 7 or self.stride != 2:
                 raise OkpError("3-channel input is supported for the 7x7/s2 stem only")
-            if dtype == torch.bfloat16 and self.out_dim == 128 and STEM_KERNEL:
-                return StemPlan(w, b)
+            if dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL:
+                return StemPlan(w, b, dtype)
             # one tap per kernel row: 8 pixels x 4 channels of the packed frame = 32 contiguous elements
             taps = []
             for r in range(7):
@@ -110,7 +110,7 @@ class convolution(_HipModule):
     def forward_frames(self, frames, dtype):
         """The stem on raw fp32 NCHW frames.  bf16: one launch of the dedicated kernel reading the frames directly;
         otherwise pack (ops.pack_frames) + the generic path."""
-        if self.inp_dim == 3 and dtype == torch.bfloat16 and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
+        if self.inp_dim == 3 and dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
             plan = self._plan(("p", dtype), lambda: self._build(dtype))
             n, _, h, w = frames.shape
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
@@ -206,7 +206,7 @@ class fire_module(_HipModule):
         squeeze, expand, wd, bd = self._plan(("p", x.dtype), lambda: self._build(x.dtype, x.t.device))
         half = self.out_dim // 2
         ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
-        if x.dtype == torch.bfloat16 and ops.fire_fusable(self.inp_dim, self.mid, self.stride, x.h, x.w):
+        if x.dtype in ops.HALF_DTYPES and ops.fire_fusable(self.inp_dim, self.mid, self.stride, x.h, x.w):
             out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
             ops.fire_fused(squeeze, expand, wd, bd, x, out, self.stride, self.skip)
             return out
@@ -272,7 +272,7 @@ def run_fire_modules(mods, x):
     mods = list(mods)
 
     def chainable(m, x):
-        if not (ops.FUSE_FIRE_CHAIN and x.dtype == torch.bfloat16 and m.stride == 1 and m.skip and m.inp_dim == m.out_dim):
+        if not (ops.FUSE_FIRE_CHAIN and x.dtype in ops.HALF_DTYPES and m.stride == 1 and m.skip and m.inp_dim == m.out_dim):
             return False
         return (m.inp_dim == 512 and x.h <= 4 and x.w <= 4) or (m.inp_dim == 384 and x.h <= 8 and x.w <= 8)
 

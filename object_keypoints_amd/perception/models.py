@@ -80,7 +80,8 @@ class KeypointNet(_HipModule):
     """CornerNet-Squeeze hourglass backbone + heat/depth/centre heads (models.py:60-85).
 
     `compute_dtype` selects the activation/weight precision of the HIP path: torch.float32
-    (parity configuration) or torch.bfloat16 (MFMA throughput configuration, fp32 accumulate).
+    (parity configuration), torch.bfloat16 or torch.float16 (MFMA throughput configurations, fp32 accumulate;
+    float16 keeps three more mantissa bits than bfloat16 at the same rate, with a range of +-65504).
     """
 
     def __init__(self, output_size=None, features=128, heatmaps_out=2, dropout=0.1, compute_dtype=torch.float32):
@@ -124,7 +125,7 @@ class KeypointNet(_HipModule):
         outs = [(0, ops.ACT_SIGMOID if sigmoid else ops.ACT_NONE, heat, k) for k in range(K)]
         outs += [(32, ops.ACT_NONE, depth, k) for k in range(K)]
         outs += [(64, ops.ACT_NONE, centers, k) for k in range(2 * (K - 1))]
-        if ops.FUSE_HEADS and cnv.dtype == torch.bfloat16 and self.features == 128:
+        if ops.FUSE_HEADS and cnv.dtype in ops.HALF_DTYPES and self.features == 128:
             ops.heads_fused(l1, l2, cnv, outs, w3, b3)           # one launch, the 384- and 96-channel tensors stay in LDS
         else:
             a1 = Act.empty(n, h, w, 3 * self.features, cnv.dtype, cnv.t.device)
@@ -147,7 +148,7 @@ class KeypointNet(_HipModule):
     def max_frames_per_pass(self, h, w):
         """Frames per launch sequence such that the largest activation (the stem output, 128 channels at half
         resolution) stays under the 2 GiB view limit of the 32-bit buffer offsets (include/okp.h)."""
-        esz = 2 if self.compute_dtype == torch.bfloat16 else 4
+        esz = 2 if self.compute_dtype in ops.HALF_DTYPES else 4
         per_frame = ((h + 1) // 2) * ((w + 1) // 2) * 128 * esz
         return max(1, (0x7FFF0000 - 1) // per_frame)
 

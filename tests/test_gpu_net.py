@@ -54,17 +54,36 @@ def test_full_forward_returns_both_stacks():
     assert tuple(c1.shape) == (1, 2, 2, 64, 64)
 
 
-def test_bf16_network_tracks_reference():
-    from object_keypoints_amd import synth
-    case = cases.NET_CASES["valve_k3"]
-    net = _net(case, torch.bfloat16)
-    x = torch.from_numpy(synth.frames(2, seed=case["frame_seed"], start=case["frame_index"])).cuda()
+@pytest.mark.parametrize("name", sorted(cases.NET_CASES))
+@pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("f16", torch.float16)])
+def test_16bit_network_within_twice_the_recorded_error(name, tag, dtype):
+    """The throughput precisions against the reference's golden outputs.  The bound is 2x the error MEASURED on MI355X and
+    committed in tests/golden/precision_measured.json (scripts/record_precision_error.py): heat, depth and centre maps (max
+    and mean), and the agreement of the peak sets found on the heat maps (the reference's bit-exact index contract holds
+    for fp32 only: 16-bit heat maps move box sums across the 0.5 gate / the 5x5 ties for a few percent of the ~100 peaks
+    a random-weight map has)."""
+    import json
+    import os
+    from object_keypoints_amd import ops, synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "precision_measured.json")) as f:
+        rec = json.load(f)[name][tag]
+    case = cases.NET_CASES[name]
+    net = _net(case, dtype)
+    x = torch.from_numpy(synth.frames(1, seed=case["frame_seed"], start=case["frame_index"])).cuda()
     heat, depth, centers = net.deployed(x)
-    g = gu.golden_net("valve_k3")
-    err = np.abs(heat[0].cpu().numpy() - g["heat"][0])
-    print(f"bf16 heat err max {err.max():.3e} mean {err.mean():.3e}")
-    # bf16 activations through ~60 layers: stated tolerance for the throughput configuration
-    assert err.mean() <= 0.02 and err.max() <= 0.25
+    g = gu.golden_net(name)
+    for key, got in (("heat", heat), ("depth", depth), ("centers", centers)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - g[key])
+        print(f"{name} {tag} {key}: max {err.max():.3e} mean {err.mean():.3e} (recorded {rec[key]['max']:.3e} / {rec[key]['mean']:.3e})")
+        assert err.max() <= 2.0 * rec[key]["max"] and err.mean() <= 2.0 * rec[key]["mean"]
+    count, yx, _ = ops.peak_nms(heat, cap=4096)
+    gcount, gyx, _ = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
+    inter = union = 0
+    for k in range(heat.shape[1]):
+        a = {tuple(p) for p in yx[0, k, :int(count[0, k])].cpu().numpy().tolist()}
+        b = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
+        inter += len(a & b); union += len(a | b)
+    assert inter / union >= 1.0 - 2.0 * (1.0 - rec["peaks"]["jaccard"]) - 0.01
 
 
 def test_batch_independence_and_eval_only():
