@@ -117,6 +117,24 @@ def lib():
     return _lib
 
 
+TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_torch.so")
+_torch_ops = False
+
+
+def torch_ops():
+    """torch.ops.okp (csrc/okp_torch.cpp: the launch entry points registered with the PyTorch dispatcher, a shim over the same
+    C ABI) or None when the shim is not built or switched off (OKP_TORCH_OPS=0); the ctypes binding then serves the launches."""
+    global _torch_ops
+    if _torch_ops is False:
+        _torch_ops = None
+        if os.environ.get("OKP_TORCH_OPS", "1") != "0" and os.path.exists(TORCH_LIB_PATH) and not os.environ.get("OKP_LIB"):
+            lib()                                   # libokp_hip.so first (and torch's HIP runtime before it)
+            import torch
+            torch.ops.load_library(TORCH_LIB_PATH)
+            _torch_ops = torch.ops.okp
+    return _torch_ops
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().okp_last_error()

@@ -15,6 +15,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libokp_hip.so")
+TORCH_LIB_PATH = os.path.join(LIB_DIR, "libokp_torch.so")      # torch.ops.okp.*: dispatcher shim over the same C ABI (csrc/okp_torch.cpp)
 OBJ_DIR = os.path.join(REPO, "build", "okp")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -59,6 +60,27 @@ def _compile(src):
     return obj, False, ""
 
 
+def build_torch_ops(verbose=False):
+    """g++ (host only) build of csrc/okp_torch.cpp against this interpreter's torch: registers torch.ops.okp.* on top of the
+    extern "C" symbols of libokp_hip.so (found next to it through an $ORIGIN rpath).  No HIP code, no GPU needed."""
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(CSRC, "okp_torch.cpp")
+    if not _stale(TORCH_LIB_PATH, [src, os.path.join(REPO, "include", "okp.h"), LIB_PATH, os.path.abspath(__file__)]):
+        return TORCH_LIB_PATH
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", src, "-o", TORCH_LIB_PATH,
+           "-I" + os.path.join(REPO, "include"), f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += ["-I" + p for p in cpp_extension.include_paths()]
+    cmd += ["-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-L" + LIB_DIR, "-lokp_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building libokp_torch.so failed:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return TORCH_LIB_PATH
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -79,6 +101,7 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_torch_ops(verbose)
     return LIB_PATH
 
 

@@ -27,6 +27,18 @@ def stream_handle():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def stream_int():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dispatch(fn, *args):
+    """Call a torch.ops.okp entry point; its TORCH_CHECK failures surface as OkpError like the ctypes path's error codes."""
+    try:
+        return fn(*args)
+    except RuntimeError as e:
+        raise OkpError(str(e).split("\n")[0]) from None
+
+
 def require_cuda(t, what):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise OkpError(f"{what} must be a device tensor: the HIP path has no CPU fallback")
@@ -122,36 +134,54 @@ class ConvPlan:
 
     def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1):
         """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch."""
-        a = _lib.okp_conv_args()
-        a.n, a.ho, a.wo = out.n, ho, wo
-        for i, s in enumerate(srcs):
+        for s in srcs:
             if s.dtype != self.dtype:
                 raise OkpError("source dtype differs from plan dtype")
-            a.src[i] = s.view()
         if out.dtype != self.dtype or out.c != self.cout:
             raise OkpError(f"out has {out.c} channels / {out.dtype}, plan has {self.cout} / {self.dtype}")
-        a.out = out.view()
-        a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
-        a.res = res.view() if res is not None else _NULL_TENSOR
-        a.tile = tile or FORCE_TILE
-        a.n_classes = n_classes
-        if dw is not None:
-            dw_w, dw_b, dw_out, dw_res = dw
-            a.dw_w_dev, a.dw_bias_dev = dw_w.data_ptr(), dw_b.data_ptr()
-            a.dw_out = dw_out.view()
-            a.dw_res = dw_res.view() if dw_res is not None else _NULL_TENSOR
-            macs_dw = out.n * ho * wo * self.cout * 9
-        else:
-            macs_dw = 0
         macs = out.n * ho * wo * self.cout * self.alg_k
+        macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
+        tile = tile or FORCE_TILE
+        T = _lib.torch_ops()
         hook = LAUNCH_HOOK
-        if hook is not None:
-            self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
-            a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
-            token = hook.before(self, a.tile, macs)
-        _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
-        if hook is not None:
-            hook.after(token)
+        if T is not None:
+            s1 = srcs[1] if len(srcs) > 1 else None
+            if hook is not None:
+                self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
+                tile = _dispatch(T.conv_select_tile, self._h, srcs[0].t, srcs[0].c0, s1.t if s1 else None, s1.c0 if s1 else 0, out.t, out.c0, ho, wo,
+                                 out_step, oy, ox, tile, n_classes, dw is not None)
+                token = hook.before(self, tile, macs)
+            if dw is not None:
+                dw_w, dw_b, dw_out, dw_res = dw
+                dwa = (dw_w, dw_b, dw_out.t, dw_out.c0, dw_res.t if dw_res is not None else None, dw_res.c0 if dw_res is not None else 0)
+            else:
+                dwa = (None, None, None, 0, None, 0)
+            _dispatch(T.conv_forward, self._h, srcs[0].t, srcs[0].c0, s1.t if s1 else None, s1.c0 if s1 else 0, out.t, out.c0, ho, wo,
+                      res.t if res is not None else None, res.c0 if res is not None else 0, out_step, oy, ox, tile, n_classes, *dwa, stream_int())
+            if hook is not None:
+                hook.after(token)
+        else:
+            a = _lib.okp_conv_args()
+            a.n, a.ho, a.wo = out.n, ho, wo
+            for i, s in enumerate(srcs):
+                a.src[i] = s.view()
+            a.out = out.view()
+            a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
+            a.res = res.view() if res is not None else _NULL_TENSOR
+            a.tile = tile
+            a.n_classes = n_classes
+            if dw is not None:
+                dw_w, dw_b, dw_out, dw_res = dw
+                a.dw_w_dev, a.dw_bias_dev = dw_w.data_ptr(), dw_b.data_ptr()
+                a.dw_out = dw_out.view()
+                a.dw_res = dw_res.view() if dw_res is not None else _NULL_TENSOR
+            if hook is not None:
+                self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
+                a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
+                token = hook.before(self, a.tile, macs)
+            _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
+            if hook is not None:
+                hook.after(token)
         COUNTERS["macs"] += macs + macs_dw
         COUNTERS["launches"] += 1
 
@@ -163,12 +193,16 @@ FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256),
 
 def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
     """One-launch fire module (bf16): see okp_fire_forward in include/okp.h."""
-    a = _lib.okp_fire_args()
-    a.n = x.n
-    a.x, a.out = x.view(), out.view()
-    a.stride, a.skip = stride, 1 if skip else 0
-    _lib.check(_lib.lib().okp_fire_forward(squeeze._h, expand._h, wd_dev.data_ptr(), bd_dev.data_ptr(), ctypes.byref(a), stream_handle()),
-               "okp_fire_forward")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.fire_forward, squeeze._h, expand._h, wd_dev, bd_dev, x.t, x.c0, out.t, out.c0, stride, bool(skip), stream_int())
+    else:
+        a = _lib.okp_fire_args()
+        a.n = x.n
+        a.x, a.out = x.view(), out.view()
+        a.stride, a.skip = stride, 1 if skip else 0
+        _lib.check(_lib.lib().okp_fire_forward(squeeze._h, expand._h, wd_dev.data_ptr(), bd_dev.data_ptr(), ctypes.byref(a), stream_handle()),
+                   "okp_fire_forward")
     half = expand.cout
     COUNTERS["macs"] += x.n * x.h * x.w * squeeze.cout * squeeze.cins[0] + out.n * out.h * out.w * half * (expand.cins[0] + 9)
     COUNTERS["launches"] += 1
@@ -181,12 +215,17 @@ FUSE_FIRE_CHAIN = os.environ.get("OKP_FUSE_FIRE_CHAIN", "1") == "1"   # consecut
 def fire_chain(modules, x, out):
     """modules: list of (squeeze plan, expand plan, dw weights, dw bias) of consecutive fire(512, 512) modules; x, out: Acts."""
     n = len(modules)
-    sq = (ctypes.c_void_p * n)(*[m[0]._h for m in modules])
-    ex = (ctypes.c_void_p * n)(*[m[1]._h for m in modules])
-    wd = (ctypes.c_void_p * n)(*[m[2].data_ptr() for m in modules])
-    bd = (ctypes.c_void_p * n)(*[m[3].data_ptr() for m in modules])
-    xv, ov = x.view(), out.view()
-    _lib.check(_lib.lib().okp_fire_chain_forward(n, sq, ex, wd, bd, x.n, ctypes.byref(xv), ctypes.byref(ov), stream_handle()), "okp_fire_chain_forward")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.fire_chain_forward, [m[0]._h for m in modules], [m[1]._h for m in modules], [m[2] for m in modules], [m[3] for m in modules],
+                  x.t, x.c0, out.t, out.c0, stream_int())
+    else:
+        sq = (ctypes.c_void_p * n)(*[m[0]._h for m in modules])
+        ex = (ctypes.c_void_p * n)(*[m[1]._h for m in modules])
+        wd = (ctypes.c_void_p * n)(*[m[2].data_ptr() for m in modules])
+        bd = (ctypes.c_void_p * n)(*[m[3].data_ptr() for m in modules])
+        xv, ov = x.view(), out.view()
+        _lib.check(_lib.lib().okp_fire_chain_forward(n, sq, ex, wd, bd, x.n, ctypes.byref(xv), ctypes.byref(ov), stream_handle()), "okp_fire_chain_forward")
     for m in modules:
         half = m[1].cout
         COUNTERS["macs"] += x.n * x.h * x.w * (m[0].cout * m[0].cins[0] + half * (m[1].cins[0] + 9))
@@ -274,8 +313,12 @@ class StemPlan:
             raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's 16-bit type")
         frames = frames.contiguous()
         n, _, h, w = frames.shape
-        ov = out.view()
-        _lib.check(_lib.lib().okp_stem_forward_nchw(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw")
+        T = _lib.torch_ops()
+        if T is not None:
+            _dispatch(T.stem_forward_nchw, self._h, frames, out.t, out.c0, stream_int())
+        else:
+            ov = out.view()
+            _lib.check(_lib.lib().okp_stem_forward_nchw(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw")
         COUNTERS["macs"] += out.n * out.h * out.w * 128 * 147
         COUNTERS["launches"] += 1
 
@@ -357,9 +400,14 @@ def _head_out_args(n, h, w, outputs, w_dev, bias_dev):
 
 def head_out(src, outputs, w_dev, bias_dev):
     """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
-    a = _head_out_args(src.n, src.h, src.w, outputs, w_dev, bias_dev)
-    a.src = src.view()
-    _lib.check(_lib.lib().okp_head_out_forward(okp_dtype(src.dtype), ctypes.byref(a), stream_handle()), "okp_head_out_forward")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.head_out_forward, src.t, src.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
+                  w_dev, bias_dev, stream_int())
+    else:
+        a = _head_out_args(src.n, src.h, src.w, outputs, w_dev, bias_dev)
+        a.src = src.view()
+        _lib.check(_lib.lib().okp_head_out_forward(okp_dtype(src.dtype), ctypes.byref(a), stream_handle()), "okp_head_out_forward")
     COUNTERS["macs"] += src.n * src.h * src.w * 32 * len(outputs)
     COUNTERS["launches"] += 1
 
@@ -369,9 +417,14 @@ FUSE_HEADS = os.environ.get("OKP_FUSE_HEADS", "1") == "1"    # bf16, 128 feature
 
 def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):
     """The three prediction heads in one launch (okp_heads_forward): l1 256 -> 384, l2 block-diagonal 384 -> 96 plans."""
-    a = _head_out_args(x.n, x.h, x.w, outputs, w_dev, bias_dev)
-    xv = x.view()
-    _lib.check(_lib.lib().okp_heads_forward(l1._h, l2._h, ctypes.byref(a), ctypes.byref(xv), stream_handle()), "okp_heads_forward")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.heads_forward, l1._h, l2._h, x.t, x.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
+                  w_dev, bias_dev, stream_int())
+    else:
+        a = _head_out_args(x.n, x.h, x.w, outputs, w_dev, bias_dev)
+        xv = x.view()
+        _lib.check(_lib.lib().okp_heads_forward(l1._h, l2._h, ctypes.byref(a), ctypes.byref(xv), stream_handle()), "okp_heads_forward")
     COUNTERS["macs"] += x.n * x.h * x.w * (l1.cout * l1.alg_k + l2.cout * l2.alg_k + 32 * len(outputs))
     COUNTERS["launches"] += 1
 
@@ -387,7 +440,11 @@ def peak_nms(heat, cap=64):
     count = torch.empty((n, k), dtype=torch.int32, device=heat.device)
     yx = torch.empty((n, k, cap, 2), dtype=torch.int32, device=heat.device)
     xyc = torch.empty((n, k, cap, 3), dtype=torch.float32, device=heat.device)
-    _lib.check(_lib.lib().okp_peak_nms(heat.data_ptr(), n * k, h, w, cap, count.data_ptr(), yx.data_ptr(), xyc.data_ptr(), stream_handle()), "okp_peak_nms")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.peak_nms, heat, cap, count, yx, xyc, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_peak_nms(heat.data_ptr(), n * k, h, w, cap, count.data_ptr(), yx.data_ptr(), xyc.data_ptr(), stream_handle()), "okp_peak_nms")
     return count, yx, xyc
 
 
@@ -444,8 +501,12 @@ def lift_peaks(cam, count, xyc, depth, max_x, max_y):
     if depth.dtype != torch.float32 or depth.shape[:2] != (n, k):
         raise OkpError("depth must be float32 [N,K,H,W] matching the peak tensors")
     out = torch.empty((n, k, cap, 4), dtype=torch.float64, device=xyc.device)
-    _lib.check(_lib.lib().okp_lift_peaks(ctypes.byref(cam), count.data_ptr(), xyc.data_ptr(), n * k, cap, depth.data_ptr(),
-                                         depth.shape[2], depth.shape[3], max_x, max_y, out.data_ptr(), stream_handle()), "okp_lift_peaks")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.lift_peaks, [cam.fx, cam.fy, cam.cx, cam.cy, cam.d[0], cam.d[1], cam.d[2], cam.d[3]], count, xyc, depth, max_x, max_y, out, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_lift_peaks(ctypes.byref(cam), count.data_ptr(), xyc.data_ptr(), n * k, cap, depth.data_ptr(),
+                                             depth.shape[2], depth.shape[3], max_x, max_y, out.data_ptr(), stream_handle()), "okp_lift_peaks")
     return out
 
 
@@ -464,10 +525,14 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
     votes = torch.empty((n, max_obj, k - 1), dtype=torch.int32, device=dev)
     assign = torch.empty((n, k, cap), dtype=torch.int32, device=dev)
     pred = torch.zeros((n, k, cap, 2), dtype=torch.float64, device=dev)
-    tc = (ctypes.c_int32 * (k - 1))(*[int(c) for c in type_count])
-    _lib.check(_lib.lib().okp_group_objects(count.data_ptr(), xyc.data_ptr(), centers.data_ptr(), n, k, cap, centers.shape[3], centers.shape[4],
-                                            tc, float(max_dist), max_obj, max_sel, n_obj.data_ptr(), sel.data_ptr(), votes.data_ptr(),
-                                            assign.data_ptr(), pred.data_ptr(), stream_handle()), "okp_group_objects")
+    T = _lib.torch_ops()
+    if T is not None:
+        _dispatch(T.group_objects, count, xyc, centers, [int(c) for c in type_count], float(max_dist), max_obj, max_sel, n_obj, sel, votes, assign, pred, stream_int())
+    else:
+        tc = (ctypes.c_int32 * (k - 1))(*[int(c) for c in type_count])
+        _lib.check(_lib.lib().okp_group_objects(count.data_ptr(), xyc.data_ptr(), centers.data_ptr(), n, k, cap, centers.shape[3], centers.shape[4],
+                                                tc, float(max_dist), max_obj, max_sel, n_obj.data_ptr(), sel.data_ptr(), votes.data_ptr(),
+                                                assign.data_ptr(), pred.data_ptr(), stream_handle()), "okp_group_objects")
     return {"n_obj": n_obj, "sel": sel, "n_votes": votes, "assign": assign, "pred": pred}
 
 

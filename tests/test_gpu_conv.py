@@ -454,3 +454,29 @@ def test_patch_resident_kernel_full_size_matches_gather_kernel(case, dtype):
     torch.cuda.synchronize()
     assert torch.equal(out13.t, out6.t)
     assert bool(torch.isfinite(out13.t.float()).all()) and float(out13.t.float().abs().max()) > 0.5
+
+
+@pytest.mark.parametrize("dtype", ALL)
+def test_torch_ops_and_ctypes_bindings_launch_the_same_kernels(dtype):
+    """The two host bindings of the C ABI (torch.ops.okp.* and ctypes) give bit-identical results: same plan, same args."""
+    from object_keypoints_amd import _lib, ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = _dev()
+    assert _lib.torch_ops() is not None
+    x = _q(_rand((2, 64, 20, 24), 61), dtype); r = _q(_rand((2, 128, 20, 24), 62), dtype)
+    wt = _rand((128, 64, 3, 3), 63) / np.sqrt(64 * 9)
+    plan = ops.ConvPlan(dtype, [64], [1], 128, conv_taps(wt.numpy()), np.zeros(128, np.float32), relu=True)
+    xa, ra = ops.Act.from_nchw(x.to(dev), dtype), ops.Act.from_nchw(r.to(dev), dtype)
+    outs = []
+    keep = _lib._torch_ops
+    try:
+        for binding in (keep, None):
+            _lib._torch_ops = binding
+            out = ops.Act.empty(2, 20, 24, 128, dtype, dev)
+            plan([xa], out, 20, 24, res=ra)
+            outs.append(out.t.clone())
+    finally:
+        _lib._torch_ops = keep
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(ops.OkpError):
+        plan([xa], ops.Act.empty(2, 20, 24, 128, dtype, dev), 21, 24)          # output grid does not fit: reported by both bindings

@@ -256,3 +256,25 @@ def test_capacity_default_is_uncapped_like_the_reference():
     from object_keypoints_amd.perception.pipeline import KeypointExtractionComponent
     comp = KeypointExtractionComponent({"keypoint_config": [1, 3]}, [64, 64])
     assert comp.capacity is None and comp.keypoint_config == [1, 1, 3]
+
+
+def test_torch_ops_are_registered_over_the_c_abi():
+    """torch.ops.okp.* (csrc/okp_torch.cpp) is a dispatcher shim over the same extern "C" symbols: every launch entry point the
+    network uses is registered, with the mutated tensors annotated in the schema; without a GPU a call fails with the
+    no-CPU-fallback error instead of computing anything."""
+    import torch
+    from object_keypoints_amd import _lib, ops
+    T = _lib.torch_ops()
+    assert T is not None, "libokp_torch.so is built by object_keypoints_amd.build alongside libokp_hip.so"
+    names = ["conv_forward", "conv_select_tile", "fire_forward", "fire_chain_forward", "heads_forward", "head_out_forward",
+             "stem_forward_nchw", "peak_nms", "lift_peaks", "group_objects"]
+    for n in names:
+        op = getattr(T, n)
+        schema = str(op.default._schema)
+        assert schema.startswith(f"okp::{n}(")
+        if n != "conv_select_tile":
+            assert "(a!)" in schema, schema
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        T.peak_nms(torch.zeros(1, 1, 8, 8), 4, torch.zeros(1, dtype=torch.int32), torch.zeros(8, dtype=torch.int32), torch.zeros(12), 0)
+    with pytest.raises(ops.OkpError):
+        ops.peak_nms(torch.zeros(1, 1, 8, 8))
