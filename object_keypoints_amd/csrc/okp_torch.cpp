@@ -168,7 +168,8 @@ void stem_forward_nchw(int64_t stem, const Tensor& frames, const Tensor& out, in
 }
 
 void peak_nms(const Tensor& heat, int64_t cap, const Tensor& count, const Tensor& yx, const Tensor& xyc, int64_t stream) {
-  TORCH_CHECK(heat.is_cuda() && heat.scalar_type() == at::kFloat && heat.dim() == 4 && heat.is_contiguous(), "okp: heat must be a contiguous float32 [N,K,H,W] device tensor");
+  TORCH_CHECK(heat.is_cuda(), "okp: heat must be a device tensor: the HIP path has no CPU fallback");
+  TORCH_CHECK(heat.scalar_type() == at::kFloat && heat.dim() == 4 && heat.is_contiguous(), "okp: heat must be a contiguous float32 [N,K,H,W] tensor");
   const int64_t maps = heat.size(0) * heat.size(1);
   TORCH_CHECK(count.is_cuda() && count.scalar_type() == at::kInt && count.numel() == maps && yx.scalar_type() == at::kInt && yx.numel() == maps * cap * 2 &&
               xyc.scalar_type() == at::kFloat && xyc.numel() == maps * cap * 3 && yx.is_cuda() && xyc.is_cuda(), "okp: peak buffers do not match the maps / capacity");
