@@ -263,12 +263,13 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       // because loads and stores share the counter.  Later: ring steps ks+1, ks+2 may stay in flight (nd LDS-DMA each)
       // and, when the squeeze weights are streamed, the weight set of step ks+1 issued between them.
       // WAR on the ring: the barrier below frees stage (ks-1) % NST for the LDS-DMA issued right behind it, so every
-      // wave's fragment reads of step ks-1 must have RETURNED before it arrives.  The k-loop is fully unrolled, and
-      // s_barrier orders memory operations only: without the pin, hipcc sinks step ks-1's MFMAs (and the lgkmcnt wait in
-      // front of them) below this barrier, the reads are still queued in the LDS pipe (8 waves x 8 ds_read_b128) when the
-      // refill of their stage lands, and the squeeze tile picks up the next k-chunk's bytes - at N=64 (several tiles per
-      // workgroup, loaded memory system) that happened in most launches (round-1 bug; scripts/probe_fire2_race.py).
-      __builtin_amdgcn_sched_barrier(0);
+      // wave's fragment reads of step ks-1 must have RETURNED before it arrives: the explicit lgkmcnt(0).  The k-loop is
+      // fully unrolled and s_barrier orders memory operations only: without that wait hipcc sinks step ks-1's MFMAs - and
+      // the lgkmcnt wait in front of them - below this barrier, the reads are still queued in the LDS pipe (8 waves x 8
+      // ds_read_b128) when the refill of their stage lands, and the squeeze tile picks up the next k-chunk's bytes.  At N=64
+      // (several tiles per workgroup, loaded memory system) that happened in most launches (round-1 bug, found by
+      // scripts/probe_kernel_determinism.py / probe_fire2_race.py).  The MFMAs themselves may still sink below the barrier
+      // and overlap the next step's reads (pinning them with sched_barrier cost 3 %).
       if (ks == 0 || (OKP_F2DBG & 8)) wait_vm(0);
       else if (ks >= (RES ? NST - 1 : 2))
         wait_vm((ks + 1 < KS1 ? nd + (RES ? 0 : 2) : 0) + (ks + 2 < KS1 ? nd : 0));
