@@ -30,15 +30,6 @@
 
 #include "okp_internal.h"
 
-#ifndef OKP_FIRE2_XCD
-#define OKP_FIRE2_XCD 1
-#endif
-#ifndef OKP_F2DBG
-#define OKP_F2DBG 0    // race hunting: 1 trailing barrier per tile, 2 no cross-tile prefetch, 8 every counted wait is vmcnt(0)
-#endif
-#ifndef OKP_FABL
-#define OKP_FABL 0     // timing ablations (WRONG results): 1 no x LDS-DMA, 2 no phase-1 MFMAs, 4 no phase-2a MFMAs, 8 no depth-wise FMAs, 16 no skip loads, 32 no stores
-#endif
 
 namespace {
 
@@ -171,7 +162,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     // slot % 8 share an L2; give each XCD a contiguous range of tiles - vertically adjacent tiles (tile +- tiles_x) then
     // find each other's halo rows in that L2 instead of fetching them into two.  Bijective for any tile count.
     const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
-    const int tile = OKP_FIRE2_XCD ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3) : slot;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
     n = fastdiv(tile, p.div_tiles_frame);
     const int trem = tile - n * p.tiles_y * p.tiles_x;
     const int ty = fastdiv(trem, p.div_tiles_x);
@@ -199,7 +190,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     }
   };
   auto issue_x = [&](int ks, int stage) {
-    if (OKP_FABL & 1) return;
 #pragma unroll
     for (int i = 0; i < NDM; ++i)
       if (UNI || i < nd)
@@ -218,12 +208,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   for (; tile < p.n_tiles; tile += gridDim.x) {
     int n, y0, x0;
     tile_origin(tile, n, y0, x0);
-    if ((OKP_F2DBG & 2) && tile != (int)blockIdx.x) {
-      __syncthreads();
-      tile_setup(tile);
-#pragma unroll
-      for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
-    }
     // opaque copies: the per-(block, register) pixel arithmetic below is tile-invariant, and hoisting ~100 such
     // values out of the tile loop costs more registers than recomputing them (a multiply-high each)
     int qt = q, tidt = tid;
@@ -240,7 +224,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
         oo[iy] = ok ? oof : kInvalid;
         rr[iy] = u32x4{0u, 0u, 0u, 0u};
-        if (p.skip && !(OKP_FABL & 16)) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
+        if (p.skip) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
         xo += (uint32_t)(p.W * p.x_ps * 2);
         oof += (uint32_t)(p.Wo * p.out_ps * 2);
       }
@@ -270,7 +254,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       // (several tiles per workgroup, loaded memory system) that happened in most launches (round-1 bug, found by
       // scripts/probe_kernel_determinism.py / probe_fire2_race.py).  The MFMAs themselves may still sink below the barrier
       // and overlap the next step's reads (pinning them with sched_barrier cost 3 %).
-      if (ks == 0 || (OKP_F2DBG & 8)) wait_vm(0);
+      if (ks == 0) wait_vm(0);
       else if (ks >= (RES ? NST - 1 : 2))
         wait_vm((ks + 1 < KS1 ? nd + (RES ? 0 : 2) : 0) + (ks + 2 < KS1 ? nd : 0));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,8 +269,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       for (int pb = 0; pb < SP / 16; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          if (OKP_FABL & 2) asm volatile("" ::"v"(a[pb]), "v"(w1f[RES ? ks : ks % 3][b]));
-          else acc[pb][b] = H16<T>::mfma16(a[pb], w1f[RES ? ks : ks % 3][b], acc[pb][b]);
+          acc[pb][b] = H16<T>::mfma16(a[pb], w1f[RES ? ks : ks % 3][b], acc[pb][b]);
     }
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     u32x4 waf[2][KS2];
@@ -337,7 +320,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         for (int r = 0; r < 4; ++r) {
           o_off[pb][r] = orr[r] == kInvalid ? kInvalid : ob + orr[r];
           r_raw[pb][r] = 0;
-          if (p.skip && !(OKP_FABL & 16) && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
+          if (p.skip && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
         }
       }
       f32x4 ac2[PBI][2];
@@ -354,8 +337,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_S + a_row[pb] + (((uint32_t)(4 * ks + qt) ^ a_key[pb]) << 4));
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              if (OKP_FABL & 4) asm volatile("" ::"v"(a), "v"(waf[b][ks]));
-              else ac2[pb][b] = H16<T>::mfma16(a, waf[b][ks], ac2[pb][b]);
+              ac2[pb][b] = H16<T>::mfma16(a, waf[b][ks], ac2[pb][b]);
           }
         }
       }
@@ -365,8 +347,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t v = okp_pack2<T>(fmaxf(ac2[pb][0][r] + H16<T>::lo(r_raw[pb][r]), 0.f), fmaxf(ac2[pb][1][r] + H16<T>::hi(r_raw[pb][r]), 0.f));
-            if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, (int)o_off[pb][r], 0, 0);
-            else asm volatile("" ::"v"(v));
+            __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, (int)o_off[pb][r], 0, 0);
           }
         }
       }
@@ -393,7 +374,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         if (!prefetched) {
           prefetched = true;
           const int next = tile + gridDim.x;
-          if (next < p.n_tiles && !(OKP_F2DBG & 2)) {
+          if (next < p.n_tiles) {
             tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
             if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
 #pragma unroll
@@ -416,7 +397,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           }
 #pragma unroll
           for (int sr = 0; sr < STR * (MAXIH - 1) + 3; ++sr) {   // squeeze row sr is tap row dy of output row (sr - dy) / STR
-            if (!(OKP_FABL & 8) && sr < STR * (p.IH - 1) + 3) {
+            if (sr < STR * (p.IH - 1) + 3) {
               const int sp = sr * p.SW + STR * ixc + dx;
               const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
               f32x2 s2[4];
@@ -442,13 +423,11 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const float hi = fmaxf(v[iy][e][1] + H16<T>::hi(rr[iy][e]), 0.f);
             o[e] = okp_pack2<T>(lo, hi);
           }
-          if (!(OKP_FABL & 32)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
-          else asm volatile("" ::"v"(o));
+          __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
         }
       }
     }
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
-    if (OKP_F2DBG & 1) __syncthreads();
   }
 }
 
@@ -469,10 +448,8 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
   // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
   long best = -1;
-  static const int force_ih = [] { const char* e = getenv("OKP_FIRE2_IH"); return e ? atoi(e) : 0; }();   // experiment knob
   for (int ih = 1; ih <= p.Ho && ih <= MAXIH; ++ih)
     for (int iw = 1; iw <= p.Wo && iw <= 96; ++iw) {
-      if (force_ih && ih != force_ih && force_ih <= p.Ho) continue;
       const int sh = stride * (ih - 1) + 3, sw = stride * (iw - 1) + 3;
       if (sh * sw > SP || ih * iw > 16 * PBI) continue;
       const long ty = (p.Ho + ih - 1) / ih, tx = (p.Wo + iw - 1) / iw;

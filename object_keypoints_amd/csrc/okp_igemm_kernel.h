@@ -21,12 +21,6 @@
 
 #include "okp_internal.h"
 
-#ifndef OKP_XB
-#define OKP_XB 1
-#endif
-#ifndef OKP_ABL
-#define OKP_ABL 0     // timing ablations (WRONG results): 1 = no LDS-DMA in the main loop, 2 = no MFMAs, 3 = no fragment reads
-#endif
 
 namespace {
 
@@ -284,7 +278,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // problem, chunks beyond Cin) use an offset past the buffer: the hardware range check then writes zeros
   // to LDS (verified by scripts/hwtests/dma_oob.hip).
   auto issue_w = [&](int t, int stage) {       // t = ring step = slice * HPS + half
-    if (OKP_ABL == 1) return;
     const uint32_t wslice = (uint32_t)(sbase + t / HPS) * (uint32_t)p.cout_pad * 128u + (uint32_t)(t % HPS) * 64u;
     char* const wt = smem + stage * STAGE + wave * 1024;
 #pragma unroll
@@ -292,7 +285,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * RPP * KB), 16, (int)(wbase[i] + wslice), 0, 0, 0);
   };
   auto issue_x = [&](int t, const SliceMeta& m, int stage) {
-    if (OKP_ABL == 1) return;
     const int half = t % HPS;                                    // KB == 64: which 64-byte half of the slice
     const bool hi_half = (KB == 128) ? (c >= 4) : (half != 0);
     const uint32_t delta = (uint32_t)(hi_half ? m.d_hi : m.d_lo);
@@ -319,13 +311,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   };
 
   auto load_frag = [&](int stage, int kk, u32x4 (&a)[TCO], u32x4 (&b)[TPX]) {
-    if (OKP_ABL == 3) {
-#pragma unroll
-      for (int i = 0; i < TCO; ++i) asm volatile("" : "+v"(a[i]));
-#pragma unroll
-      for (int j = 0; j < TPX; ++j) asm volatile("" : "+v"(b[j]));
-      return;
-    }
     const char* wt = smem + stage * STAGE;
     const char* xt = wt + BCO * KB;
 #pragma unroll
@@ -334,13 +319,6 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4*>(xt + swz<KB>((wpx * TPX + j) * MT + fr, CHK * kk + fh));
   };
   auto mma_step = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX]) {
-    if (OKP_ABL == 2) {
-#pragma unroll
-      for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-      for (int j = 0; j < TPX; ++j) asm volatile("" ::"v"(b[j]));
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < TCO; ++i)
 #pragma unroll
@@ -368,7 +346,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // step t is computed AFTER the barrier that opens step t+1, so its MFMAs cover the latency of step t+1's first
   // fragment reads and the issue slots of the next LDS-DMA.  Without it every wave leaves the barrier with empty
   // fragment registers and the matrix cores idle until the first ds_reads return (all waves in lock step).
-  constexpr bool XB = OKP_XB && (MT == 32 || WCO * WPX == 4);
+  constexpr bool XB = MT == 32 || WCO * WPX == 4;
   if constexpr (XB) {
     auto mma_half = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX], auto half) {     // first / second half of the rows
       constexpr int I0 = decltype(half)::value ? (TCO + 1) / 2 : 0;

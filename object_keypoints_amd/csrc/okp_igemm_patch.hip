@@ -2,7 +2,7 @@
 //
 // okp_igemm_kernel gathers the pixel operand of EVERY K-slice from L2: a 3x3 convolution moves each input line nine
 // times into LDS (32 KiB of pixels + 32 KiB of weights per slice and workgroup).  Timing ablations of that kernel
-// (OKP_ABL in okp_igemm_kernel.h, conv 256->256 at 64x64, N=64) gave 269 us complete, 185 us without the LDS-DMA and
+// (round 1; conv 256->256 at 64x64, N=64) gave 269 us complete, 185 us without the LDS-DMA and
 // 194 us without the MFMAs: the L2 -> LDS stream costs as much as the matrix work and the two overlap poorly.
 //
 // Here a workgroup owns 256 output channels x one 16x16-pixel block of ONE frame.  For each 64-channel chunk of a source
@@ -31,12 +31,6 @@
 
 #include "okp_igemm_kernel.h"
 
-#ifndef OKP_PPIPE
-#define OKP_PPIPE 1
-#endif
-#ifndef OKP_PABL
-#define OKP_PABL 0    // timing ablations (WRONG results): bit 0 = no weight DMA, bit 1 = no patch DMA, bit 2 = no MFMAs, bit 3 = DMA never waited for, bit 4 = no epilogue
-#endif
 
 namespace {
 
@@ -77,8 +71,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
 
-  unsigned long long clk0 = 0, rt0 = 0;
-  if (p.dbg) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   if (tid < p.n_steps) reinterpret_cast<u32x4*>(steps_lds)[tid] = reinterpret_cast<const u32x4*>(p.steps)[tid];
   __syncthreads();
 
@@ -112,7 +104,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     }
 
     auto issue_w = [&](int t, int stage) {
-      if (OKP_PABL & 1) return;
       const uint32_t wslice = (uint32_t)t * (uint32_t)p.cout_pad * 128u;
       char* const wt = smem + stage * kWStage + wave * 1024;
 #pragma unroll
@@ -121,7 +112,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     };
     // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
     auto issue_patch = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
-      if (OKP_PABL & 2) return;
       const OkpPatchGeom& G = p.g[geom];                         // uniform index into the kernel arguments: scalar loads
       const int PW = G.PW, npx = G.npx;                          // valid columns; rows x kPitch
       const int H = G.H, W = G.W, ps2 = G.pix_stride * 2, step = G.step;
@@ -168,7 +158,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 
       // my part of step t's weights (and of its patch) has landed, and my fragment reads of step t-1 have returned (the
       // barrier frees their stage / patch buffer for the next LDS-DMA)
-      if (!(OKP_PABL & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
 
       const char* const wt = smem + (t & 1) * kWStage;
@@ -178,7 +168,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       // for all eight j, which are then reached by immediate offsets of one row pitch (kPitch * 128 bytes).
       const char* const bb = pbase + tap_bytes + (uint32_t)((wpx * TPX * kPitch + fr) * 128);
       const uint32_t bsw = patch_key(fr + dxo);
-#if OKP_PPIPE
       // Fragment pipeline: the pixel fragments are read two at a time, one pair ahead of the eight MFMAs that use
       // them, and the second k-step's weight fragments during the first k-step - so the LDS reads of a wave run
       // under its own MFMAs instead of in a burst after the barrier that all eight waves issue (and wait for) together.
@@ -190,12 +179,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       };
       auto mma8 = [&](const u32x4 (&a)[TCO], const u32x4 (&bq)[2], auto s) {
         constexpr int S = decltype(s)::value;
-        if (OKP_PABL & 4) {
-#pragma unroll
-          for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
-          asm volatile("" ::"v"(bq[0]), "v"(bq[1]));
-          return;
-        }
 #pragma unroll
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
@@ -238,44 +221,10 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       __builtin_amdgcn_sched_barrier(0);
       mma8(a1, bq0, S2{});
       mma8(a1, bq1, S3{});
-#else
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        u32x4 a[TCO], b[TPX];
-#pragma unroll
-        for (int i = 0; i < TCO; ++i) a[i] = *reinterpret_cast<const u32x4*>(wt + swz<128>((wco * TCO + i) * 16 + fr, 4 * kk + fh));
-#pragma unroll
-        for (int j = 0; j < TPX; ++j) {
-          // patch pixel of tile row wpx*8 + j, column fr, shifted by the tap: the swizzle follows the patch row index
-          b[j] = *reinterpret_cast<const u32x4*>(bb + j * (kPitch * 128) + ((((uint32_t)(4 * kk + fh)) ^ bsw) << 4));
-        }
-        if (kk == 0 && more) issue_w(t + 1, (t + 1) & 1);
-        if (kk == 1 && next_patch) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
-        if (OKP_PABL & 4) {
-#pragma unroll
-          for (int i = 0; i < TCO; ++i) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-          for (int j = 0; j < TPX; ++j) asm volatile("" ::"v"(b[j]));
-          continue;
-        }
-#pragma unroll
-        for (int i = 0; i < TCO; ++i)
-#pragma unroll
-          for (int j = 0; j < TPX; ++j)
-            acc[i][j] = H16<T>::mfma16(a[i], b[j], acc[i][j]);
-      }
-#endif
     }
     __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
 
     // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
-    if (OKP_PABL & 16) {
-#pragma unroll
-      for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPX; ++j) asm volatile("" ::"v"(acc[i][j]));
-      continue;
-    }
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
       const int co_l = (wco * TCO + i) * 16 + 4 * fh;
@@ -344,10 +293,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     }
     __syncthreads();                               // staging is free again: the next tile's LDS-DMA may overwrite it
   }
-  if (p.dbg && blockIdx.x == 0 && tid == 0) {
-    p.dbg[0] = __builtin_readcyclecounter() - clk0;
-    p.dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-  }
 }
 
 }  // namespace
@@ -387,20 +332,7 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;
   const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
-  static unsigned long long* dbg = [] {
-    unsigned long long* d = nullptr;
-    const char* e = getenv("OKP_PCLK");
-    if (e && e[0] == '1') (void)hipMalloc((void**)&d, 16);
-    return d;
-  }();
-  p.dbg = dbg;
   if (plan->dtype == OKP_BF16) hipLaunchKernelGGL(okp_igemm_patch_kernel<__bf16>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(okp_igemm_patch_kernel<_Float16>, grid, block, 0, stream, p);
-  if (dbg) {
-    unsigned long long h[2] = {0, 0};
-    (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(h, dbg, 16, hipMemcpyDeviceToHost);
-    fprintf(stderr, "okp_igemm_patch: workgroup 0 ran %llu shader clocks in %.1f us -> %.3f GHz\n", h[0], h[1] / 100.0, h[1] ? h[0] / (h[1] * 10.0) : 0.0);
-  }
   return okp_check_hip(hipGetLastError(), "okp_igemm_patch launch");
 }

@@ -157,7 +157,6 @@ struct OkpPatchParams {
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
   int32_t act, n_co_tiles, n_tiles;
-  unsigned long long* dbg;     // OKP_PCLK=1: {shader clocks, 100 MHz ticks} of workgroup 0 (diagnostic)
 };
 
 struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 128 -> 256, stride 1

@@ -137,3 +137,105 @@ def test_graph_replay_equals_eager_at_batch64(side):
     net.load_state_dict(net.state_dict())
     with pytest.raises(pp.OkpError):
         step.replay(x1)
+
+
+def test_config4_cups_multi_object_batch64():
+    """BASELINE configs[3], one rank's share: 64 frames, config/cups.json (K = 4: centre + three single-instance keypoint
+    types), multi-object scenes (4 objects per frame).  The bf16 network runs the 64 frames (shapes of the four-map heads,
+    frame independence), and peaks -> 3D -> objects on the injected scenes equal the oracle's pipeline frame by frame for
+    a sample; `points` is the fixed-capacity all-gather payload [64, 4, cap, 4] (NaN = unused slot)."""
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import pipeline as op
+    cfg = {"keypoint_config": [1, 1, 1]}
+    net = _net(torch.bfloat16, k=4)
+    cam_o = op.eval_camera(CALIB)
+    pipe = pp.BatchedKeypointPipeline(net, cfg, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size), capacity=128)
+    x = _frames(64, seed=11)
+    with torch.no_grad():
+        out = pipe.forward_device(x)
+        assert tuple(out["heat"].shape) == (64, 4, 64, 64) and tuple(out["centers"].shape) == (64, 3, 2, 64, 64)
+        assert tuple(out["points"].shape) == (64, 4, 128, 4) and out["points"].dtype == torch.float64
+        rev = pipe.forward_device(torch.flip(x, dims=[0]).contiguous())
+        assert torch.equal(out["heat"], torch.flip(rev["heat"], dims=[0])) and torch.equal(out["count"], torch.flip(rev["count"], dims=[0]))
+    scenes = [synth.bump_scene([1, 1, 1], n_objects=4, seed=31, index=i) for i in range(64)]
+    to = lambda key: torch.from_numpy(np.stack([s[key] for s in scenes])).cuda()
+    post = pipe.postprocess_device(to("heat"), to("depth"), to("centers"))
+    assert not bool(post["overflow"])
+    pts = post["points"].cpu().numpy()
+    cnt = post["count"].cpu().numpy()
+    assert int(cnt[:, 0].min()) >= 3                       # the four centres (two may merge inside one 5x5 window)
+    for n in range(64):
+        for k in range(4):
+            c = int(cnt[n, k])
+            assert np.isnan(pts[n, k, c:]).all() and not np.isnan(pts[n, k, :c]).any()
+    opipe = op.ObjectKeypointPipeline([64, 64], None, cfg)
+    opipe.reset(cam_o)
+    for n in (0, 21, 42, 63):
+        want = opipe(scenes[n]["heat"][None], scenes[n]["depth"][None], scenes[n]["centers"][None])
+        got = pipe.objects(post, n)
+        assert len(got) == len(want) >= 3
+        for g, w_ in zip(got, want):
+            for a, b in zip(g["keypoints"], w_["keypoints"]):
+                assert np.asarray(a).shape == np.asarray(b).shape
+                if np.asarray(a).size:
+                    np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+            for a, b in zip(g["p_C"], w_["p_C"]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)          # north_star: 3D points within 1e-4 m
+
+
+def test_config5_stereo_stream_fp16_network_fp32_geometry():
+    """BASELINE configs[4] in miniature: 8 camera streams = 4 stereo pairs, fp16 convolutions, fp32 / fp64 geometry.
+    (a) the fp16 network on the 8 frames stays within the recorded fp16 error of the fp32 HIP path (which meets the 1e-3
+    bar against the reference), frame by frame; (b) on heat maps rendered from known 3D points through the left and right
+    cameras, peaks -> association -> triangulation recover the points: the geometry never sees fp16."""
+    import json
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import geometry as og
+    _need(torch.float16)
+    x = _frames(8, seed=21)
+    with torch.no_grad():
+        h16, d16, c16 = _net(torch.float16).deployed(x)
+        h32, d32, c32 = _net(torch.float32).deployed(x)
+    with open(os.path.join(REPO, "tests", "golden", "precision_measured.json")) as f:
+        rec = json.load(f)["valve_k3"]["f16"]
+    for n in range(8):
+        assert float((h16[n] - h32[n]).abs().max()) <= 2.0 * rec["heat"]["max"]
+        assert float((d16[n] - d32[n]).abs().max()) <= 2.0 * rec["depth"]["max"]
+    assert h16.dtype == torch.float32 and d16.dtype == torch.float32          # heads hand fp32 maps to the geometry stage
+    p = og.load_calibration_params(CALIB)
+    scale = 0.25
+    oleft = og.FisheyeCamera(p["K"], p["D"], p["image_size"]).scale(scale)
+    oright = og.FisheyeCamera(p["Kp"], p["Dp"], p["image_size"]).scale(scale)
+    stereo = cu.StereoCamera(cu.FisheyeCamera(oleft.K, oleft.D, oleft.image_size), cu.FisheyeCamera(oright.K, oright.D, oright.image_size), p["T_RL"])
+    assoc = pp.AssociationComponent(max_distance=3.0); assoc.reset(stereo)
+    tri = pp.TriangulationComponent(); tri.reset(stereo)
+    H, W = 180, 320
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    base = np.array([[0.05, 0.02, 1.0], [0.21, 0.10, 1.1], [-0.18, -0.12, 0.9], [0.10, -0.20, 1.2], [-0.25, 0.15, 1.05]])
+    maps, truth = [], []
+    for pair in range(4):                                  # four rigs looking at the point set from slightly different poses
+        # (points well separated across epipolar lines: matching by epipolar distance alone is ambiguous otherwise)
+        X = base * np.array([1.0 - 0.04 * pair, 1.0 + 0.03 * pair, 1.0]) + np.array([0.01 * pair, -0.008 * pair, 0.05 * pair])
+        truth.append(X)
+        for cam, T in ((oleft, np.eye(4)), (oright, p["T_RL"])):
+            m = np.zeros((H, W), np.float32)
+            for px, py in cam.project(X, T):
+                m += np.exp(-((xs - px) ** 2 + (ys - py) ** 2) / 4.0).astype(np.float32)
+            maps.append(np.clip(m, 0, 1))
+    heat = torch.from_numpy(np.stack(maps)[:, None]).cuda()                 # [8 streams, 1 map, H, W]: ONE launch for all cameras
+    count, _, xyc = [t.cpu().numpy() for t in ops.peak_nms(heat, cap=16)]
+    for pair in range(4):
+        cl, cr = int(count[2 * pair, 0]), int(count[2 * pair + 1, 0])
+        left2d, right2d = xyc[2 * pair, 0, :cl, :2].astype(np.float64), xyc[2 * pair + 1, 0, :cr, :2].astype(np.float64)
+        match = assoc(left2d, right2d)
+        ok = match >= 0
+        assert ok.sum() >= 4                               # two bumps of a view may merge; the rest must pair up
+        X_hat = tri(left2d[ok], right2d[match[ok]])
+        d = np.linalg.norm(X_hat[:, None] - truth[pair][None], axis=2)
+        assert d.min(axis=1).max() < 0.05, d.min(axis=1)
