@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 1
+#define OKP_ABI_VERSION 2     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan... */
 
 enum { OKP_F32 = 0, OKP_BF16 = 1, OKP_F16 = 2 };   /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]) */
 enum { OKP_ACT_NONE = 0, OKP_ACT_RELU = 1, OKP_ACT_SIGMOID = 2 };
@@ -241,11 +241,18 @@ int okp_nms_maxpool(const float* x_dev, int32_t n_maps, int32_t h, int32_t w, in
 
 /* ------------------------------------------------------------------------------------
  * Geometry (fp64 on device).
- * okp_camera: pinhole + Kalibr "equidistant" (OpenCV fisheye) distortion.
+ * okp_camera: pinhole + distortion.  model OKP_CAM_EQUIDISTANT: Kalibr "equidistant" = OpenCV fisheye, d = k1..k4
+ * (FisheyeCamera, utils/camera_utils.py:64-81); model OKP_CAM_RADTAN: Kalibr "radtan" = OpenCV plumb-bob, d = k1, k2, p1, p2
+ * (RadTanPinholeCamera, camera_utils.py:45-62: cv2.undistortPoints with P = K, five fixed-point iterations in OpenCV 3.4).
+ * Every entry point that undistorts (okp_unproject_depth, okp_lift_peaks, okp_triangulate_dlt, okp_camera_undistort)
+ * follows the camera's model.
  * ---------------------------------------------------------------------------------- */
+enum { OKP_CAM_EQUIDISTANT = 0, OKP_CAM_RADTAN = 1 };
 typedef struct okp_camera {
   double fx, fy, cx, cy;
   double d[4];
+  int32_t model;
+  int32_t reserved;
 } okp_camera;
 
 /* Replaces DetectionToPoint.__call__ (perception/pipeline.py:164-171) =
@@ -296,7 +303,9 @@ int okp_triangulate_dlt(const okp_camera* left, const okp_camera* right, const d
                         const float* left_xy_dev, const float* right_xy_dev, int32_t m,
                         double* out_dev, void* stream);
 
-/* Undistort only (FisheyeCamera.undistort, camera_utils.py:75-81): xy [m][2] fp32 -> out [m][2] fp64. */
+/* Undistort only (FisheyeCamera.undistort, camera_utils.py:75-81 / RadTanPinholeCamera.undistort, :57-62, by cam->model):
+ * xy [m][2] fp32 -> out [m][2] fp64.  okp_fisheye_undistort is the same entry point under its round-1 name. */
+int okp_camera_undistort(const okp_camera* cam, const float* xy_dev, int32_t m, double* out_dev, void* stream);
 int okp_fisheye_undistort(const okp_camera* cam, const float* xy_dev, int32_t m, double* out_dev, void* stream);
 
 #ifdef __cplusplus

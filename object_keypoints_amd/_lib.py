@@ -11,6 +11,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 LIB_PATH = os.environ.get("OKP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_hip.so")   # OKP_LIB: A/B builds
 
 OKP_F32, OKP_BF16, OKP_F16 = 0, 1, 2
+OKP_ABI = 2
+CAM_EQUIDISTANT, CAM_RADTAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 HEAD_MAX_OUT = 32
 
@@ -48,7 +50,8 @@ class okp_head_out_args(Structure):
 
 
 class okp_camera(Structure):
-    _fields_ = [("fx", c_double), ("fy", c_double), ("cx", c_double), ("cy", c_double), ("d", c_double * 4)]
+    _fields_ = [("fx", c_double), ("fy", c_double), ("cx", c_double), ("cy", c_double), ("d", c_double * 4),
+                ("model", c_int32), ("reserved", c_int32)]
 
 
 # every symbol include/okp.h declares: (name, restype, argtypes)
@@ -84,6 +87,7 @@ SIGNATURES = [
     ("okp_group_objects", c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("okp_triangulate_dlt", c_int, [POINTER(okp_camera), POINTER(okp_camera), POINTER(c_double), POINTER(c_double), c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_fisheye_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),
+    ("okp_camera_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),
 ]
 
 _lib = None
@@ -111,7 +115,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError = ABI mismatch, let it surface
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.okp_abi_version() != 1:
+        if handle.okp_abi_version() != OKP_ABI:
             raise OkpError("libokp_hip.so ABI version mismatch")
         _lib = handle
     return _lib

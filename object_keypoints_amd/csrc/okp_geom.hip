@@ -32,11 +32,34 @@ __device__ __forceinline__ void fisheye_undistort(const okp_camera& cam, double 
   yu = cam.fy * (pwy * scale) + cam.cy;
 }
 
+// cv2.undistortPoints(xy, K, D, P=K) of OpenCV 3.4 for the plumb-bob model with D = (k1, k2, p1, p2): five fixed-point iterations
+//   x <- (x0 - (2 p1 x y + p2 (r^2 + 2 x^2))) / (1 + k1 r^2 + k2 r^4),  y likewise with p1 (r^2 + 2 y^2) + 2 p2 x y
+__device__ __forceinline__ void radtan_undistort(const okp_camera& cam, double u, double v, double& xu, double& yu) {
+  const double x0 = (u - cam.cx) / cam.fx, y0 = (v - cam.cy) / cam.fy;
+  const double k1 = cam.d[0], k2 = cam.d[1], p1 = cam.d[2], p2 = cam.d[3];
+  double x = x0, y = y0;
+  for (int j = 0; j < 5; ++j) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2);
+    const double dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+    const double dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  xu = cam.fx * x + cam.cx;
+  yu = cam.fy * y + cam.cy;
+}
+
+__device__ __forceinline__ void camera_undistort(const okp_camera& cam, double x, double y, double& xu, double& yu) {
+  if (cam.model == OKP_CAM_RADTAN) radtan_undistort(cam, x, y, xu, yu);
+  else fisheye_undistort(cam, x, y, xu, yu);
+}
+
 __global__ void okp_undistort_kernel(okp_camera cam, const float* __restrict__ xy, int m, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   double xu, yu;
-  fisheye_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
+  camera_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
   out[2 * i] = xu;
   out[2 * i + 1] = yu;
 }
@@ -55,7 +78,7 @@ __global__ void okp_unproject_kernel(okp_camera cam, const float* __restrict__ x
   // cv2 returns the dtype it was given: the reference passes float32 peaks, so the undistorted
   // point is rounded to float32 before it is used (pipeline.py:167-171).
   double xu, yu;
-  fisheye_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
+  camera_undistort(cam, (double)xy[2 * i], (double)xy[2 * i + 1], xu, yu);
   const float xf = (float)xu, yf = (float)yu;
   int xi = (int)rintf(xf), yi = (int)rintf(yf);        // numpy round = half to even
   xi = min(max(xi, 0), max_x);
@@ -81,7 +104,7 @@ __global__ void okp_lift_peaks_kernel(okp_camera cam, const int* __restrict__ co
   }
   const float* pk = xyc + (size_t)i * 3;
   double xu, yu;
-  fisheye_undistort(cam, (double)pk[0], (double)pk[1], xu, yu);
+  camera_undistort(cam, (double)pk[0], (double)pk[1], xu, yu);
   const float xf = (float)xu, yf = (float)yu;
   int xi = (int)rintf(xf), yi = (int)rintf(yf);
   xi = min(max(xi, 0), max_x);
@@ -375,8 +398,8 @@ __global__ void okp_triangulate_kernel(TriParams tp, const float* __restrict__ l
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   double xl, yl, xr, yr;
-  fisheye_undistort(tp.left, (double)lxy[2 * i], (double)lxy[2 * i + 1], xl, yl);
-  fisheye_undistort(tp.right, (double)rxy[2 * i], (double)rxy[2 * i + 1], xr, yr);
+  camera_undistort(tp.left, (double)lxy[2 * i], (double)lxy[2 * i + 1], xl, yl);
+  camera_undistort(tp.right, (double)rxy[2 * i], (double)rxy[2 * i + 1], xr, yr);
   // cv2 hands float32 back for float32 input (camera_utils.py:93-97)
   xl = (double)(float)xl; yl = (double)(float)yl; xr = (double)(float)xr; yr = (double)(float)yr;
   if (tp.correct) {
@@ -410,10 +433,15 @@ __global__ void okp_triangulate_kernel(TriParams tp, const float* __restrict__ l
 }  // namespace
 
 extern "C" int okp_fisheye_undistort(const okp_camera* cam, const float* xy, int32_t m, double* out, void* stream) {
-  if (!cam || (m > 0 && (!xy || !out))) { okp_set_error("okp_fisheye_undistort: null argument"); return OKP_EINVAL; }
+  return okp_camera_undistort(cam, xy, m, out, stream);
+}
+
+extern "C" int okp_camera_undistort(const okp_camera* cam, const float* xy, int32_t m, double* out, void* stream) {
+  if (!cam || (m > 0 && (!xy || !out))) { okp_set_error("okp_camera_undistort: null argument"); return OKP_EINVAL; }
+  if (cam->model != OKP_CAM_EQUIDISTANT && cam->model != OKP_CAM_RADTAN) { okp_set_error("okp_camera_undistort: unknown camera model %d", cam->model); return OKP_EINVAL; }
   if (m <= 0) return OKP_OK;
   hipLaunchKernelGGL(okp_undistort_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cam, xy, m, out);
-  return okp_check_hip(hipGetLastError(), "okp_fisheye_undistort launch");
+  return okp_check_hip(hipGetLastError(), "okp_camera_undistort launch");
 }
 
 extern "C" int okp_unproject_depth(const okp_camera* cam, const float* xy, const int32_t* map_id, int32_t m,

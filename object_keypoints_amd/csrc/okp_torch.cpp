@@ -178,8 +178,8 @@ void peak_nms(const Tensor& heat, int64_t cap, const Tensor& count, const Tensor
 }
 
 inline okp_camera camera_of(at::ArrayRef<double> c) {
-  TORCH_CHECK(c.size() == 8, "okp: camera = [fx, fy, cx, cy, d0, d1, d2, d3]");
-  okp_camera cam{c[0], c[1], c[2], c[3], {c[4], c[5], c[6], c[7]}};
+  TORCH_CHECK(c.size() == 9, "okp: camera = [fx, fy, cx, cy, d0, d1, d2, d3, model]");
+  okp_camera cam{c[0], c[1], c[2], c[3], {c[4], c[5], c[6], c[7]}, (int32_t)c[8], 0};
   return cam;
 }
 

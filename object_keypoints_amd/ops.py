@@ -460,7 +460,7 @@ def nms_maxpool(x, size=5):
     return out
 
 
-def make_camera(K, D):
+def make_camera(K, D, model=_lib.CAM_EQUIDISTANT):
     K = np.asarray(K, dtype=np.float64)
     D = np.asarray(D, dtype=np.float64).reshape(-1)
     if abs(K[0, 1]) > 1e-12 or abs(K[1, 0]) > 1e-12:
@@ -468,15 +468,20 @@ def make_camera(K, D):
     cam = _lib.okp_camera(K[0, 0], K[1, 1], K[0, 2], K[1, 2])
     for i in range(4):
         cam.d[i] = D[i] if i < D.size else 0.0
+    cam.model = model
     return cam
 
 
-def fisheye_undistort(cam, xy):
+def camera_undistort(cam, xy):
+    """xy [M,2] pixels (device) -> [M,2] fp64 undistorted pixels (P = K), by the camera's distortion model."""
     require_cuda(xy, "xy")
     xy = xy.to(torch.float32).contiguous()
     out = torch.empty((xy.shape[0], 2), dtype=torch.float64, device=xy.device)
-    _lib.check(_lib.lib().okp_fisheye_undistort(ctypes.byref(cam), xy.data_ptr(), xy.shape[0], out.data_ptr(), stream_handle()), "okp_fisheye_undistort")
+    _lib.check(_lib.lib().okp_camera_undistort(ctypes.byref(cam), xy.data_ptr(), xy.shape[0], out.data_ptr(), stream_handle()), "okp_camera_undistort")
     return out
+
+
+fisheye_undistort = camera_undistort
 
 
 def unproject_depth(cam, xy, map_id, depth, max_x, max_y):
@@ -503,7 +508,7 @@ def lift_peaks(cam, count, xyc, depth, max_x, max_y):
     out = torch.empty((n, k, cap, 4), dtype=torch.float64, device=xyc.device)
     T = _lib.torch_ops()
     if T is not None:
-        _dispatch(T.lift_peaks, [cam.fx, cam.fy, cam.cx, cam.cy, cam.d[0], cam.d[1], cam.d[2], cam.d[3]], count, xyc, depth, max_x, max_y, out, stream_int())
+        _dispatch(T.lift_peaks, [cam.fx, cam.fy, cam.cx, cam.cy, cam.d[0], cam.d[1], cam.d[2], cam.d[3], float(cam.model)], count, xyc, depth, max_x, max_y, out, stream_int())
     else:
         _lib.check(_lib.lib().okp_lift_peaks(ctypes.byref(cam), count.data_ptr(), xyc.data_ptr(), n * k, cap, depth.data_ptr(),
                                              depth.shape[2], depth.shape[3], max_x, max_y, out.data_ptr(), stream_handle()), "okp_lift_peaks")

@@ -1,9 +1,9 @@
 """Drop-in for the hot-path part of the reference's perception/utils/camera_utils.py (:7-110,119-189).
 
-Same classes and method signatures (PinholeCamera, FisheyeCamera, StereoCamera, camera_matrix,
+Same classes and method signatures (PinholeCamera, RadTanPinholeCamera, FisheyeCamera, StereoCamera, camera_matrix,
 projection_matrix, load_calibration_params, scale_camera_matrix, fundamental_matrix); the OpenCV
 calls of the reference (cv2.fisheye.undistortPoints, cv2.correctMatches, cv2.triangulatePoints) are
-replaced by fp64 HIP kernels behind the C ABI (okp_fisheye_undistort, okp_triangulate_dlt).
+replaced by fp64 HIP kernels behind the C ABI (okp_camera_undistort, okp_triangulate_dlt).
 NumPy arrays in, NumPy arrays out, as in the reference; there is no CPU implementation of the hot path here.
 `FisheyeCamera.project` (reference :47-56: cv2.fisheye.projectPoints; used by the evaluation harness, the labelling tool
 and the data sets, never per frame on the inference path) is plain host NumPy: the Kalibr equidistant model, which
@@ -50,8 +50,35 @@ class PinholeCamera:
         over = (x >= self.image_size).any(axis=1)
         return np.bitwise_or(under, over) == False  # noqa: E712
 
+    MODEL = 0          # okp_camera.model: 0 = equidistant (FisheyeCamera), 1 = radtan (RadTanPinholeCamera)
+
     def okp(self):
-        return ops.make_camera(self.K, self.D)
+        return ops.make_camera(self.K, self.D, self.MODEL)
+
+    def undistort(self, xy):
+        """xy: N x 2 image points -> N x 2 undistorted points (device kernel), in the dtype given (as cv2 does)."""
+        xy = np.asarray(xy)
+        out = ops.camera_undistort(self.okp(), torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32)).to(_device()))
+        out = out.cpu().numpy()
+        return out.astype(xy.dtype) if xy.dtype in (np.float32, np.float64) else out
+
+
+class RadTanPinholeCamera(PinholeCamera):
+    """Kalibr "radtan" = OpenCV plumb-bob with D = (k1, k2, p1, p2) (reference camera_utils.py:45-62).  `undistort` is the device
+    kernel (cv2.undistortPoints with P = K: five fixed-point iterations); `project` is host NumPy like FisheyeCamera.project.
+    As in the reference, scale() / cut() return a FisheyeCamera (PinholeCamera's methods construct one, camera_utils.py:18-29)."""
+    MODEL = 1
+
+    def project(self, X, T_CW=np.eye(4)):
+        X = linalg.transform_points(np.asarray(T_CW, dtype=np.float64), np.asarray(X, dtype=np.float64))
+        x, y = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+        k1, k2, p1, p2 = [float(v) for v in np.asarray(self.D).reshape(-1)[:4]]
+        r2 = x * x + y * y
+        radial = 1 + k1 * r2 + k2 * r2 * r2
+        xd = x * radial + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * radial + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        K = self.K
+        return np.stack([K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]], axis=1)
 
 
 class FisheyeCamera(PinholeCamera):
@@ -68,13 +95,6 @@ class FisheyeCamera(PinholeCamera):
         x, y = a * scale, b * scale
         K = self.K
         return np.stack([K[0, 0] * x + K[0, 1] * y + K[0, 2], K[1, 1] * y + K[1, 2]], axis=1)
-
-    def undistort(self, xy):
-        """xy: N x 2 image points -> N x 2 undistorted points, in the dtype given (as cv2 does)."""
-        xy = np.asarray(xy)
-        out = ops.fisheye_undistort(self.okp(), torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32)).to(_device()))
-        out = out.cpu().numpy()
-        return out.astype(xy.dtype) if xy.dtype in (np.float32, np.float64) else out
 
 
 class StereoCamera:
@@ -117,6 +137,8 @@ def from_calibration(calibration_file):
     D = np.array(camera['distortion_coeffs'])
     if camera['distortion_model'] == 'equidistant' and camera['camera_model'] == 'pinhole':
         return FisheyeCamera(K, D, camera['resolution'][::-1])
+    if camera['distortion_model'] == 'radtan' and camera['camera_model'] == 'pinhole':
+        return RadTanPinholeCamera(K, D, camera['resolution'][::-1])
     raise ValueError(f"Unrecognized calibration type {camera['distortion_model']}.")
 
 

@@ -193,6 +193,48 @@ class PinholeCamera:
         return ~((x <= 0.0).any(axis=1) | (x >= self.image_size).any(axis=1))
 
 
+def radtan_project(X, K, D, T_CW=None):
+    """cv2.projectPoints for the plumb-bob model with D = (k1, k2, p1, p2) (reference camera_utils.py:46-55)."""
+    X = np.asarray(X, dtype=np.float64)
+    if T_CW is not None:
+        X = transform_points(np.asarray(T_CW, dtype=np.float64), X)
+    x, y = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+    k1, k2, p1, p2 = [float(v) for v in np.asarray(D).reshape(-1)[:4]]
+    r2 = x * x + y * y
+    radial = 1 + k1 * r2 + k2 * r2 * r2
+    xd = x * radial + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * radial + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]], axis=1)
+
+
+def radtan_undistort(xy, K, D, P=None, iterations=5):
+    """cv2.undistortPoints(xy, K, D, P=P) of OpenCV 3.4.2 (reference camera_utils.py:57-62): `iterations` fixed-point steps of
+    x <- (x0 - tangential(x, y)) / radial(x, y); the result is in the dtype of `xy`.  Parity-unpinned against OpenCV itself
+    (cv2 is not importable here and the reference's tests hold no radtan vector): pinned by project(undistort) properties."""
+    xy_in = np.asarray(xy)
+    out_dtype = xy_in.dtype if xy_in.dtype in (np.float32, np.float64) else np.float64
+    pts = xy_in.astype(np.float64)
+    P = K if P is None else P
+    k1, k2, p1, p2 = [float(v) for v in np.asarray(D).reshape(-1)[:4]]
+    x0, y0 = (pts[:, 0] - K[0, 2]) / K[0, 0], (pts[:, 1] - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iterations):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x, y = (x0 - dx) * icdist, (y0 - dy) * icdist
+    return np.stack([P[0, 0] * x + P[0, 2], P[1, 1] * y + P[1, 2]], axis=1).astype(out_dtype)
+
+
+class RadTanPinholeCamera(PinholeCamera):
+    def project(self, X, T_CW=np.eye(4)):
+        return radtan_project(X, self.K, self.D, T_CW)
+
+    def undistort(self, xy):
+        return radtan_undistort(xy, self.K, self.D, P=self.K)
+
+
 class FisheyeCamera(PinholeCamera):
     def project(self, X, T_CW=np.eye(4)):
         return fisheye_project(X, self.K, self.D, T_CW)

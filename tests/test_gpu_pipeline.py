@@ -165,6 +165,28 @@ def test_undistort_matches_oracle():
     assert cam.undistort(xy.astype(np.float32)).dtype == np.float32
 
 
+def test_radtan_camera_matches_oracle():
+    """RadTanPinholeCamera: the device undistortion (okp_camera_undistort, model radtan) against the oracle's restatement of
+    cv2.undistortPoints, and depth lifting (DetectionToPoint) through such a camera."""
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    K = np.array([[42.0, 0.0, 32.0], [0.0, 41.5, 32.0], [0.0, 0.0, 1.0]])
+    D = np.array([-0.28, 0.07, 0.0006, -0.0002])
+    cam, ocam = cu.RadTanPinholeCamera(K, D, [64, 64]), og.RadTanPinholeCamera(K, D, [64, 64])
+    rng = np.random.default_rng(2)
+    xy = np.stack([rng.uniform(0, 64, 300), rng.uniform(0, 64, 300)], axis=1)
+    got = cam.undistort(xy)
+    want = ocam.undistort(xy.astype(np.float32).astype(np.float64))
+    assert got.dtype == np.float64 and np.abs(got - want).max() < 1e-10
+    X = np.array([[0.1, -0.05, 1.0], [-0.2, 0.1, 1.5]])
+    np.testing.assert_allclose(cam.project(X), ocam.project(X), rtol=0, atol=1e-12)
+    depth = rng.uniform(0.3, 1.5, (64, 64)).astype(np.float32)
+    pts = xy[:40].astype(np.float32)
+    d2p, od2p = pp.DetectionToPoint(), op.DetectionToPoint()
+    d2p.reset(cam); od2p.reset(ocam)
+    assert np.abs(d2p(pts, depth) - od2p(pts, depth)).max() < 1e-6
+
+
 def test_batch64_properties():
     """BASELINE batch size: every frame of a 64-frame batch gives the peaks it gives alone (frames are
     independent), peaks are sorted row-major, and lifted points agree with the oracle on sampled frames."""

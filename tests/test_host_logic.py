@@ -32,14 +32,14 @@ def test_library_exports_every_declared_symbol():
     from object_keypoints_amd import _lib
     bound = {n for n, _, _ in _lib.SIGNATURES}
     assert declared == bound, f"ctypes binding and header disagree: {declared ^ bound}"
-    assert _lib.lib().okp_abi_version() == 1
+    assert _lib.lib().okp_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     from object_keypoints_amd import _lib
     assert ctypes.sizeof(_lib.okp_tensor) == 32
     assert ctypes.sizeof(_lib.okp_tap) == 24
-    assert ctypes.sizeof(_lib.okp_camera) == 64
+    assert ctypes.sizeof(_lib.okp_camera) == 72 and _lib.okp_camera.model.offset == 64
     assert _lib.okp_conv_args.src.offset == 16 and _lib.okp_conv_args.out.offset == 80
     assert _lib.okp_conv_args.res.offset == 128 and _lib.okp_conv_args.dw_out.offset == 184 and _lib.okp_conv_args.n_classes.offset == 248 and ctypes.sizeof(_lib.okp_conv_args) == 256
 
@@ -278,3 +278,21 @@ def test_torch_ops_are_registered_over_the_c_abi():
         T.peak_nms(torch.zeros(1, 1, 8, 8), 4, torch.zeros(1, dtype=torch.int32), torch.zeros(8, dtype=torch.int32), torch.zeros(12), 0)
     with pytest.raises(ops.OkpError):
         ops.peak_nms(torch.zeros(1, 1, 8, 8))
+
+
+def test_from_calibration_picks_the_camera_model(tmp_path):
+    """camera_utils.from_calibration (reference :131-144): equidistant -> FisheyeCamera, radtan -> RadTanPinholeCamera,
+    anything else -> ValueError."""
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    base = "cam0:\n  camera_model: pinhole\n  intrinsics: [420.0, 415.0, 320.0, 240.0]\n  distortion_coeffs: [-0.28, 0.07, 0.0006, -0.0002]\n  resolution: [640, 480]\n  distortion_model: {}\n"
+    for model, cls in (("equidistant", cu.FisheyeCamera), ("radtan", cu.RadTanPinholeCamera)):
+        f = tmp_path / f"{model}.yaml"
+        f.write_text(base.format(model))
+        cam = cu.from_calibration(str(f))
+        assert type(cam) is cls and cam.image_size.tolist() == [480, 640] and cam.okp().model == (0 if model == "equidistant" else 1)
+    f = tmp_path / "other.yaml"
+    f.write_text(base.format("fov"))
+    with pytest.raises(ValueError):
+        cu.from_calibration(str(f))
+    # as in the reference, PinholeCamera.scale()/cut() construct a FisheyeCamera whatever the receiver is (camera_utils.py:18-29)
+    assert type(cu.from_calibration(str(tmp_path / "radtan.yaml")).scale(0.5)) is cu.FisheyeCamera

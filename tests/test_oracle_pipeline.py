@@ -184,3 +184,24 @@ def test_box_sum_order_is_the_contract():
     rows = sum(pad[:, dx:dx + 64] for dx in range(5)).astype(np.float32)
     sep = sum(rows[dy:dy + 64] for dy in range(5)).astype(np.float32)
     assert (a != sep).any()
+
+
+def test_radtan_undistort_inverts_projection():
+    """RadTanPinholeCamera (reference camera_utils.py:45-62; cv2.projectPoints / cv2.undistortPoints, parity-unpinned: cv2 is
+    absent and the reference's tests hold no radtan vector): undistorting a projected point gives the pinhole projection of
+    the same 3D point, to the accuracy of OpenCV's five fixed-point iterations; a zero-distortion camera is the identity."""
+    from oracle import geometry as og
+    K = np.array([[420.0, 0.0, 320.0], [0.0, 415.0, 240.0], [0.0, 0.0, 1.0]])
+    D = np.array([-0.28, 0.07, 0.0006, -0.0002])
+    cam = og.RadTanPinholeCamera(K, D, [480, 640])
+    rng = np.random.default_rng(1)
+    X = np.stack([rng.uniform(-0.5, 0.5, 200), rng.uniform(-0.4, 0.4, 200), rng.uniform(0.8, 2.0, 200)], axis=1)
+    px = cam.project(X)
+    ideal = np.stack([K[0, 0] * X[:, 0] / X[:, 2] + K[0, 2], K[1, 1] * X[:, 1] / X[:, 2] + K[1, 2]], axis=1)
+    assert np.abs(px - ideal).max() > 1.0                       # the distortion is not negligible on this set
+    und = cam.undistort(px)
+    assert np.abs(und - ideal).max() < 0.05                     # five iterations: a few hundredths of a pixel at the edge
+    assert np.abs(og.radtan_undistort(px, K, D, iterations=50) - ideal).max() < 1e-9
+    flat = og.RadTanPinholeCamera(K, np.zeros(4), [480, 640])
+    assert np.abs(flat.undistort(px) - px).max() < 1e-12
+    assert cam.undistort(px.astype(np.float32)).dtype == np.float32
