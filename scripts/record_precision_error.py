@@ -14,6 +14,10 @@ def stats(got, ref):
     e = np.abs(got.astype(np.float64) - ref.astype(np.float64)).ravel()
     return {"max": float(e.max()), "mean": float(e.mean()), "p99": float(np.quantile(e, 0.99)), "ref_absmax": float(np.abs(ref).max())}
 
+from object_keypoints_amd.perception.utils import camera_utils as cu
+_p = cu.load_calibration_params(os.path.join(REPO, "config", "calibration.yaml"))
+_c = cu.FisheyeCamera(_p["K"], _p["D"], _p["image_size"]).scale(511 / 720)
+CAM = _c.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511).okp()
 out = {"device": torch.cuda.get_device_name(0), "note": "HIP path vs golden outputs of the reference (fp32 CPU), one 511x511 frame per case"}
 for name in sorted(cases.NET_CASES):
     case = cases.NET_CASES[name]
@@ -31,13 +35,23 @@ for name in sorted(cases.NET_CASES):
             gcount, gyx, _ = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
         row = {"heat": stats(heat.cpu().numpy(), g["heat"]), "depth": stats(depth.cpu().numpy(), g["depth"]),
                "centers": stats(centers.cpu().numpy(), g["centers"])}
-        # peak sets on this precision's heat map vs on the golden heat map (same device kernel, so only the maps differ)
+        # peak sets on this precision's heat map vs on the golden heat map (same device kernel, so only the maps differ),
+        # and the 3D points lifted at the peaks both have in common (this precision's centroid + depth vs the golden's)
+        with torch.no_grad():
+            _, _, xyc = ops.peak_nms(heat, cap=4096)
+            _, _, gxyc = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
+            pts = ops.lift_peaks(CAM, count, xyc, depth, 63, 63).cpu().numpy()
+            gpts = ops.lift_peaks(CAM, gcount, gxyc, torch.from_numpy(g["depth"]).cuda(), 63, 63).cpu().numpy()
         inter = union = 0
+        d3 = []
         for k in range(heat.shape[1]):
-            a = {tuple(p) for p in yx[0, k, :int(count[0, k])].cpu().numpy().tolist()}
-            b = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
-            inter += len(a & b); union += len(a | b)
-        row["peaks"] = {"golden": int(gcount.sum()), "found": int(count.sum()), "jaccard": inter / max(union, 1)}
+            la = yx[0, k, :int(count[0, k])].cpu().numpy().tolist(); lb = gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()
+            a = {tuple(p): i for i, p in enumerate(la)}; b = {tuple(p): i for i, p in enumerate(lb)}
+            inter += len(a.keys() & b.keys()); union += len(a.keys() | b.keys())
+            for key in a.keys() & b.keys():
+                d3.append(float(np.abs(pts[0, k, a[key], :3] - gpts[0, k, b[key], :3]).max()))
+        row["peaks"] = {"golden": int(gcount.sum()), "found": int(count.sum()), "jaccard": inter / max(union, 1),
+                        "p_C_max_m_at_common_peaks": max(d3), "p_C_mean_m_at_common_peaks": float(np.mean(d3))}
         out.setdefault(name, {})[tag] = row
         print(name, tag, json.dumps(row), flush=True)
 dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "precision_measured.json")

@@ -84,6 +84,24 @@ def test_16bit_network_within_twice_the_recorded_error(name, tag, dtype):
         b = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
         inter += len(a & b); union += len(a | b)
     assert inter / union >= 1.0 - 2.0 * (1.0 - rec["peaks"]["jaccard"]) - 0.01
+    # 3D points at the peaks both maps agree on (the depth head is O(1-5) on these weights: metres)
+    import os as _os
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    repo = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    p_ = cu.load_calibration_params(_os.path.join(repo, "config", "calibration.yaml"))
+    cam = cu.FisheyeCamera(p_["K"], p_["D"], p_["image_size"]).scale(511 / 720)
+    cam = cam.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511).okp()
+    _, _, xyc = ops.peak_nms(heat, cap=4096)
+    _, _, gxyc = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
+    pts = ops.lift_peaks(cam, count, xyc, depth, 63, 63).cpu().numpy()
+    gpts = ops.lift_peaks(cam, gcount, gxyc, torch.from_numpy(g["depth"]).cuda(), 63, 63).cpu().numpy()
+    worst = 0.0
+    for k in range(heat.shape[1]):
+        a = {tuple(p): i for i, p in enumerate(yx[0, k, :int(count[0, k])].cpu().numpy().tolist())}
+        b = {tuple(p): i for i, p in enumerate(gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist())}
+        for key in a.keys() & b.keys():
+            worst = max(worst, float(np.abs(pts[0, k, a[key], :3] - gpts[0, k, b[key], :3]).max()))
+    assert worst <= 2.0 * rec["peaks"]["p_C_max_m_at_common_peaks"]
 
 
 def test_batch_independence_and_eval_only():
