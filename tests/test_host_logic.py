@@ -296,3 +296,40 @@ def test_from_calibration_picks_the_camera_model(tmp_path):
         cu.from_calibration(str(f))
     # as in the reference, PinholeCamera.scale()/cut() construct a FisheyeCamera whatever the receiver is (camera_utils.py:18-29)
     assert type(cu.from_calibration(str(tmp_path / "radtan.yaml")).scale(0.5)) is cu.FisheyeCamera
+
+
+def test_evaluation_results_match_the_reference_table():
+    """perception.evaluation.Results against the row the REFERENCE's Results class (scripts/eval_model.py:129-232) produced on
+    the same six synthetic frames (tests/golden/evaluation.json, written by tests/golden/make_goldens_eval.py): detections
+    missed, keypoint types without detection, a keypoint not lifted, one beyond the 2 m range."""
+    import json
+    from object_keypoints_amd.perception.evaluation import Results
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    with open(os.path.join(REPO, "tests", "golden", "evaluation.json")) as f:
+        g = json.load(f)
+    params = cu.load_calibration_params(os.path.join(REPO, "config", "calibration.yaml"))
+    cam = cu.FisheyeCamera(params["K"], params["D"], params["image_size"]).scale(511 / 720)
+    cam = cam.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511)
+
+    def groups(p_C):
+        out = []
+        for grp in p_C:
+            if grp is None:
+                out.append(None)
+            elif any(p is None for p in grp):
+                out.append([None if p is None else np.array(p) for p in grp])
+            else:
+                out.append(np.array(grp))
+        return out
+
+    res = Results()
+    res.set_calibration(cam)
+    truth = np.array(g["truth"])
+    for fr in g["frames"]:
+        res.add(np.array(fr["T_WC"]), [{"p_C": groups(o["p_C"])} for o in fr["objects"]], truth)
+    s = res.summary()
+    row = g["row"]
+    assert s["points"] == int(row["points"])
+    assert abs(s["missing"] - float(row["missing"].rstrip("%"))) < 0.006          # the reference prints two decimals
+    for col in ("mean", "mean xy", "std", "< 3cm", "25th percentile", "75th percentile"):
+        assert abs(s[col] - float(row[col])) < 1e-9, col
