@@ -293,6 +293,10 @@ int okp_group_objects(const int32_t* count_dev, const float* xyc_dev, const floa
                       int32_t max_obj, int32_t max_sel, int32_t* n_obj_dev, int32_t* sel_dev, int32_t* n_votes_dev,
                       int32_t* assign_dev, double* pred_dev, void* stream);
 
+/* The fixed-capacity tensors can truncate where the reference (which keeps every peak, pipeline.py:73) cannot: flag[0] = 1 iff some
+ * map has more than `cap` peaks or some centre map (map 0 of each frame of K maps) more than `max_obj`; else 0.  Device-side, no sync. */
+int okp_capacity_overflow(const int32_t* count_dev, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, int32_t* flag_dev, void* stream);
+
 /* Replaces StereoCamera.triangulate (utils/camera_utils.py:92-110) and the labelling tool's
  * 2-view DLT (scripts/label.py:285-305): undistort both views (P=K) -> optional Hartley-Sturm
  * correction against F (cv2.correctMatches) -> DLT null vector of the 4x4 system built from

@@ -85,6 +85,7 @@ SIGNATURES = [
     ("okp_unproject_depth", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_lift_peaks", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_group_objects", c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("okp_capacity_overflow", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_triangulate_dlt", c_int, [POINTER(okp_camera), POINTER(okp_camera), POINTER(c_double), POINTER(c_double), c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_fisheye_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_camera_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),

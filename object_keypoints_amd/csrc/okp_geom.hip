@@ -470,6 +470,27 @@ extern "C" int okp_lift_peaks(const okp_camera* cam, const int32_t* count, const
   return okp_check_hip(hipGetLastError(), "okp_lift_peaks launch");
 }
 
+__global__ void okp_capacity_overflow_kernel(const int* __restrict__ count, int n_maps, int K, int cap, int max_obj, int* __restrict__ flag) {
+  // one workgroup: any map with more peaks than `cap`, or any centre map (map 0 of a frame) with more than `max_obj`
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = threadIdx.x; i < n_maps; i += blockDim.x) {
+    const int c = count[i];
+    bad |= (c > cap) || ((i % K) == 0 && c > max_obj);
+  }
+  if (bad) atomicOr(&any, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = any;
+}
+
+extern "C" int okp_capacity_overflow(const int32_t* count, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, int32_t* flag, void* stream) {
+  if (!count || !flag || K < 1) { okp_set_error("okp_capacity_overflow: bad argument"); return OKP_EINVAL; }
+  hipLaunchKernelGGL(okp_capacity_overflow_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, count, n_maps, K, cap, max_obj, flag);
+  return okp_check_hip(hipGetLastError(), "okp_capacity_overflow launch");
+}
+
 extern "C" int okp_group_objects(const int32_t* count, const float* xyc, const float* centers, int32_t n, int32_t K, int32_t cap,
                                  int32_t h, int32_t w, const int32_t* type_count, float max_dist, int32_t max_obj, int32_t max_sel,
                                  int32_t* n_obj, int32_t* sel, int32_t* n_votes, int32_t* assign, double* pred, void* stream) {

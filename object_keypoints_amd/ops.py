@@ -541,6 +541,16 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
     return {"n_obj": n_obj, "sel": sel, "n_votes": votes, "assign": assign, "pred": pred}
 
 
+def capacity_overflow(count, cap, max_obj):
+    """count [N,K] int32 (device) -> 0-d bool tensor (device): some map holds more than `cap` peaks, or some frame more than
+    `max_obj` centre peaks.  One small launch, no host sync."""
+    require_cuda(count, "count")
+    flag = torch.empty((1,), dtype=torch.int32, device=count.device)
+    n, k = count.shape
+    _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
+    return flag[0] != 0
+
+
 def triangulate_dlt(cam_l, cam_r, T_RL, left_xy, right_xy, F=None):
     require_cuda(left_xy, "left_xy")
     left_xy = left_xy.to(torch.float32).contiguous()

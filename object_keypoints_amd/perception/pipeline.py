@@ -414,7 +414,7 @@ class BatchedKeypointPipeline:
         # The reference has no capacity (pipeline.py:73 keeps every peak); the fixed-capacity tensors do.  `overflow` is a
         # device-side flag (no sync here): a map with more peaks than `capacity`, or more centre peaks than `max_objects`,
         # means `points` / the grouping are truncated - callers check it (objects() raises, bench.py asserts).
-        out["overflow"] = (count > self.capacity).any() | (count[:, 0] > self.max_objects).any()
+        out["overflow"] = ops.capacity_overflow(count, self.capacity, self.max_objects)
         return out
 
     def objects(self, out, n):

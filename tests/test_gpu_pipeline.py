@@ -58,6 +58,33 @@ def test_peak_capacity_overflow_is_explicit(golden):
         comp(c["heat"][None])
 
 
+def test_batched_pipeline_flags_capacity_overflow():
+    """The batched pipeline's fixed capacities can truncate where the reference keeps every peak: `overflow` (device flag,
+    okp_capacity_overflow) says so and objects() raises instead of returning a truncated frame."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    cam_o = op.eval_camera(CALIB)
+    cam = cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size)
+    c = cases.pipeline_case("noise")                                   # about a hundred peaks per map
+    k = c["heat"].shape[0]
+    heat = torch.from_numpy(c["heat"][None]).cuda()
+    depth = torch.ones_like(heat)
+    centers = torch.zeros((1, k - 1, 2, 64, 64), device="cuda")
+    cfg = {"keypoint_config": c["config"]}
+    small = pp.BatchedKeypointPipeline(None, cfg, cam, capacity=16)
+    out = small.postprocess_device(heat, depth, centers)
+    assert bool(out["overflow"])
+    with pytest.raises(ops.OkpError):
+        small.objects(out, 0)
+    s = synth.bump_scene([1, 3], n_objects=2, seed=7, index=0)
+    fine = pp.BatchedKeypointPipeline(None, {"keypoint_config": [1, 3]}, cam, capacity=64)
+    out = fine.postprocess_device(*[torch.from_numpy(s[key][None]).cuda() for key in ("heat", "depth", "centers")])
+    assert not bool(out["overflow"])
+    many = pp.BatchedKeypointPipeline(None, {"keypoint_config": [1, 3]}, cam, capacity=64, max_objects=1)    # two centres, one object slot
+    assert bool(many.postprocess_device(*[torch.from_numpy(s[key][None]).cuda() for key in ("heat", "depth", "centers")])["overflow"])
+
+
 def test_nms_function_matches_oracle():
     from object_keypoints_amd.perception.models import nms
     from oracle import net as onet
