@@ -10,7 +10,8 @@ for a in sys.argv[1:]:
 m = bb.unpool_merge(256).eval()
 low = ops.Act(torch.randn(kw["n"], kw["hw"], kw["hw"], 256, device="cuda").bfloat16())
 up1 = ops.Act(torch.randn(kw["n"], 2 * kw["hw"], 2 * kw["hw"], 256, device="cuda").bfloat16())
-for rep in range(2):
+for tile in (13, 14, 14, 13):
+    bb.UNPOOL_TILE = tile
     for _ in range(3): y = m(low, up1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,4 +20,4 @@ for rep in range(2):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     fl = 2.0 * kw["n"] * (2 * kw["hw"]) ** 2 * 256 * 256 * 4
-    print(f"unpool {kw}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s")
+    print(f"unpool {kw} tile {tile}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s")
