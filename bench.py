@@ -110,10 +110,12 @@ class KernelTimer:
         self.key = (dtype, tile, n_src)
         self.records = []
         self.enabled = False
+        self.step = 0
+        self.every = int(os.environ.get("OKP_BENCH_TIMER_EVERY", "1"))
 
     def before(self, plan, tile, macs):
         import torch
-        if not self.enabled or plan.dtype != self.key[0] or tile not in self.key[1] or (self.key[2] is not None and plan.n_src != self.key[2]):
+        if not self.enabled or self.step % self.every or plan.dtype != self.key[0] or tile not in self.key[1] or (self.key[2] is not None and plan.n_src != self.key[2]):
             return None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -267,7 +269,8 @@ def run_precision(name, ctx, steps, warmup):
         dist_.barrier(); torch.cuda.synchronize()
         timer.enabled = True
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            timer.step = i
             out, gathered = step()
         dist_.barrier(); torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0

@@ -255,6 +255,15 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
         }
         ok = !okp_check_hip(hipMalloc(&plan->frag_dev, n16 * 16), "hipMalloc(fragment-order weights)");
         ok = ok && !okp_check_hip(hipMemcpy(plan->frag_dev, fr.data(), n16 * 16, hipMemcpyHostToDevice), "hipMemcpy(fragment-order weights)");
+        // okp_fire2 multiplies with the CHANNELS as MFMA rows (a lane then holds eight adjacent channels of one pixel: 16-byte
+        // loads / stores): row i = lane & 15 of block b is channel 32 w + 8 (i >> 2) + 4 b + (i & 3)
+        for (size_t i = 0; i < n16; ++i) {
+          const int lane = (int)(i & 63), ks = (int)((i >> 6) % ksteps), b = (int)(((i >> 6) / ksteps) & 1), w = (int)((i >> 6) / ksteps / 2);
+          const int r = lane & 15, ch = 32 * w + 8 * (r >> 2) + 4 * b + (r & 3), q = lane >> 4;
+          std::memcpy(&fr[i * 8], &h[(((size_t)(ks >> 1) * plan->cout_pad + ch) * 8 + (ks & 1) * 4 + q) * 8], 16);
+        }
+        ok = ok && !okp_check_hip(hipMalloc(&plan->fragT_dev, n16 * 16), "hipMalloc(fragment-order weights, channel rows)");
+        ok = ok && !okp_check_hip(hipMemcpy(plan->fragT_dev, fr.data(), n16 * 16, hipMemcpyHostToDevice), "hipMemcpy(fragment-order weights, channel rows)");
       }
     } else {
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, packed.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
@@ -277,6 +286,7 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
   if (plan->bias_dev) (void)hipFree(plan->bias_dev);
   if (plan->slices_dev) (void)hipFree(plan->slices_dev);
   if (plan->frag_dev) (void)hipFree(plan->frag_dev);
+  if (plan->fragT_dev) (void)hipFree(plan->fragT_dev);
   if (plan->patch_steps_dev) (void)hipFree(plan->patch_steps_dev);
   delete plan;
 }

@@ -13,10 +13,12 @@
 // Shape of the kernel (MID/32 waves; MID = 128: 256 threads, ~71 KB LDS -> two workgroups per CU; persistent grid):
 //  * A workgroup owns an IH x IW rectangle of output pixels; the squeeze tile is that rectangle plus a one-pixel
 //    halo (SH x SW <= 128 pixels).  Halo pixels outside the frame are zero in s (the reference zero-pads s).
-//  * Both GEMMs run on 16x16x32 MFMAs with PIXELS as rows (A operand, read from LDS) and CHANNELS as columns
-//    (B operand = weights).  Wave w owns 32 channels; column j of block b is channel 32 w + 2 j + b, so a lane's two
-//    accumulator blocks are two ADJACENT channels: one dword per pixel, 16 lanes = one 64-byte line.  The squeeze
-//    result goes to LDS with ds_write_b32, the expand result straight to HBM in whole lines - no transposition.
+//  * Both GEMMs run on 16x16x32 MFMAs with CHANNELS as rows (A operand = weights) and PIXELS as columns (B operand, read
+//    from LDS).  Wave w owns 32 channels; row i of block b is channel 32 w + 8 (i >> 2) + 4 b + (i & 3), so lane
+//    (column j, row group q) holds in its two accumulator blocks the EIGHT ADJACENT channels 32 w + 8 q .. + 7 of pixel j:
+//    16 bytes.  The squeeze result goes to LDS with one ds_write_b128 per 16 pixels, the skip values come and the expand
+//    result goes straight to HBM with one 16-byte access per 16 pixels - no transposition (with the pixels as rows a lane
+//    held channel PAIRS of four pixels: four times the memory instructions, measured 2-3 us of a 16 us tile).
 //  * CIN = 256: squeeze weights stay in registers for the whole kernel (64 VGPRs per lane, gathered once from the
 //    packed [slice][cout][128 B] plan layout).  Wider inputs stream them from L2 two k-steps ahead (three rotating
 //    fragment sets; the counted waits of the x ring include them).  Expand weights are re-fetched per tile.
@@ -34,6 +36,14 @@
 namespace {
 
 constexpr uint32_t kInvalid = 0x80000000u;
+#ifdef OKP_FIRE2_CLK                              // debug build only (scripts/probe_fire2_clk.py): phase time stamps of each workgroup's first tile
+__device__ long long okp_fire2_clk_buf[1024 * 8];
+#define CLK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define CLKNW(i) do { if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define CLK(i)
+#define CLKNW(i)
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -88,13 +98,17 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, q = lane >> 4;
+#ifdef OKP_FIRE2_CLK
+  bool first_tile = true;
+#endif
+  CLKNW(0);
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
 
   // ---- once per workgroup: resident squeeze weights, depth-wise constants -> LDS -----------------------------
   // B fragment (column = channel c, k-step ks, k-group q) = 16 bytes at [slice ks/2][row c][64 (ks&1) + 16 q]
-  const int ch0 = 32 * w + 2 * l16;                         // this lane's channel pair (ch0, ch0 + 1) in both GEMMs
+  const int chq = 32 * w + 8 * q;                           // this lane's eight channels chq .. chq + 7 (block b, register r: chq + 4 b + r) in both GEMMs
   // weights in fragment order [wave][block b][k-step][lane][16 B] (okp_ensure_frags): one load = 1 KiB contiguous per
   // wave (the packed plan layout would give 16 separate 64-byte segments per load: measured 4x slower to stream)
   const u32x4* const w1_lane = static_cast<const u32x4*>(p.w1) + (size_t)w * 2 * KS1 * 64 + lane;
@@ -108,8 +122,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     for (int ks = 0; ks < KS1; ++ks) load_w1(ks, w1f[ks]);
   }
   const u32x4* const wa_lane = static_cast<const u32x4*>(p.wa) + (size_t)w * 2 * KS2 * 64 + lane;
-  const float b1v0 = p.b1[ch0], b1v1 = p.b1[ch0 + 1];
-  const float bav0 = p.ba[ch0], bav1 = p.ba[ch0 + 1];
+  const f32x4 b1v0 = *reinterpret_cast<const f32x4*>(p.b1 + chq), b1v1 = *reinterpret_cast<const f32x4*>(p.b1 + chq + 4);
+  const f32x4 bav0 = *reinterpret_cast<const f32x4*>(p.ba + chq), bav1 = *reinterpret_cast<const f32x4*>(p.ba + chq + 4);
   for (int i = tid; i < 10 * HALF; i += NT)
     reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
   if (tid < 16 * PBI) {
@@ -132,13 +146,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   }
   // x-ring fragment read: row 16 pb + l16, chunk q sits at position (q + 2 (row >> 2)) & 3 = (q + 2 (l16 >> 2)) & 3
   const uint32_t xfrag_off = (uint32_t)l16 * 64u + (uint32_t)((q + 2 * (l16 >> 2)) & 3) * 16u;
-  // squeeze result -> LDS: register r of block pb is tile row 16 pb + 4 q + r; the pair (ch0, ch0 + 1) is one dword
-  uint32_t s_dst[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rl = 4 * q + r;
-    s_dst[r] = (uint32_t)(OFF_S + rl * (MID * 2) + (((4 * w + (l16 >> 2)) ^ (rl & SWM)) << 4) + (l16 & 3) * 4);
-  }
+  // squeeze result -> LDS: block pb is tile rows 16 pb + l16; the lane's eight channels are the 16-byte chunk 4 w + q of the row
+  const uint32_t s_dst = (uint32_t)(OFF_S + l16 * (MID * 2) + (((4 * w + q) ^ (l16 & SWM)) << 4));
   // LDS-DMA geometry: a ring step is SP/16 = 8 instructions of 16 rows; wave w issues row blocks w, w + NW, ...
   // lane -> (row, position).  The lane FETCHES the 16-byte k-chunk that the read-side rotation expects there.
   constexpr bool UNI = (SP / 16) % NW == 0;                  // every wave issues the same number of instructions
@@ -199,7 +208,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
+  CLKNW(1);
   __syncthreads();                                           // depth-wise constants are in LDS
+  CLK(2);
   tile_setup(tile);
   if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
 #pragma unroll
@@ -229,7 +240,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         oof += (uint32_t)(p.Wo * p.out_ps * 2);
       }
     };
-    uint32_t o_off[PBI][4], r_raw[PBI][4];                  // phase 2a: output offsets and residual pairs of this lane's pixels
+    uint32_t o_off[PBI];                                    // phase 2a: output offset and skip values of this lane's pixel of block pb
+    u32x4 r_raw[PBI];
     u32x4 rr[MAXIH];                                        // phase 2b: residuals / output offsets of this thread's first column
     uint32_t oo[MAXIH];
 
@@ -238,8 +250,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     f32x4 acc[SP / 16][2];
 #pragma unroll
     for (int pb = 0; pb < SP / 16; ++pb) {
-      acc[pb][0] = f32x4{b1v0, b1v0, b1v0, b1v0};
-      acc[pb][1] = f32x4{b1v1, b1v1, b1v1, b1v1};
+      acc[pb][0] = b1v0;
+      acc[pb][1] = b1v1;
     }
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
@@ -269,8 +281,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       for (int pb = 0; pb < SP / 16; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[pb][b] = H16<T>::mfma16(a[pb], w1f[RES ? ks : ks % 3][b], acc[pb][b]);
+          acc[pb][b] = H16<T>::mfma16(w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
     }
+    CLKNW(3);
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     u32x4 waf[2][KS2];
 #pragma unroll
@@ -281,53 +294,55 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     // s -> LDS (zero outside the frame: the reference zero-pads the squeeze output)
     {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(smem + OFF_MASK);
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
       uint32_t mq[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mq[i] = mk[i] >> (4 * qt);
+      for (int i = 0; i < 4; ++i) mq[i] = mk[i] >> l16t;
 #pragma unroll
       for (int pb = 0; pb < SP / 16; ++pb) {
+        const bool ok = (mq[pb >> 1] >> (16 * (pb & 1))) & 1u;
+        u32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = (mq[pb >> 1] >> (16 * (pb & 1) + r)) & 1u;
-          *reinterpret_cast<uint32_t*>(smem + s_dst[r] + pb * 16 * (MID * 2)) = okp_pack2<T>(ok ? acc[pb][0][r] : 0.f, ok ? acc[pb][1][r] : 0.f);
+        for (int b = 0; b < 2; ++b) {
+          v[2 * b] = okp_pack2<T>(ok ? acc[pb][b][0] : 0.f, ok ? acc[pb][b][1] : 0.f);
+          v[2 * b + 1] = okp_pack2<T>(ok ? acc[pb][b][2] : 0.f, ok ? acc[pb][b][3] : 0.f);
         }
+        *reinterpret_cast<u32x4*>(smem + s_dst + pb * 16 * (MID * 2)) = v;
       }
     }
     __syncthreads();
+    CLKNW(4);
     // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
     {
       // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
       // pixels from the per-workgroup table (one 16-byte LDS read per block); edge tiles do the arithmetic.
       const bool full = y0 + p.IH <= p.Ho && x0 + p.IW <= p.Wo;
       const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
-      const uint32_t xb = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)ch0 * 2u, ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)ch0 * 2u;
+      const uint32_t xb = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)chq * 2u, ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)chq * 2u;
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
 #pragma unroll
       for (int pb = 0; pb < PBI; ++pb) {
-        u32x4 xr = {kInvalid, kInvalid, kInvalid, kInvalid}, orr = {kInvalid, kInvalid, kInvalid, kInvalid};
+        uint32_t xr = kInvalid, orr = kInvalid;
         if (16 * pb < p.IP) {
-          xr = *reinterpret_cast<const u32x4*>(smem + OFF_TAB + (16 * pb + 4 * qt) * 4);
-          orr = *reinterpret_cast<const u32x4*>(smem + OFF_TAB + (96 + 16 * pb + 4 * qt) * 4);
+          const int ip = 16 * pb + l16t;
+          xr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + ip * 4);
+          orr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + (96 + ip) * 4);
           if (!full) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ip = 16 * pb + 4 * qt + r;
-              const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
-              if (y0 + iy >= p.Ho || x0 + ix >= p.Wo) { xr[r] = kInvalid; orr[r] = kInvalid; }
-            }
+            const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
+            if (y0 + iy >= p.Ho || x0 + ix >= p.Wo) { xr = kInvalid; orr = kInvalid; }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o_off[pb][r] = orr[r] == kInvalid ? kInvalid : ob + orr[r];
-          r_raw[pb][r] = 0;
-          if (p.skip && 16 * pb < p.IP) r_raw[pb][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xr[r] == kInvalid ? kInvalid : xb + xr[r]), 0, 0);
-        }
+        o_off[pb] = orr == kInvalid ? kInvalid : ob + orr;
+        r_raw[pb] = u32x4{0u, 0u, 0u, 0u};
+        if (p.skip && 16 * pb < p.IP) r_raw[pb] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xr == kInvalid ? kInvalid : xb + xr), 0, 0);
       }
       f32x4 ac2[PBI][2];
 #pragma unroll
       for (int pb = 0; pb < PBI; ++pb) {
-        ac2[pb][0] = f32x4{bav0, bav0, bav0, bav0};
-        ac2[pb][1] = f32x4{bav1, bav1, bav1, bav1};
+        ac2[pb][0] = bav0;
+        ac2[pb][1] = bav1;
       }
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
@@ -337,22 +352,25 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const u32x4 a = *reinterpret_cast<const u32x4*>(smem + OFF_S + a_row[pb] + (((uint32_t)(4 * ks + qt) ^ a_key[pb]) << 4));
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              ac2[pb][b] = H16<T>::mfma16(a, waf[b][ks], ac2[pb][b]);
+              ac2[pb][b] = H16<T>::mfma16(waf[b][ks], a, ac2[pb][b]);
           }
         }
       }
 #pragma unroll
       for (int pb = 0; pb < PBI; ++pb) {
         if (16 * pb < p.IP) {
+          u32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint32_t v = okp_pack2<T>(fmaxf(ac2[pb][0][r] + H16<T>::lo(r_raw[pb][r]), 0.f), fmaxf(ac2[pb][1][r] + H16<T>::hi(r_raw[pb][r]), 0.f));
-            __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, (int)o_off[pb][r], 0, 0);
+          for (int b = 0; b < 2; ++b) {
+            v[2 * b] = okp_pack2<T>(fmaxf(ac2[pb][b][0] + H16<T>::lo(r_raw[pb][2 * b]), 0.f), fmaxf(ac2[pb][b][1] + H16<T>::hi(r_raw[pb][2 * b]), 0.f));
+            v[2 * b + 1] = okp_pack2<T>(fmaxf(ac2[pb][b][2] + H16<T>::lo(r_raw[pb][2 * b + 1]), 0.f), fmaxf(ac2[pb][b][3] + H16<T>::hi(r_raw[pb][2 * b + 1]), 0.f));
           }
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)o_off[pb], 0, 0);
         }
       }
     }
     asm volatile("" ::: "memory");             // keep the stores here (the scheduler otherwise sinks them below phase 2b)
+    CLKNW(5);
 
     // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
@@ -428,10 +446,24 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
+    CLKNW(6);
+    CLK(7);
+#ifdef OKP_FIRE2_CLK
+    first_tile = false;
+#endif
   }
 }
 
 }  // namespace
+
+#ifdef OKP_FIRE2_CLK
+extern "C" int okp_fire2_clk_read(long long* host, int n) {
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(okp_fire2_clk_buf), sizeof(long long) * (size_t)n);
+  static long long zeros[1024 * 8];
+  if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(okp_fire2_clk_buf), zeros, sizeof(zeros));
+  return rc;
+}
+#endif
 
 bool okp_fire2_supported(int cin, int mid, int half, int stride) {
   if (half != mid) return false;
@@ -516,8 +548,8 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.N = a->n; q.skip = a->skip;
     if (int e = okp_ensure_frags(squeeze, (hipStream_t)stream)) return e;
     if (int e = okp_ensure_frags(expand, (hipStream_t)stream)) return e;
-    q.w1 = squeeze->frag_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
-    q.wa = expand->frag_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
+    q.w1 = squeeze->fragT_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
+    q.wa = expand->fragT_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev;
     q.wd = dw_w_dev; q.bd = dw_bias_dev;
     return okp_launch_fire2(squeeze->dtype, q, cin, mid, a->stride, (hipStream_t)stream);
   }

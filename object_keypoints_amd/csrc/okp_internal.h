@@ -199,6 +199,7 @@ struct okp_conv {
   int32_t patch_n_geom;
   int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
   void* frag_dev;          // single-tap 16-bit plans: weights re-laid in MFMA-fragment order (built by okp_conv_create; NULL otherwise)
+  void* fragT_dev;         // the same with the channel-as-ROW order of okp_fire2 (row i of block b = channel 32 w + 8 (i >> 2) + 4 b + (i & 3))
 };
 
 void okp_set_error(const char* fmt, ...);

@@ -233,6 +233,7 @@ def fire_chain(modules, x, out):
 
 
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
+SIDE_MIN_LEVEL = int(os.environ.get("OKP_SIDE_MIN_LEVEL", "1"))   # hourglass levels (4 = 64x64 ... 1 = 8x8) from which the fork is used
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64
 FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "8"))    # 4x4 maps: two launches are faster (25 vs 20 us)

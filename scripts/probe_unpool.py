@@ -10,7 +10,7 @@ for a in sys.argv[1:]:
 m = bb.unpool_merge(256).eval()
 low = ops.Act(torch.randn(kw["n"], kw["hw"], kw["hw"], 256, device="cuda").bfloat16())
 up1 = ops.Act(torch.randn(kw["n"], 2 * kw["hw"], 2 * kw["hw"], 256, device="cuda").bfloat16())
-for tile in (13, 14, 14, 13):
+for tile in (13, 13):
     bb.UNPOOL_TILE = tile
     for _ in range(3): y = m(low, up1)
     torch.cuda.synchronize()
