@@ -470,8 +470,8 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride) {
   if (stride == 1)
     return (cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 512 && mid == 256) ||
            (cin == 384 && mid == 128) || (cin == 512 && mid == 192);
-  // (256 -> 192 at stride 2 was measured at 163 us against 43 us for two launches - 6 waves with resident squeeze weights
-  //  spill - and is left to the two-launch path)
+  // (256 -> 192 at stride 2, 32x32 -> 16x16, N=64: 163 us with resident squeeze weights - six waves spill - and 40 us with
+  //  streamed ones against 37.6 us for the two-launch path, no change of the step: left to the two launches)
   return stride == 2 && ((cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 384 && mid == 256));
 }
 

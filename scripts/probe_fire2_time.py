@@ -4,10 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from object_keypoints_amd import ops
 from object_keypoints_amd.perception import backbone as bb
-kw = dict(c=256, hw=64, n=64, stride=1)
+kw = dict(c=256, co=0, hw=64, n=64, stride=1)
 for a in sys.argv[1:]:
     k, v = a.split("="); kw[k] = int(v)
-m = bb.fire_module(kw["c"], kw["c"], stride=kw["stride"]).eval()
+m = bb.fire_module(kw["c"], kw["co"] or kw["c"], stride=kw["stride"]).eval()
 x = ops.Act(torch.randn((kw["n"], kw["hw"], kw["hw"], kw["c"]), device="cuda").bfloat16())
 res = []
 for rep in range(3):
