@@ -90,6 +90,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
   constexpr int CG = MID / 8;                      // 8-channel groups of the depth-wise branch; NT / CG = 16 column slots
   constexpr int NDM = (SP / 16 + NW - 1) / NW;     // LDS-DMA instructions per ring step, at most, per wave
+  // skip connection (CIN == 2 MID, stride 1): the depth-wise branch adds x[:, MID:], i.e. k-steps KS1/2 .. KS1-1 - with
+  // KS1/2 <= NST those are exactly the steps the ring still holds when phase 1 ends: taken from LDS instead of re-read from L2
+  constexpr bool RING_SKIP = STR == 1 && CIN == 2 * MID && KS1 / 2 <= NST;
   using L = FireLds<MID>;
   constexpr int OFF_S = L::OFF_S, OFF_X = L::OFF_X, OFF_WD = L::OFF_WD, OFF_TAB = L::OFF_TAB, OFF_MASK = L::OFF_MASK;
   static_assert(NT / CG == 16 && L::BYTES <= 160 * 1024, "thread mapping / LDS");
@@ -235,7 +238,14 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
         oo[iy] = ok ? oof : kInvalid;
         rr[iy] = u32x4{0u, 0u, 0u, 0u};
-        if (p.skip) rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
+        if (p.skip) {
+          if constexpr (RING_SKIP) {
+            const int row = (iy + 1) * p.SW + (ix < p.IW ? ix : 0) + 1;                   // squeeze-tile row of interior pixel (iy, ix)
+            rr[iy] = *reinterpret_cast<const u32x4*>(smem + OFF_X + ((KS1 / 2 + (cg >> 2)) % NST) * XST + row * 64 + (((cg & 3) + 2 * (row >> 2)) & 3) * 16);
+          } else {
+            rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalid), 0, 0);
+          }
+        }
         xo += (uint32_t)(p.W * p.x_ps * 2);
         oof += (uint32_t)(p.Wo * p.out_ps * 2);
       }
@@ -389,8 +399,11 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         // residuals of the whole column first, then the next tile's first ring steps (HBM): those land behind the
         // residuals, while the taps run
         load_col_residuals(ix, rr, oo);
-        if (!prefetched) {
+        if (RING_SKIP ? ix + 16 >= ((p.IW + 15) & ~15) : !prefetched) {     // (ring skip: behind the LAST column's reads of the ring)
           prefetched = true;
+          if constexpr (RING_SKIP) {
+            if (p.skip) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }   // every thread has its skip values: the ring is free
+          }
           const int next = tile + gridDim.x;
           if (next < p.n_tiles) {
             tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
