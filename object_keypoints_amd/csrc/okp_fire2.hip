@@ -38,8 +38,14 @@ namespace {
 constexpr uint32_t kInvalid = 0x80000000u;
 #ifdef OKP_FIRE2_CLK                              // debug build only (scripts/probe_fire2_clk.py): phase time stamps of each workgroup's first tile
 __device__ long long okp_fire2_clk_buf[1024 * 8];
+// OKP_FIRE2_CLK=1: stamps of the first tile; =2: stamp i accumulates the time since the previous stamp over ALL tiles (slot 7: tile count)
+#if OKP_FIRE2_CLK == 2
+#define CLKNW(i) do { const long long t_ = wall_clock64(); clk_acc[i] += t_ - clk_prev; clk_prev = t_; } while (0)
+#define CLK(i) CLKNW(i)
+#else
 #define CLK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #define CLKNW(i) do { if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#endif
 #else
 #define CLK(i)
 #define CLKNW(i)
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, q = lane >> 4;
 #ifdef OKP_FIRE2_CLK
+  long long clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_prev = wall_clock64();
   bool first_tile = true;
 #endif
   CLKNW(0);
@@ -460,11 +467,19 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     }
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
     CLKNW(6);
+#if OKP_FIRE2_CLK == 2
+    clk_acc[7] += 1;
+#else
     CLK(7);
+#endif
 #ifdef OKP_FIRE2_CLK
     first_tile = false;
 #endif
   }
+#if OKP_FIRE2_CLK == 2
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) okp_fire2_clk_buf[blockIdx.x * 8 + i] = clk_acc[i];
+#endif
 }
 
 }  // namespace
