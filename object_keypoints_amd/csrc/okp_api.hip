@@ -374,7 +374,15 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
 // several taps (3x3 convolutions: the patch is read once instead of once per tap) and the problem is made of whole
 // 16x16-pixel blocks written densely.
 static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
-  const int tile = okp_select_tile(plan->dtype, plan->cout_pad, (long)a->n * a->ho * a->wo);
+  // (the sub-pixel classes of a transposed convolution are separate tiles of the same launch: they count towards filling the CUs -
+  //  8x8 -> 16x16 at N=64, 384 channels: 128x128 tiles 34 us, the 64x64 ones the per-class count chose 45 us; 4x4 -> 8x8 stays at 64x64: 17 vs 23 us)
+  const int ncls0 = a->n_classes > 1 ? a->n_classes : 1;
+  const long px = (long)a->n * a->ho * a->wo;
+  int tile = okp_select_tile(plan->dtype, plan->cout_pad, px);
+  if (ncls0 > 1 && tile != 6 && tile != 3) {
+    const int t2 = okp_select_tile(plan->dtype, plan->cout_pad, px * ncls0);
+    if (t2 == 2 || tile == 2) tile = 2;
+  }
   static const bool patch_on = [] { const char* e = getenv("OKP_PATCH"); return !(e && e[0] == '0'); }();   // OKP_PATCH=0: A/B against the gather tile
   const int ncls = a->n_classes > 1 ? a->n_classes : 1;
   const bool dense1 = ncls == 1 && a->out_step == 1 && a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo;
