@@ -93,17 +93,21 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
   const float b1a = p.b1[F * h + ch0], b1b = p.b1[F * h + ch0 + 1];
   const float b2a = p.b2[F2 * h + 2 * l16], b2b = p.b2[F2 * h + 2 * l16 + 1];
 
-  for (int tile = tile0; tile < p.n_tiles; tile += gridDim.x / 3) {
+  auto issue_x = [&](int tile) {
     const long pix0 = (long)tile * TP;
-    __syncthreads();                                // the previous tile's readers of x / h2 are done; w3 is in LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long pix = pix0 + d_row[i];
       const uint32_t off = pix < p.n_pix ? (uint32_t)pix * (uint32_t)(p.x_ps * 2) + d_chunk[i] : kInvalid;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + OFF_X + (8 * w + i) * 1024), 16, (int)off, 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  const int tstep = gridDim.x / 3;
+  if (tile0 < p.n_tiles) issue_x(tile0);
+  for (int tile = tile0; tile < p.n_tiles; tile += tstep) {
+    const long pix0 = (long)tile * TP;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's x (issued behind GEMM 1 of the previous tile) has landed
+    __syncthreads();                                // ... for every wave; the previous tile's readers of h2 are done; w3 is in LDS
 
     {
       // ---- GEMM 1: h1[64 px][128] = relu(W1_h x + b1_h) ------------------------------------------------------
@@ -132,6 +136,8 @@ __global__ __launch_bounds__(256, 2) void okp_heads_kernel(const HeadsParams p) 
           }
       }
       __syncthreads();
+      // x is free (every wave has read its fragments): the next tile's x streams in under GEMM 2 and the last layer (89 -> 86 us)
+      if (tile + tstep < p.n_tiles) issue_x(tile + tstep);
       // ---- GEMM 2: h2[64 px][32] = relu(W2_h h1 + b2_h); wave w takes pixel block w ---------------------------------
       {
         f32x4 acc0 = {b2a, b2a, b2a, b2a}, acc1 = {b2b, b2b, b2b, b2b};
