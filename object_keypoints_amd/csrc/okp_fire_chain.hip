@@ -58,7 +58,12 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
   using x8_t = typename H16<T>::x8;
   constexpr int MID = C::MID, NT = C::NT, KS1 = C::KS1, KS2 = C::KS2, XROW = C::XROW, SROW = C::SROW, NPX = C::NPX;
   constexpr int XK = C::XKEY, SK = C::SKEY;
-  constexpr int PF = 8;                                // weight fragments in flight ahead of the MFMAs
+  // Weight fragments stream through ONE register ring of PF = KS2 k-steps that never drains: the last PF squeeze steps fetch the
+  // expand fragments, the expand steps fetch the NEXT module's first squeeze fragments (KS1 = 2 KS2, so a k-step's slot
+  // ks % PF is the same in every phase).  A module streams 390 KB per workgroup: with a ring per phase the pipe restarted
+  // three times per module and a module took 9.7 us at 40 GB/s per CU.
+  constexpr int PF = KS2;
+  static_assert(KS1 % PF == 0 && KS2 % PF == 0, "ring slots");
   __shared__ __attribute__((aligned(16))) char smem[C::BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +112,12 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  u32x4 wf[PF][2];
+  {
+    const u32x4* w1_first = static_cast<const u32x4*>(p.mod[0].w1) + (size_t)w * 2 * KS1 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { wf[i][0] = w1_first[(size_t)i * 64]; wf[i][1] = w1_first[(size_t)(KS1 + i) * 64]; }
+  }
   int cur = 0;
   for (int m = 0; m < p.n_modules; ++m) {
     const OkpFireChainModule mod = p.mod[m];
@@ -129,9 +140,6 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
       f32x4 acc0[PXB], acc1[PXB];
 #pragma unroll
       for (int pb = 0; pb < PXB; ++pb) { acc0[pb] = f32x4{b0, b0, b0, b0}; acc1[pb] = f32x4{b1, b1, b1, b1}; }
-      u32x4 wf[PF][2];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, KS1, i, 0); wf[i][1] = frag(w1_lane, KS1, i, 1); }
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
         u32x4 a[PXB];
@@ -139,6 +147,7 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         for (int pb = 0; pb < PXB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(xc + xoff<XK>(16 * pb + l16, 4 * ks + q, XROW));
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
+        else { wf[ks % PF][0] = frag(wa_lane, KS2, ks + PF - KS1, 0); wf[ks % PF][1] = frag(wa_lane, KS2, ks + PF - KS1, 1); }   // expand step ks + PF - KS1
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
           acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
@@ -171,17 +180,15 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
         acc0[pb] = f32x4{b0, b0, b0, b0}; acc1[pb] = f32x4{b1, b1, b1, b1};
         arow[pb] = srow(16 * pb + l16 < HW ? 16 * pb + l16 : 0);
       }
-      u32x4 wf[PF][2];
-      constexpr int PF2 = PF < KS2 ? PF : KS2;
-#pragma unroll
-      for (int i = 0; i < PF2; ++i) { wf[i][0] = frag(wa_lane, KS2, i, 0); wf[i][1] = frag(wa_lane, KS2, i, 1); }
+      const bool more = m + 1 < p.n_modules;
+      const u32x4* w1_next = static_cast<const u32x4*>(p.mod[more ? m + 1 : m].w1) + (size_t)w * 2 * KS1 * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
         u32x4 a[PXB];
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff<SK>(arow[pb], 4 * ks + q, SROW));
-        const u32x4 f0 = wf[ks % PF2][0], f1 = wf[ks % PF2][1];
-        if (ks + PF2 < KS2) { wf[ks % PF2][0] = frag(wa_lane, KS2, ks + PF2, 0); wf[ks % PF2][1] = frag(wa_lane, KS2, ks + PF2, 1); }
+        const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
+        if (more) { wf[ks % PF][0] = frag(w1_next, KS1, ks, 0); wf[ks % PF][1] = frag(w1_next, KS1, ks, 1); }      // the next module's squeeze step ks
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
           acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
@@ -229,7 +236,12 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB>::NT)) void okp_fire_chain_kerne
       for (int e = 0; e < 8; ++e) out[e] = (T)(dpx < HW ? fmaxf(v[e] + (float)xv[e], 0.f) : 0.f);
       *reinterpret_cast<x8_t*>(xn + o) = out;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next module's constants have landed (this wave's share)
+    // the next module's constants have landed (this wave's share); its first 2 PF squeeze fragments, issued after them, may stay in flight
+    if (m + 1 < p.n_modules) {
+      if constexpr (PF == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      static_assert(PF == 8 || PF == 6, "counted wait");
+    }
     __syncthreads();
     cur ^= 1;
   }
