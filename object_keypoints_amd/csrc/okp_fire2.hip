@@ -80,7 +80,9 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
   }
 }
 
@@ -93,6 +95,12 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr int KS1 = CIN / 32;                    // squeeze k-steps
   constexpr int KS2 = MID / 32;                    // expand k-steps
   constexpr bool RES = CIN <= 256;                 // squeeze weights resident in registers
+  // Wider inputs stream the squeeze weights.  With >= 192 squeeze channels (one workgroup per CU, LDS to spare) they go through a
+  // per-wave LDS ring of DW k-steps filled by LDS-DMA (fragment order: 1 KiB per instruction, read back by the lane that needs it -
+  // no barrier, no registers): DW - 1 steps in flight cover the 2-3 us the weights take to arrive (every XCD misses its L2 on them once
+  // per launch), where the three register sets of the 128-channel instance (two workgroups per CU, no LDS left) cover 2 steps.
+  constexpr bool WRING = !RES && MID >= 192;
+  constexpr int DW = !WRING ? 0 : MID == 192 ? 5 : 3;
   constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
   constexpr int CG = MID / 8;                      // 8-channel groups of the depth-wise branch; NT / CG = 16 column slots
   constexpr int NDM = (SP / 16 + NW - 1) / NW;     // LDS-DMA instructions per ring step, at most, per wave
@@ -101,8 +109,10 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr bool RING_SKIP = STR == 1 && CIN == 2 * MID && KS1 / 2 <= NST;
   using L = FireLds<MID>;
   constexpr int OFF_S = L::OFF_S, OFF_X = L::OFF_X, OFF_WD = L::OFF_WD, OFF_TAB = L::OFF_TAB, OFF_MASK = L::OFF_MASK;
-  static_assert(NT / CG == 16 && L::BYTES <= 160 * 1024, "thread mapping / LDS");
-  __shared__ __attribute__((aligned(16))) char smem[L::BYTES];
+  constexpr int OFF_W1 = (L::BYTES + 1023) / 1024 * 1024;   // [DW][wave][block b][1 KiB] squeeze-weight ring (WRING)
+  constexpr int LDS_TOTAL = WRING ? OFF_W1 + DW * NW * 2048 : L::BYTES;
+  static_assert(NT / CG == 16 && LDS_TOTAL <= 160 * 1024, "thread mapping / LDS");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +135,23 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   auto load_w1 = [&](int ks, u32x4 (&dst)[2]) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) dst[b] = w1_lane[(size_t)(b * KS1 + ks) * 64];
+  };
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, NW * 2 * KS1 * 1024, 0x00020000);
+  auto issue_w = [&](int ks) {                                // this wave's two fragment blocks of k-step ks -> ring slot ks % DW
+    if constexpr (WRING) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_ptr_t)(smem + OFF_W1 + ((ks % DW) * NW + w) * 2048 + b * 1024), 16,
+                                                 (int)(((uint32_t)(w * 2 + b) * KS1 + (uint32_t)ks) * 1024u + (uint32_t)lane * 16u), 0, 0, 0);
+    }
+  };
+  auto first_weights = [&](u32x4 (&f)[RES ? KS1 : 3][2]) {    // what a tile needs before its k-loop starts
+    if constexpr (WRING) {
+#pragma unroll
+      for (int ks = 0; ks < DW; ++ks) issue_w(ks);
+    } else if constexpr (!RES) {
+      load_w1(0, f[0]); load_w1(1, f[1]);
+    }
   };
   u32x4 w1f[RES ? KS1 : 3][2];                                // resident: all k-steps; streamed: three rotating sets
   if constexpr (RES) {
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   __syncthreads();                                           // depth-wise constants are in LDS
   CLK(2);
   tile_setup(tile);
-  if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
+  first_weights(w1f);
 #pragma unroll
   for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
 
@@ -283,22 +310,33 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       // (several tiles per workgroup, loaded memory system) that happened in most launches (round-1 bug, found by
       // scripts/probe_kernel_determinism.py / probe_fire2_race.py).  The MFMAs themselves may still sink below the barrier
       // and overlap the next step's reads (pinning them with sched_barrier cost 3 %).
+      // (WRING: step j issues the weights of step j - 1 + DW into the slot step j - 1 has just read, then ring step j + 3: behind x(ks)
+      //  come w(ks - 3 + DW) - needed itself when DW == 3 -, x(ks + 1), w(ks - 2 + DW), x(ks + 2))
       if (ks == 0) wait_vm(0);
-      else if (ks >= (RES ? NST - 1 : 2))
+      else if constexpr (WRING) {
+        auto nw = [](int j) { return j >= 1 && j - 1 + DW < KS1 ? 2 : 0; };
+        auto nx = [](int j) { return j >= 0 && j + NST - 1 < KS1 ? 1 : 0; };
+        wait_vm((DW >= 4 ? nw(ks - 2) : 0) + nw(ks - 1) + (nx(ks - 2) + nx(ks - 1)) * nd);
+      } else if (ks >= (RES ? NST - 1 : 2))
         wait_vm((ks + 1 < KS1 ? nd + (RES ? 0 : 2) : 0) + (ks + 2 < KS1 ? nd : 0));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if constexpr (!RES) { if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % 3]); }
+      if constexpr (WRING) { if (ks >= 1 && ks - 1 + DW < KS1) issue_w(ks - 1 + DW); }
+      else if constexpr (!RES) { if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % 3]); }
       if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
       const char* st = smem + OFF_X + (ks % NST) * XST + xfrag_off;
-      u32x4 a[SP / 16];
+      u32x4 a[SP / 16], wr[2] = {};
+      if constexpr (WRING) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) wr[b] = *reinterpret_cast<const u32x4*>(smem + OFF_W1 + ((ks % DW) * NW + w) * 2048 + b * 1024 + lane * 16);
+      }
 #pragma unroll
       for (int pb = 0; pb < SP / 16; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
 #pragma unroll
       for (int pb = 0; pb < SP / 16; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[pb][b] = H16<T>::mfma16(w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
+          acc[pb][b] = H16<T>::mfma16(WRING ? wr[b] : w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
     }
     CLKNW(3);
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
@@ -414,7 +452,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           const int next = tile + gridDim.x;
           if (next < p.n_tiles) {
             tile_setup(next);                                // (the validity bits are next read behind >= 8 barriers)
-            if constexpr (!RES) { load_w1(0, w1f[0]); load_w1(1, w1f[1]); }
+            first_weights(w1f);
 #pragma unroll
             for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
           }
