@@ -134,7 +134,11 @@ int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const floa
  * the activations resident in LDS (one workgroup per frame): cin = 512 on maps of at most 4 x 4 pixels (the six
  * fire_module(512, 512) of the innermost hourglass level, CornerNet_Squeeze.py:10-51, modules [2,2,2,2,4]) and cin = 384
  * on maps of at most 8 x 8 pixels (the pairs of fire_module(384, 384) one level up).
- * Module m is given as for okp_fire_forward: squeeze[m], expand[m] plans, depth-wise weights / bias on the device. */
+ * Module m is given as for okp_fire_forward: squeeze[m], expand[m] plans, depth-wise weights / bias on the device.
+ * Entry / exit form (the whole innermost hourglass level - low1, low2, low3 of hg_module n = 1, modules.py:36-66 - in one launch):
+ * when module 0 is the stride-2 fire module 384 -> 256 -> 512 (make_hg_layer's first) and the last one the fire module
+ * 512 -> 192 -> 384 (make_layer_revr's last), with one to six fire(512, 512) between them, x is the 384-channel map of at most
+ * 8 x 8 pixels the entry module reads and out the 384-channel map of ceil(h / 2) x ceil(w / 2) pixels the exit module writes. */
 #define OKP_FIRE_CHAIN_MAX 8
 int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv* const* expand,   /* plans gain a fragment-order weight copy on first use */
                            const float* const* dw_w_dev, const float* const* dw_bias_dev,

@@ -177,6 +177,7 @@ struct OkpFireChainModule {   // okp_fire_chain.hip
 };
 struct OkpFireChainParams {
   const void* x; void* out; int32_t x_ps, out_ps, H, W, n_modules;
+  int32_t He, We;               // EE form (entry + exit modules): size of the map the stride-2 entry module reads
   OkpFireChainModule mod[OKP_FIRE_CHAIN_MAX];
 };
 

@@ -209,6 +209,7 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
 
 
 FIRE_CHAIN_MAX = 8
+FUSE_FIRE_CHAIN_FRAMED = os.environ.get("OKP_FIRE_CHAIN_FRAMED", "1") == "1"   # entry (stride 2) + chain + exit modules of the innermost level in one launch
 FUSE_FIRE_CHAIN = os.environ.get("OKP_FUSE_FIRE_CHAIN", "1") == "1"   # consecutive 512-channel fire modules on <= 4x4 maps: one resident launch
 
 
@@ -226,9 +227,10 @@ def fire_chain(modules, x, out):
         bd = (ctypes.c_void_p * n)(*[m[3].data_ptr() for m in modules])
         xv, ov = x.view(), out.view()
         _lib.check(_lib.lib().okp_fire_chain_forward(n, sq, ex, wd, bd, x.n, ctypes.byref(xv), ctypes.byref(ov), stream_handle()), "okp_fire_chain_forward")
-    for m in modules:
+    for i, m in enumerate(modules):
         half = m[1].cout
-        COUNTERS["macs"] += x.n * x.h * x.w * (m[0].cout * m[0].cins[0] + half * (m[1].cins[0] + 9))
+        sq_px = x.h * x.w if i == 0 else out.h * out.w          # (entry / exit form: the entry module squeezes at the input resolution)
+        COUNTERS["macs"] += x.n * (sq_px * m[0].cout * m[0].cins[0] + out.h * out.w * half * (m[1].cins[0] + 9))
     COUNTERS["launches"] += 1
 
 

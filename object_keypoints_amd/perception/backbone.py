@@ -276,8 +276,33 @@ def run_fire_modules(mods, x):
             return False
         return (m.inp_dim == 512 and x.h <= 4 and x.w <= 4) or (m.inp_dim == 384 and x.h <= 8 and x.w <= 8)
 
+    def framed_chain(i, x):
+        """[stride-2 fire(384, 512) on a map of at most 8 x 8] + fire(512, 512) x k + [fire(512, 384)]: the whole innermost hourglass
+        level (low1, low2, low3 of hg_module n = 1) is ONE launch (the entry / exit form of okp_fire_chain_forward)."""
+        m0 = mods[i]
+        if not (ops.FUSE_FIRE_CHAIN and ops.FUSE_FIRE_CHAIN_FRAMED and x.dtype in ops.HALF_DTYPES and m0.stride == 2 and m0.inp_dim == 384
+                and m0.out_dim == 512 and x.h <= 8 and x.w <= 8):
+            return 0
+        j = i + 1
+        while j < len(mods) and mods[j].stride == 1 and mods[j].skip and mods[j].inp_dim == 512 and mods[j].out_dim == 512:
+            j += 1
+        if j - i - 1 < 1 or j >= len(mods) or j - i + 1 > ops.FIRE_CHAIN_MAX:
+            return 0
+        mx = mods[j]
+        if not (mx.stride == 1 and mx.inp_dim == 512 and mx.out_dim == 384):
+            return 0
+        return j - i + 1
+
     i = 0
     while i < len(mods):
+        k = framed_chain(i, x)
+        if k:
+            plans = [m._plan(("p", x.dtype), lambda m=m: m._build(x.dtype, x.t.device)) for m in mods[i:i + k]]
+            out = Act.empty(x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, 384, x.dtype, x.t.device)
+            ops.fire_chain(plans, x, out)
+            x = out
+            i += k
+            continue
         j = i
         while j < len(mods) and j - i < ops.FIRE_CHAIN_MAX and chainable(mods[j], x) and mods[j].inp_dim == mods[i].inp_dim:
             j += 1

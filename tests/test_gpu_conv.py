@@ -314,6 +314,53 @@ def test_fire_chain_matches_module_by_module(c, h, w, n, count, dtype):
     assert float((got - single).abs().max()) <= eps * (0.02 * scale * max(1, count // 2) + 0.02)
 
 
+@pytest.mark.parametrize("h,w,n,count", [(8, 8, 5, 6), (8, 8, 1, 1), (7, 5, 3, 2), (2, 3, 2, 6), (1, 1, 2, 1)])
+@pytest.mark.parametrize("dtype", HALF)
+def test_framed_fire_chain_matches_module_by_module(h, w, n, count, dtype):
+    """The innermost hourglass level as ONE launch (entry / exit form of okp_fire_chain_forward): stride-2 fire(384, 512) on an
+    h x w map, `count` fire(512, 512), fire(512, 384) - against the oracle's modules applied one by one (fp32) and against the
+    product's own module-by-module path (hg_module n = 1: low1, low2, low3; CornerNet_Squeeze.py:10-51, modules.py hg_module)."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    dev = _dev()
+    shapes = [(384, 512, 2)] + [(512, 512, 1)] * count + [(512, 384, 1)]
+    omods = [onet.load_synthetic(onet.fire_module(a, b, stride=st), seed=60 + i) for i, (a, b, st) in enumerate(shapes)]
+    mods = []
+    for o, (a, b, st) in zip(omods, shapes):
+        m = bb.fire_module(a, b, stride=st)
+        m.load_state_dict(o.state_dict())
+        mods.append(m.eval())
+    x = _q(_rand((n, 384, h, w), 78), dtype)
+    ref = x
+    with torch.no_grad():
+        for o in omods:
+            ref = o(ref)
+    xa = ops.Act.from_nchw(x.to(dev), dtype)
+    keep = ops.FUSE_FIRE_CHAIN_FRAMED
+    try:
+        ops.FUSE_FIRE_CHAIN_FRAMED = True
+        l0 = ops.COUNTERS["launches"]
+        m0 = ops.COUNTERS["macs"]
+        got = bb.run_fire_modules(mods, xa).to_nchw().float().cpu()
+        assert ops.COUNTERS["launches"] - l0 == 1
+        macs_fused = ops.COUNTERS["macs"] - m0
+        again = bb.run_fire_modules(mods, xa).to_nchw().float().cpu()
+        ops.FUSE_FIRE_CHAIN_FRAMED = False
+        m0 = ops.COUNTERS["macs"]
+        single = bb.run_fire_modules(mods, xa).to_nchw().float().cpu()
+        assert ops.COUNTERS["macs"] - m0 == macs_fused            # the FLOP accounting does not depend on the fusion
+    finally:
+        ops.FUSE_FIRE_CHAIN_FRAMED = keep
+    assert got.shape == ref.shape == (n, 384, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    assert torch.equal(got, again)
+    scale = float(ref.abs().max())
+    eps = 1.0 if dtype == torch.bfloat16 else 0.15
+    depth = max(1, (count + 2) // 2)
+    assert float((got - ref).abs().max()) <= eps * (0.03 * scale * depth + 0.02), float((got - ref).abs().max())
+    assert float((got - single).abs().max()) <= eps * (0.02 * scale * depth + 0.02)
+
+
 @pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile", "conv3x3_s2", "conv3x3_s2_odd_input"])
 @pytest.mark.parametrize("dtype", HALF)
 def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
