@@ -372,11 +372,18 @@ class hg_module(nn.Module):
         return self.low3(self.low2(self.low1(x)))
 
     def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_side", st)
+        """Three side streams per device, shared by every hourglass: the 64 x 64 level, the 32 x 32 level, and one for the two levels
+        below.  A stream of its own per hg_module (eight of them, HIP deals streams round-robin onto its four hardware queues) put
+        one of the side branches of the second hourglass on the MAIN stream's queue, i.e. back into the critical chain (step +0.7 %
+        with the shared three; GPU_MAX_HW_QUEUES above its default of 4 costs 30 %, below it 1-5 %)."""
+        key = (device.type, device.index, min(4 - self.n, 2) if self.n <= 4 else 0)
+        st = _SIDE_STREAMS.get(key)
+        if st is None:
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
         return st
+
+
+_SIDE_STREAMS = {}
 
 
 class _MergeMod(nn.Sequential):
