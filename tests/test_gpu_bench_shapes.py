@@ -61,20 +61,23 @@ def test_batch64_frame_independence_and_side_stream_determinism(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("h,stride", [(64, 1), (32, 1), (64, 2)])
-def test_streaming_fire_kernel_at_bench_shapes(h, stride, dtype):
-    """okp_fire2 <256,128> exactly as the bench launches it (N=64; 64x64 and 32x32 at stride 1, 64x64 -> 32x32 at stride 2;
-    XCD-aware tile order) against the oracle's fire_module on frames 0, 31 and 63."""
+@pytest.mark.parametrize("c,co,h,stride", [(256, 256, 64, 1), (256, 256, 32, 1), (256, 256, 64, 2),
+                                            (384, 384, 16, 1), (384, 256, 16, 1), (384, 384, 16, 2), (384, 384, 8, 1), (512, 512, 8, 1), (512, 384, 8, 1)])
+def test_streaming_fire_kernel_at_bench_shapes(c, co, h, stride, dtype):
+    """okp_fire2 exactly as the bench launches it at N=64 (XCD-aware tile order) against the oracle's fire_module on frames 0, 31
+    and 63: <256,128> at 64x64 and 32x32 (stride 1, skip values of the depth-wise branch from the LDS ring) and 64x64 -> 32x32
+    (stride 2); the wide instances of the lower levels, whose squeeze weights stream through the per-wave LDS ring (384 -> 192 at
+    16x16 / 8x8 and at stride 2, 512 -> 256 and 512 -> 192 at 8x8) or through three register sets (384 -> 128)."""
     from object_keypoints_amd import ops
     from object_keypoints_amd.perception import backbone as bb
     from oracle import net as onet
     _need(dtype)
-    o = onet.load_synthetic(onet.fire_module(256, 256, stride=stride), seed=21)
-    m = bb.fire_module(256, 256, stride=stride)
+    o = onet.load_synthetic(onet.fire_module(c, co, stride=stride), seed=21)
+    m = bb.fire_module(c, co, stride=stride)
     m.load_state_dict(o.state_dict())
     m.eval()
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
-    x = torch.randn((64, h, h, 256), generator=gen, device="cuda").to(dtype)
+    x = torch.randn((64, h, h, c), generator=gen, device="cuda").to(dtype)
     l0 = ops.COUNTERS["launches"]
     got = m(ops.Act(x))
     assert ops.COUNTERS["launches"] - l0 == 1
