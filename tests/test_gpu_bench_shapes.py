@@ -93,6 +93,45 @@ def test_streaming_fire_kernel_at_bench_shapes(c, co, h, stride, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", ["innermost_level", "pair_384"])
+def test_resident_chains_at_bench_batch(form, dtype):
+    """okp_fire_chain at N=64 as the bench launches it: the innermost hourglass level in one launch (stride-2 fire(384, 512) from 8x8,
+    six fire(512, 512), fire(512, 384): entry / exit form) and a pair of fire(384, 384) at 8x8 - against the oracle's modules on frames
+    0, 31, 63, bit-equal to the single-frame launch for those frames (one workgroup per frame) and run to run."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    _need(dtype)
+    shapes = [(384, 512, 2)] + [(512, 512, 1)] * 6 + [(512, 384, 1)] if form == "innermost_level" else [(384, 384, 1)] * 2
+    omods = [onet.load_synthetic(onet.fire_module(a, b, stride=st), seed=80 + i) for i, (a, b, st) in enumerate(shapes)]
+    mods = []
+    for o, (a, b, st) in zip(omods, shapes):
+        m = bb.fire_module(a, b, stride=st)
+        m.load_state_dict(o.state_dict())
+        mods.append(m.eval())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    x = torch.randn((64, 8, 8, 384), generator=gen, device="cuda").to(dtype)
+    l0 = ops.COUNTERS["launches"]
+    got = bb.run_fire_modules(mods, ops.Act(x))
+    assert ops.COUNTERS["launches"] - l0 == 1
+    sample = [0, 31, 63]
+    with torch.no_grad():
+        ref = x[sample].float().permute(0, 3, 1, 2).cpu()
+        for o in omods:
+            ref = o(ref)
+    g = got.t[sample].float().permute(0, 3, 1, 2).cpu()
+    assert g.shape == ref.shape
+    scale = float(ref.abs().max())
+    eps = (0.03 if dtype == torch.bfloat16 else 0.004) * max(1, len(shapes) // 2)
+    assert float((g - ref).abs().max()) <= eps * scale + eps, float((g - ref).abs().max())
+    for i in sample:
+        one = bb.run_fire_modules(mods, ops.Act(x[i:i + 1].contiguous()))
+        assert torch.equal(one.t, got.t[i:i + 1]), f"frame {i} differs between batch 64 and batch 1"
+    again = bb.run_fire_modules(mods, ops.Act(x))
+    assert torch.equal(again.t, got.t)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fused_heads_at_bench_batch(dtype):
     """okp_heads at N=64 (the three workgroups of a tile on one XCD) against the three-launch path, all 64 frames."""
     from object_keypoints_amd import ops
