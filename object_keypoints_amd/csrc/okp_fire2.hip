@@ -36,20 +36,6 @@
 namespace {
 
 constexpr uint32_t kInvalid = 0x80000000u;
-#ifdef OKP_FIRE2_CLK                              // debug build only (scripts/probe_fire2_clk.py): phase time stamps of each workgroup's first tile
-__device__ long long okp_fire2_clk_buf[1024 * 8];
-// OKP_FIRE2_CLK=1: stamps of the first tile; =2: stamp i accumulates the time since the previous stamp over ALL tiles (slot 7: tile count)
-#if OKP_FIRE2_CLK == 2
-#define CLKNW(i) do { const long long t_ = wall_clock64(); clk_acc[i] += t_ - clk_prev; clk_prev = t_; } while (0)
-#define CLK(i) CLKNW(i)
-#else
-#define CLK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#define CLKNW(i) do { if (threadIdx.x == 0 && first_tile && blockIdx.x < 1024) okp_fire2_clk_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#endif
-#else
-#define CLK(i)
-#define CLKNW(i)
-#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -117,11 +103,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, q = lane >> 4;
-#ifdef OKP_FIRE2_CLK
-  long long clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_prev = wall_clock64();
-  bool first_tile = true;
-#endif
-  CLKNW(0);
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
@@ -245,9 +226,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
-  CLKNW(1);
   __syncthreads();                                           // depth-wise constants are in LDS
-  CLK(2);
   tile_setup(tile);
   first_weights(w1f);
 #pragma unroll
@@ -338,7 +317,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         for (int b = 0; b < 2; ++b)
           acc[pb][b] = H16<T>::mfma16(WRING ? wr[b] : w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
     }
-    CLKNW(3);
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     u32x4 waf[2][KS2];
 #pragma unroll
@@ -367,7 +345,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     __syncthreads();
-    CLKNW(4);
     // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
     {
       // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
@@ -425,7 +402,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     asm volatile("" ::: "memory");             // keep the stores here (the scheduler otherwise sinks them below phase 2b)
-    CLKNW(5);
 
     // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
@@ -504,32 +480,11 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
-    CLKNW(6);
-#if OKP_FIRE2_CLK == 2
-    clk_acc[7] += 1;
-#else
-    CLK(7);
-#endif
-#ifdef OKP_FIRE2_CLK
-    first_tile = false;
-#endif
   }
-#if OKP_FIRE2_CLK == 2
-  if (threadIdx.x == 0 && blockIdx.x < 1024)
-    for (int i = 0; i < 8; ++i) okp_fire2_clk_buf[blockIdx.x * 8 + i] = clk_acc[i];
-#endif
 }
 
 }  // namespace
 
-#ifdef OKP_FIRE2_CLK
-extern "C" int okp_fire2_clk_read(long long* host, int n) {
-  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(okp_fire2_clk_buf), sizeof(long long) * (size_t)n);
-  static long long zeros[1024 * 8];
-  if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(okp_fire2_clk_buf), zeros, sizeof(zeros));
-  return rc;
-}
-#endif
 
 bool okp_fire2_supported(int cin, int mid, int half, int stride) {
   if (half != mid) return false;
