@@ -83,8 +83,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr bool RES = CIN <= 256;                 // squeeze weights resident in registers
   // Wider inputs stream the squeeze weights.  With >= 192 squeeze channels (one workgroup per CU, LDS to spare) they go through a
   // per-wave LDS ring of DW k-steps filled by LDS-DMA (fragment order: 1 KiB per instruction, read back by the lane that needs it -
-  // no barrier, no registers): DW - 1 steps in flight cover the 2-3 us the weights take to arrive (every XCD misses its L2 on them once
-  // per launch), where the three register sets of the 128-channel instance (two workgroups per CU, no LDS left) cover 2 steps.
+  // no barrier, no registers): DW - 1 steps in flight cover the 2-3 us a weight load takes to return under load (hot or cold in L2
+  // alike), where the three register sets of the 128-channel instance (two workgroups per CU, no LDS left) cover 2 steps.
   constexpr bool WRING = !RES && MID >= 192;
   constexpr int DW = !WRING ? 0 : MID == 192 ? 5 : 3;
   constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
