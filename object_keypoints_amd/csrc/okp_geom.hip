@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void okp_group_objects_kernel(const GroupParams
   for (int i = lane; i < p.max_obj * (p.K - 1); i += 64) votes[i] = 0;
   int* assign = p.assign + (size_t)f * p.K * p.cap;
   double* pred = p.pred + (size_t)f * p.K * p.cap * 2;
-  for (int i = lane; i < p.K * p.cap; i += 64) assign[i] = -1;
+  for (int i = lane; i < p.K * p.cap; i += 64) { assign[i] = -1; pred[2 * i] = 0.0; pred[2 * i + 1] = 0.0; }   // unused slots are defined output (callers hand over uninitialised buffers)
   if (nobj == 0) return;
   if (lane < nobj) { oc[2 * lane] = pk[lane * 3 + 0]; oc[2 * lane + 1] = pk[lane * 3 + 1]; }
   __syncthreads();

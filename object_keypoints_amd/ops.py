@@ -532,7 +532,7 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
     sel = torch.empty((n, max_obj, k - 1, max_sel), dtype=torch.int32, device=dev)
     votes = torch.empty((n, max_obj, k - 1), dtype=torch.int32, device=dev)
     assign = torch.empty((n, k, cap), dtype=torch.int32, device=dev)
-    pred = torch.zeros((n, k, cap, 2), dtype=torch.float64, device=dev)
+    pred = torch.empty((n, k, cap, 2), dtype=torch.float64, device=dev)      # (the kernel zeroes the unused slots)
     T = _lib.torch_ops()
     if T is not None:
         _dispatch(T.group_objects, count, xyc, centers, [int(c) for c in type_count], float(max_dist), max_obj, max_sel, n_obj, sel, votes, assign, pred, stream_int())
@@ -545,13 +545,13 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
 
 
 def capacity_overflow(count, cap, max_obj):
-    """count [N,K] int32 (device) -> 0-d bool tensor (device): some map holds more than `cap` peaks, or some frame more than
-    `max_obj` centre peaks.  One small launch, no host sync."""
+    """count [N,K] int32 (device) -> 0-d int32 tensor (device), non-zero when some map holds more than `cap` peaks or some frame more
+    than `max_obj` centre peaks (`bool(flag)` on the host).  One small launch, no host sync, no torch kernel."""
     require_cuda(count, "count")
     flag = torch.empty((1,), dtype=torch.int32, device=count.device)
     n, k = count.shape
     _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
-    return flag[0] != 0
+    return flag[0]
 
 
 def triangulate_dlt(cam_l, cam_r, T_RL, left_xy, right_xy, F=None):

@@ -363,7 +363,7 @@ class BatchedKeypointPipeline:
     forward_device(frames) returns device tensors
         heat [N,K,H,W], depth [N,K,H,W], centers [N,K-1,2,H,W],
         count [N,K] int32, xyc [N,K,cap,3] fp32 (x, y, confidence), points [N,K,cap,4] fp64 (X, Y, Z, confidence),
-        overflow (0-d bool: some map exceeded `capacity` peaks or `max_objects` centres - results are truncated)
+        overflow (0-d int32, non-zero: some map exceeded `capacity` peaks or `max_objects` centres - results are truncated)
     `points` is the fixed-capacity payload that is all-gathered across ranks (object_keypoints_amd.distributed).
     objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points.
     """
