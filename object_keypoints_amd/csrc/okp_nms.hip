@@ -16,14 +16,18 @@ constexpr int kNmsThreads = 1024;            // 4 pixels per thread on a 64x64 m
 
 // The map is walked in strips of R rows (R = H when it fits: one strip for the 64x64 maps of the network).  A strip keeps
 // the probabilities of rows [r0-4, r0+R+4) and the box sums of rows [r0-2, r0+R+2) in LDS: the 5x5 maximum of a box-sum
-// row needs box rows +-2, each of which needs probability rows +-2.  Strips are processed in order by the same workgroup
-// with a running peak count, so the row-major peak order of the reference is kept for maps of any size.
+// row needs box rows +-2, each of which needs probability rows +-2.  Both arrays carry a two-pixel border of ZEROS (columns
+// -2, -1, W, W+1 and the rows outside the image): the box sum adds the padding exactly as the reference's zero-padded
+// convolution does (x + 0 = x in fp32, same tap order), and a zero never wins the 5x5 maximum against the non-negative box
+// sums - so neither inner loop tests a bound.  Strips are processed in order by the same workgroup with a running peak
+// count, so the row-major peak order of the reference is kept for maps of any size.
 __global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* __restrict__ heat, int H, int W, int R, int cap,
                                                                    int* __restrict__ count, int* __restrict__ yx,
                                                                    float* __restrict__ xyc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* prob = lds;                       // [(R+8) rows][W]
-  float* box = lds + (size_t)(R + 8) * W;  // [(R+4) rows][W]
+  const int WP = W + 4;                    // padded row pitch
+  float* prob = lds;                       // [(R+8) rows][WP]: image rows r0-4 .. r0+R+3, columns -2 .. W+1
+  float* box = lds + (size_t)(R + 8) * WP; // [(R+4) rows][WP]: image rows r0-2 .. r0+R+1
   __shared__ int wave_tot[kNmsThreads / 64];
   const int map = blockIdx.x;
   const int tid = threadIdx.x;
@@ -32,44 +36,48 @@ __global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* 
   int running = 0;
   int* my_yx = yx + (size_t)map * cap * 2;
   float* my_xyc = xyc + (size_t)map * cap * 3;
+  // this thread's position in a row-major walk over W-wide rows, advanced by kNmsThreads per step without a division
+  const int sy = kNmsThreads / W, sx = kNmsThreads - sy * W;
   for (int r0 = 0; r0 < H; r0 += R) {
-    const int p0 = max(r0 - 4, 0), p1 = min(r0 + R + 4, H);        // probability rows held
-    const int b0 = max(r0 - 2, 0), b1 = min(r0 + R + 2, H);        // box-sum rows held
     const int s1 = min(r0 + R, H);                                 // rows [r0, s1) are classified in this strip
-    for (int i = tid; i < (p1 - p0) * W; i += kNmsThreads) prob[i] = src[(size_t)p0 * W + i];
+    // probabilities with their zero border
+    for (int i = tid; i < (R + 8) * WP; i += kNmsThreads) {
+      const int ly = i / WP, lx = i - ly * WP;
+      const int y = r0 - 4 + ly, x = lx - 2;
+      prob[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+    }
+    for (int i = tid; i < (R + 4) * WP; i += kNmsThreads) box[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < (b1 - b0) * W; i += kNmsThreads) {
-      const int y = b0 + i / W, x = i % W;
-      float s = 0.f;
-      for (int dy = -2; dy <= 2; ++dy) {
-        const int yy = y + dy;
-        for (int dx = -2; dx <= 2; ++dx) {
-          const int xx = x + dx;
-          const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? prob[(yy - p0) * W + xx] : 0.f;
-          s = s + v;     // sequential fp32, row-major taps: the reference's accumulation order
-        }
+    // box sums of the image rows max(r0-2, 0) .. min(r0+R+2, H) - 1
+    {
+      const int b0 = max(r0 - 2, 0), b1 = min(r0 + R + 2, H);
+      int y = b0 + tid / W, x = tid % W;
+      for (; y < b1; ) {
+        const float* pp = prob + (size_t)(y - (r0 - 4) - 2) * WP + x;       // tap (dy, dx) = pp[(dy + 2) * WP + dx + 2]
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) s = s + pp[dy * WP + dx];           // sequential fp32, row-major taps: the reference's accumulation order
+        box[(size_t)(y - (r0 - 2)) * WP + x + 2] = s;
+        x += sx; y += sy;
+        if (x >= W) { x -= W; ++y; }
       }
-      box[i] = s;
     }
     __syncthreads();
     const int n_px = (s1 - r0) * W;
+    int y = r0 + tid / W, x = tid % W;
     for (int base = 0; base < n_px; base += kNmsThreads) {
       const int i = base + tid;
       bool peak = false;
-      int y = 0, x = 0;
       if (i < n_px) {
-        y = r0 + i / W; x = i % W;
-        const float b = box[(y - b0) * W + x];
+        const float* bp = box + (size_t)(y - (r0 - 2) - 2) * WP + x;         // tap (dy, dx) = bp[(dy + 2) * WP + dx + 2]
+        const float b = bp[2 * WP + 2];
         float m = b;
-        for (int dy = -2; dy <= 2; ++dy) {
-          const int yy = y + dy;
-          if (yy < 0 || yy >= H) continue;
-          for (int dx = -2; dx <= 2; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            m = fmaxf(m, box[(yy - b0) * W + xx]);
-          }
-        }
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) m = fmaxf(m, bp[dy * WP + dx]);
         peak = (b == m) && (b > 0.5f);
       }
       const unsigned long long ball = __ballot(peak);
@@ -86,21 +94,23 @@ __global__ __launch_bounds__(kNmsThreads) void okp_peak_nms_kernel(const float* 
       }
       if (peak && off < cap) {
         const int y0 = max(y - 2, 0), y1 = min(y + 3, H), x0 = max(x - 2, 0), x1 = min(x + 3, W);
-        float sp = 0.f, sy = 0.f, sx = 0.f;
+        float sp = 0.f, sy2 = 0.f, sx2 = 0.f;
         for (int yy = y0; yy < y1; ++yy)
           for (int xx = x0; xx < x1; ++xx) {
-            const float pv = prob[(yy - p0) * W + xx];
+            const float pv = prob[(size_t)(yy - (r0 - 4)) * WP + xx + 2];
             sp += pv;
-            sy += pv * (float)yy;
-            sx += pv * (float)xx;
+            sy2 += pv * (float)yy;
+            sx2 += pv * (float)xx;
           }
         my_yx[off * 2 + 0] = y;
         my_yx[off * 2 + 1] = x;
-        my_xyc[off * 3 + 0] = sx / sp;
-        my_xyc[off * 3 + 1] = sy / sp;
+        my_xyc[off * 3 + 0] = sx2 / sp;
+        my_xyc[off * 3 + 1] = sy2 / sp;
         my_xyc[off * 3 + 2] = sp;
       }
       running += tot;
+      x += sx; y += sy;
+      if (x >= W) { x -= W; ++y; }
       __syncthreads();
     }
   }
@@ -155,11 +165,11 @@ extern "C" int okp_peak_nms(const float* heat, int32_t n_maps, int32_t h, int32_
   if (n_maps < 0 || h < 1 || w < 1 || cap < 1) { okp_set_error("okp_peak_nms: bad sizes n_maps=%d h=%d w=%d cap=%d", n_maps, h, w, cap); return OKP_EINVAL; }
   // strip height: (R + 8) probability rows + (R + 4) box-sum rows of w floats in at most 128 KiB of LDS
   constexpr long kLdsFloats = 32768;
-  long rmax = (kLdsFloats / w - 12) / 2;
-  if (rmax < 1) { okp_set_error("okp_peak_nms: maps wider than %ld pixels are not supported (width %d)", kLdsFloats / 14, w); return OKP_EINVAL; }
+  long rmax = (kLdsFloats / (w + 4) - 12) / 2;           // rows of w + 4 floats (two-pixel zero border)
+  if (rmax < 1) { okp_set_error("okp_peak_nms: maps wider than %ld pixels are not supported (width %d)", kLdsFloats / 14 - 4, w); return OKP_EINVAL; }
   const int R = (int)(rmax < h ? rmax : h);
   if (n_maps == 0) return OKP_OK;
-  const size_t lds = (size_t)(2 * R + 12) * w * sizeof(float);
+  const size_t lds = (size_t)(2 * R + 12) * (w + 4) * sizeof(float);
   // the attribute is per device: one bit per device id (idempotent, so a race only repeats the call)
   static std::atomic<unsigned long long> attr_set{0ull};
   int dev = 0;
