@@ -23,12 +23,19 @@ def okp_dtype(torch_dtype):
         raise OkpError(f"unsupported activation dtype {torch_dtype}; use torch.float32, torch.bfloat16 or torch.float16")
 
 
-def stream_handle():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+# torch.cuda.current_stream() builds a Stream object through four Python layers (8 us under a profiler, ~75 calls per network pass);
+# the raw handle of the current stream of the current device is one C call
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_int():
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
+
+
+def stream_handle():
+    return ctypes.c_void_p(stream_int())
 
 
 def _dispatch(fn, *args):
@@ -235,6 +242,8 @@ def fire_chain(modules, x, out):
 
 
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
+SIDE_MIN_BATCH = int(os.environ.get("OKP_SIDE_MIN_BATCH", "8"))    # eager passes of fewer frames are host-bound and a fork / join costs the host ~40 us:
+                                                                   # below this batch the branches run on the main stream (unless a hipGraph is being captured)
 SIDE_MIN_LEVEL = int(os.environ.get("OKP_SIDE_MIN_LEVEL", "1"))   # hourglass levels (4 = 64x64 ... 1 = 8x8) from which the fork is used
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64

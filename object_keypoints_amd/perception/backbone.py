@@ -351,7 +351,7 @@ class hg_module(nn.Module):
         """up1(x) and the whole low path are independent until the merge.  The low path is a long chain of small,
         latency-bound launches that leave most of the 256 CUs idle, so up1 runs on a side HIP stream and fills
         them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph)."""
-        if not ops.SIDE_STREAMS or self.n < ops.SIDE_MIN_LEVEL:
+        if not ops.SIDE_STREAMS or self.n < ops.SIDE_MIN_LEVEL or (x.n < ops.SIDE_MIN_BATCH and not torch.cuda.is_current_stream_capturing()):
             up1 = self.up1(x)
             low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)
             return self.up2(low3, up1)
