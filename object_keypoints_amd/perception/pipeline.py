@@ -218,6 +218,25 @@ class DetectionToPoint:
         out = ops.unproject_depth(self.camera.okp(), pts, ids, depth, int(self.max_index[0]), int(self.max_index[1]))
         return out.cpu().numpy()
 
+    def lift_groups(self, groups, p_depth):
+        """Every keypoint group of a frame in ONE launch: groups = [(xy (n_i, 2), depth-map index k_i), ...], p_depth (K, H, W) ->
+        [(n_i, 3) float64 or None, ...], each exactly what __call__(xy, p_depth[k_i]) returns (the kernel treats points one by one;
+        one upload, one launch and one read-back per frame instead of three tiny transfers and a launch per group)."""
+        sizes = [int(np.asarray(xy).shape[0]) for xy, _ in groups]
+        if sum(sizes) == 0:
+            return [None] * len(groups)
+        dev = _device()
+        xy_all = np.concatenate([np.asarray(xy, dtype=np.float32).reshape(-1, 2) for xy, _ in groups if np.asarray(xy).shape[0]], axis=0)
+        ids_all = np.concatenate([np.full(n, k, dtype=np.int32) for n, (_, k) in zip(sizes, groups) if n])
+        depth = torch.from_numpy(np.ascontiguousarray(p_depth, dtype=np.float32)).to(dev)
+        out = ops.unproject_depth(self.camera.okp(), torch.from_numpy(np.ascontiguousarray(xy_all)).to(dev), torch.from_numpy(ids_all).to(dev),
+                                  depth, int(self.max_index[0]), int(self.max_index[1])).cpu().numpy()
+        res, at = [], 0
+        for n in sizes:
+            res.append(out[at:at + n] if n else None)
+            at += n
+        return res
+
 
 class ObjectKeypointPipeline:
     def __init__(self, prediction_size, points_3d, keypoint_config):
@@ -235,14 +254,20 @@ class ObjectKeypointPipeline:
         p_depth = (p_depth[0].numpy() if isinstance(p_depth, torch.Tensor) else np.asarray(p_depth)[0])
         points, confidence = self.keypoint_extraction(heatmap)
         detected_objects = self.object_extraction(points[0], confidence[0], p_centers)
-        objects = []
+        # the reference lifts group by group (pipeline.py:190-200); here all groups of the frame go through one launch
+        groups = []
         for obj in detected_objects:
-            world_points = [self.detection_to_point(obj['center'][None], p_depth[0])]
+            groups.append((obj['center'][None], 0))
             for i in range(len(obj['heatmap_points'])):
-                world_points.append(self.detection_to_point(obj['heatmap_points'][i], p_depth[1 + i]))
+                groups.append((obj['heatmap_points'][i], 1 + i))
+        lifted = self.detection_to_point.lift_groups(groups, p_depth) if groups else []
+        objects, at = [], 0
+        for obj in detected_objects:
+            n_groups = 1 + len(obj['heatmap_points'])
             objects.append({'p_centers': obj['p_centers'],
                             'keypoints': [obj['center'][None]] + obj['heatmap_points'],
-                            'p_C': world_points})
+                            'p_C': lifted[at:at + n_groups]})
+            at += n_groups
         return objects
 
 
