@@ -27,9 +27,15 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 2     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan... */
+#define OKP_ABI_VERSION 3     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3 */
 
-enum { OKP_F32 = 0, OKP_BF16 = 1, OKP_F16 = 2 };   /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]) */
+/* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
+ * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
+ * fp32 tensor - but the products run on the fp16 matrix pipe as the three-term split x*w = x_hi*w_hi + x_lo*w_hi + x_hi*w_lo
+ * (x = x_hi + x_lo, two fp16 halves = 22 significant bits; fp32 accumulation).  Results agree with OKP_F32 to ~1e-6 relative
+ * (the reference's fp32 tolerance, perception/pipeline.py:20-27, holds) at a multiple of its speed; operands must stay below
+ * 65504 in magnitude. */
+enum { OKP_F32 = 0, OKP_BF16 = 1, OKP_F16 = 2, OKP_F32X3 = 3 };
 enum { OKP_ACT_NONE = 0, OKP_ACT_RELU = 1, OKP_ACT_SIGMOID = 2 };
 enum {
   OKP_OK = 0,
@@ -89,9 +95,9 @@ typedef struct okp_conv_args {
   okp_tensor out;                  /* out.h/out.w are the FULL output tensor's spatial size */
   int32_t out_step, out_oy, out_ox;/* sub-pixel placement (1,0,0 for ordinary convs) */
   okp_tensor res;                  /* optional residual, same spatial mapping as out; data==NULL if none */
-  int32_t tile;                    /* 0 = auto; 1 64x64, 2 128x128, 3 256x256 (32x32 MFMA); 4/5 half-slice rings; 6/7/8 = 256/128/64 on 16x16 MFMA;
-                                      9-12 experimental tiles; 13 = patch-resident 3x3 kernel (bf16, cout_pad % 256 == 0, whole 16x16-pixel
-                                      blocks, dense output; OKP_EINVAL where it does not apply) */
+  int32_t tile;                    /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x256 (32x32 MFMA); 4 = 128x256 on a half-slice ring;
+                                      6 / 8 = 256x256 / 64x64 on 16x16 MFMAs (16-bit types); 13 = patch-resident 3x3 kernel (16-bit types,
+                                      cout_pad % 256 == 0, whole 16x16-pixel blocks; OKP_EINVAL where it does not apply) */
   /* Optional fused depth-wise branch (the fire-module tail, CornerNet_Squeeze.py:15-17,25-30): the same launch
    * also computes  dw_out[..., c] = act(dw_bias[c] + dw_res[..., c] + sum_{3x3 taps} dw_w[tap][c] * src[0][..., c])
    * for c in [0, cout) with the plan's conv_stride[0] and pad 1, so that `expand 1x1 || depth-wise 3x3` of one

@@ -1,5 +1,6 @@
 // C-ABI glue of libokp_hip.so: error reporting, convolution plans (weight packing + upload),
 // argument validation and launch of the implicit-GEMM kernel.  See include/okp.h.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
@@ -62,7 +63,7 @@ extern "C" int okp_device_arch(int dev, char* buf, int buflen) {
 
 extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
                                      int32_t n_taps, const okp_tap* taps, const float* bias, int act) {
-  if (dtype != OKP_F32 && !okp_is16(dtype)) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
+  if (dtype != OKP_F32 && dtype != OKP_F32X3 && !okp_is16(dtype)) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
   if (n_src < 1 || n_src > 2 || !cin || !conv_stride || !taps) { okp_set_error("okp_conv_create: bad sources"); return nullptr; }
   if (n_taps < 1 || n_taps > OKP_MAX_TAPS) { okp_set_error("okp_conv_create: n_taps %d not in [1,%d]", n_taps, OKP_MAX_TAPS); return nullptr; }
   if (cout < 8 || cout % 8) { okp_set_error("okp_conv_create: cout %d must be a positive multiple of 8", cout); return nullptr; }
@@ -265,6 +266,39 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
         ok = ok && !okp_check_hip(hipMalloc(&plan->fragT_dev, n16 * 16), "hipMalloc(fragment-order weights, channel rows)");
         ok = ok && !okp_check_hip(hipMemcpy(plan->fragT_dev, fr.data(), n16 * 16, hipMemcpyHostToDevice), "hipMemcpy(fragment-order weights, channel rows)");
       }
+    } else if (dtype == OKP_F32X3) {
+      // split-product plans: every 128-byte row (32 fp32 of K) becomes [hi k0-15 | lo k0-15 | hi k16-31 | lo k16-31] in fp16,
+      // hi = fp16(w), lo = fp16(w - hi): the weight fragments of okp_igemm_kernel<F32S> are read ready-made.
+      // A channel's weights are first multiplied by a power of two that puts the largest of them in [256, 512): the low halves
+      // of all weights down to 2^-12 of it are then normal fp16 numbers whatever the scale BatchNorm folding left them at (a row of
+      // weights around 1e-5 would otherwise have no low halves at all).  The kernel multiplies the accumulator by 1 / scale (exact).
+      std::vector<float> osc(bias_pad, 1.f);
+      for (int co = 0; co < cout; ++co) {
+        float mx = 0.f;
+        for (int si = 0; si < plan->n_slices; ++si)
+          for (int k = 0; k < 32; ++k) mx = std::max(mx, std::fabs(packed[((size_t)si * plan->cout_pad + co) * 32 + k]));
+        if (mx > 0.f && std::isfinite(mx)) {
+          int e; std::frexp(mx, &e);                       // mx = f * 2^e, f in [0.5, 1)
+          const float sc = std::ldexp(1.f, 9 - e);         // mx * sc in [256, 512)
+          osc[co] = 1.f / sc;
+          for (int si = 0; si < plan->n_slices; ++si)
+            for (int k = 0; k < 32; ++k) packed[((size_t)si * plan->cout_pad + co) * 32 + k] *= sc;
+        }
+      }
+      ok = !okp_check_hip(hipMalloc((void**)&plan->oscale_dev, sizeof(float) * bias_pad), "hipMalloc(oscale)");
+      ok = ok && !okp_check_hip(hipMemcpy(plan->oscale_dev, osc.data(), sizeof(float) * bias_pad, hipMemcpyHostToDevice), "hipMemcpy(oscale)");
+      std::vector<uint16_t> h(n_el * 2);
+      for (size_t r = 0; r < n_el / 32; ++r)
+        for (int k = 0; k < 32; ++k) {
+          const float w = packed[r * 32 + k];
+          const _Float16 hi = (_Float16)w;
+          const _Float16 lo = (_Float16)(w - (float)hi);
+          uint16_t uh, ul;
+          std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
+          const size_t base = r * 64 + (size_t)(k / 16) * 32 + (k % 16);
+          h[base] = uh; h[base + 16] = ul;
+        }
+      ok = ok && !okp_check_hip(hipMemcpy(plan->weights_dev, h.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
     } else {
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, packed.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
     }
@@ -284,6 +318,7 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
   if (!plan) return;
   if (plan->weights_dev) (void)hipFree(plan->weights_dev);
   if (plan->bias_dev) (void)hipFree(plan->bias_dev);
+  if (plan->oscale_dev) (void)hipFree(plan->oscale_dev);
   if (plan->slices_dev) (void)hipFree(plan->slices_dev);
   if (plan->frag_dev) (void)hipFree(plan->frag_dev);
   if (plan->fragT_dev) (void)hipFree(plan->fragT_dev);
@@ -341,7 +376,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
     p.srcH[s] = a->src[ss].h; p.srcW[s] = a->src[ss].w; p.src_pix_stride[s] = a->src[ss].pix_stride;
     p.conv_stride[s] = plan->conv_stride[ss];
   }
-  p.weights = plan->weights_dev; p.w_bytes = plan->w_bytes; p.cout_pad = plan->cout_pad; p.bias = plan->bias_dev;
+  p.weights = plan->weights_dev; p.w_bytes = plan->w_bytes; p.cout_pad = plan->cout_pad; p.bias = plan->bias_dev; p.oscale = plan->oscale_dev;
   p.slices = plan->slices_dev; p.n_slices = plan->n_slices; p.n_taps = plan->n_taps;
   p.N = a->n; p.Ho = a->ho; p.Wo = a->wo;
   p.div_howo = okp_fastdiv((uint32_t)(a->ho * a->wo)); p.div_wo = okp_fastdiv((uint32_t)a->wo);

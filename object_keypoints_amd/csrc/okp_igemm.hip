@@ -15,6 +15,16 @@ int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStre
   }
 }
 
+// OKP_F32X3: the fp32-storage tiles with the split-product loop (32x32x16 fp16 MFMAs)
+int launch_tile_x3(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
+  switch (tile) {
+    case 4: return launch_cfg<F32S, 128, 256, 2, 2, 3, 64>(plan, p, stream);
+    case 3: case 6: return launch_cfg<F32S, 256, 256, 4, 2, 2, 128>(plan, p, stream);
+    case 2: return launch_cfg<F32S, 128, 128, 2, 2, 2, 128>(plan, p, stream);
+    default: return launch_cfg<F32S, 64, 64, 2, 2, 4, 128>(plan, p, stream);
+  }
+}
+
 }  // namespace
 
 int okp_select_tile(int dtype, int cout_pad, long P) {
@@ -32,5 +42,6 @@ int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hi
   if (tile == 0) tile = okp_select_tile(plan->dtype, p.cout_pad, (long)p.N * p.Ho * p.Wo);
   if (plan->dtype == OKP_BF16) return launch_tile<__bf16>(plan, p, tile, stream);
   if (plan->dtype == OKP_F16) return launch_tile<_Float16>(plan, p, tile, stream);
+  if (plan->dtype == OKP_F32X3) return launch_tile_x3(plan, p, tile, stream);
   return launch_tile<float>(plan, p, tile, stream);
 }

@@ -26,7 +26,42 @@ namespace {
 
 constexpr uint32_t kInvalidOff = 0x80000000u;   // >= num_records of every tensor we accept (< 2 GiB)
 
+// fp32 activations and weights whose products run on the fp16 matrix pipe as a three-term split (OKP_F32X3): an fp32
+// value x is x_hi + x_lo with x_hi = fp16(x), x_lo = fp16(x - x_hi) (22 significant bits together), and
+// x * w = x_hi w_hi + x_lo w_hi + x_hi w_lo (+ x_lo w_lo, 2^-22 relative: dropped), each term exact in the fp32
+// accumulator.  3 MFMAs of 32 cycles do the work of eight 64-cycle fp32 MFMAs: 5.3x the fp32 matrix peak at fp32-grade
+// results (tests/precision/emulate.py: the heat maps stay within 3e-6 of the reference, like the exact-fp32 kernel).
+// Tensors in HBM and LDS stay fp32: the weight blob holds the two fp16 halves pre-split by okp_conv_create
+// (per 128-byte K-slice row: [hi k0-15 | lo k0-15 | hi k16-31 | lo k16-31], the bytes of 32 fp32), the activation
+// fragments are split in registers.  Operands must be below 65504 in magnitude (as for OKP_F16).
+struct F32S { float v; };
+static_assert(sizeof(F32S) == 4, "fp32 storage");
+
+// 8 fp32 of K held by a lane (two 16-byte chunks) -> its fp16 hi / lo fragments
+__device__ __forceinline__ void okp_split8(const u32x4& r0, const u32x4& r1, u32x4& hi, u32x4& lo) {
+  const f32x4 x0 = __builtin_bit_cast(f32x4, r0), x1 = __builtin_bit_cast(f32x4, r1);
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 a = (_Float16)x0[e], b = (_Float16)x1[e];
+    h[e] = a; h[4 + e] = b;
+    l[e] = (_Float16)__builtin_fmaf((float)a, -1.0f, x0[e]); l[4 + e] = (_Float16)__builtin_fmaf((float)b, -1.0f, x1[e]);    // one v_fma_mix_f32 each
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+
 template <typename T, int MT> struct Mma;
+template <> struct Mma<F32S, 32> {
+  using acc_t = f32x16;
+  // (the split kernel has its own main loop: operands arrive as hi / lo pairs)
+  static __device__ __forceinline__ void run3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x16& c) {
+    c = H16<_Float16>::mfma32(al, bh, c);
+    c = H16<_Float16>::mfma32(ah, bl, c);
+    c = H16<_Float16>::mfma32(ah, bh, c);
+  }
+  static __device__ __forceinline__ void run(const u32x4&, const u32x4&, f32x16&) {}
+};
 template <> struct Mma<float, 32> {
   using acc_t = f32x16;
   // 16 B = 4 fp32 of K per lane: four 32x32x2 MFMAs, lane half h supplies k = 4h+e (K order is
@@ -101,11 +136,13 @@ template <typename T> struct Io16 {
     *reinterpret_cast<x8*>(p) = a;
   }
 };
+template <> struct Io<F32S> : Io<float> {};
 template <> struct Io<__bf16> : Io16<__bf16> {};
 template <> struct Io<_Float16> : Io16<_Float16> {};
 // vector types of the element type (fp32 never uses the 16-bit ones; they only have to name a type)
 template <typename T> struct Vt { using x4 = typename H16<T>::x4; using x8 = typename H16<T>::x8; };
 template <> struct Vt<float> { using x4 = bf16x4; using x8 = bf16x8; };
+template <> struct Vt<F32S> { using x4 = bf16x4; using x8 = bf16x8; };
 
 __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
@@ -159,9 +196,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   constexpr int PITCH = BCO * ESZ;
 
   // ONE LDS object (a second __shared__ array makes hipcc drain LDS-DMA before unrelated ds_reads)
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta) + 1024];
+  constexpr bool X3 = std::is_same<T, F32S>::value;      // split-product plans (OKP_F32X3): see struct F32S
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta) + (X3 ? 2048 : 1024)];
   SliceMeta* const meta = reinterpret_cast<SliceMeta*>(smem + LDS_BYTES);
-  char* const bias_lds = smem + LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta);     // this tile's BCO biases (fp32)
+  char* const bias_lds = smem + LDS_BYTES + kMetaMax * (int)sizeof(SliceMeta);     // this tile's BCO biases (fp32); X3: + BCO output scales
   static_assert(BCO <= 256, "bias staging is one 1 KiB LDS-DMA");
 
   const int tid = threadIdx.x;
@@ -181,6 +219,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[0]), 0, (int)p.src_bytes[0], 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[NSRC - 1]), 0, (int)p.src_bytes[NSRC - 1], 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * BCO * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X3 ? p.oscale : p.bias), 0, p.n_co_tiles * BCO * 4, 0x00020000);
 
   // ---- slice constants -> LDS (one thread per slice) -------------------------------------------
   for (int s = tid; s < p.n_slices; s += NT) {
@@ -220,6 +259,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // this tile's biases -> LDS by one LDS-DMA (wave 0), consumed only in the epilogue: the load is never waited for
   if (wave == 0)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16,
+                                             (int)(lane * 4 < BCO ? (uint32_t)(co0 + lane * 4) * 4u : kInvalidOff), 0, 0, 0);
+  if (X3 && wave == 1)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_ptr_t)(bias_lds + 1024), 16,
                                              (int)(lane * 4 < BCO ? (uint32_t)(co0 + lane * 4) * 4u : kInvalidOff), 0, 0, 0);
 
   // ---- per-thread row state -------------------------------------------------------------
@@ -347,7 +389,57 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   // fragment reads and the issue slots of the next LDS-DMA.  Without it every wave leaves the barrier with empty
   // fragment registers and the matrix cores idle until the first ds_reads return (all waves in lock step).
   constexpr bool XB = MT == 32 || WCO * WPX == 4;
-  if constexpr (XB) {
+  if constexpr (X3) {
+    // Split-product loop: a ring step holds KB / 64 sub-steps of K = 16.  Per sub-step a lane reads its weight fragments
+    // ready-made (hi: chunk 4m + h, lo: chunk 4m + 2 + h of the row) and two fp32 chunks of every pixel fragment
+    // (k = 16m + 8h .. + 7, the same K order as the weight fragment), splits the latter in registers and issues
+    // three 32x32x16 fp16 MFMAs per tile pair.  One fragment set: with two waves per SIMD the partner's MFMAs cover
+    // this wave's reads and conversions.
+    static_assert(MT == 32, "the split product runs on 32x32x16 MFMAs");
+    constexpr int SUB = KB / 64;
+    int st_c = 0, st_i = NS - 1;
+    SliceMeta m = meta[sbase + (NS - 1 < T_ ? NS - 1 : 0) / HPS];
+    for (int t = 0; t < T_; ++t) {
+      const int nxt = t + NS - 1;
+      const bool more = nxt < T_;
+      if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* wt = smem + st_c * STAGE;
+      const char* xt = wt + BCO * KB;
+#pragma unroll
+      for (int mm = 0; mm < SUB; ++mm) {
+        // pixel fragments one at a time (raw fp32 of fragment j + 1 in flight under the MFMAs of fragment j): the split
+        // needs 16 registers per fragment on top of the 128 accumulators, so only two fragments are ever live
+        u32x4 ah[TCO], al[TCO], r0[2], r1[2];
+        auto read_b = [&](int j, int slot) {
+          const int row = (wpx * TPX + j) * MT + fr;
+          r0[slot] = *reinterpret_cast<const u32x4*>(xt + swz<KB>(row, 4 * mm + 2 * fh));
+          r1[slot] = *reinterpret_cast<const u32x4*>(xt + swz<KB>(row, 4 * mm + 2 * fh + 1));
+        };
+        read_b(0, 0);
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+          const int row = (wco * TCO + i) * MT + fr;
+          ah[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>(row, 4 * mm + fh));
+          al[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>(row, 4 * mm + 2 + fh));
+        }
+        if (mm == 0 && more) issue_w(nxt, st_i);
+        if (mm == SUB - 1 && more) issue_x(nxt, m, st_i);
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+          if (j + 1 < TPX) read_b(j + 1, (j + 1) & 1);
+          u32x4 bh, bl;
+          okp_split8(r0[j & 1], r1[j & 1], bh, bl);
+#pragma unroll
+          for (int i = 0; i < TCO; ++i) Mma<F32S, 32>::run3(ah[i], al[i], bh, bl, acc[i][j]);
+        }
+      }
+      m = meta[sbase + (nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];
+      st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+      st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+    }
+  } else if constexpr (XB) {
     auto mma_half = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX], auto half) {     // first / second half of the rows
       constexpr int I0 = decltype(half)::value ? (TCO + 1) / 2 : 0;
       constexpr int I1 = decltype(half)::value ? TCO : (TCO + 1) / 2;
@@ -462,6 +554,8 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
           // accumulator rows: 32x32 -> 8g + 4*(lane>>5) + e ; 16x16 -> 4*(lane>>4) + e  (4 consecutive channels per lane)
           const int co_l = (wco * TCO + i) * MT + (MT == 32 ? 8 * g + 4 * fh : 4 * fh);
           const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + co_l * 4);
+          f32x4 sv = {1.f, 1.f, 1.f, 1.f};
+          if constexpr (X3) sv = *reinterpret_cast<const f32x4*>(bias_lds + 1024 + co_l * 4);
 #pragma unroll
           for (int j = 0; j < TPX; ++j) {
             const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * MT + fr;
@@ -474,7 +568,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
             } else {
               f32x4 v;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+              for (int e = 0; e < 4; ++e) v[e] = X3 ? __builtin_fmaf(acc[i][j][4 * g + e], sv[e], bv[e]) : acc[i][j][4 * g + e] + bv[e];
               *reinterpret_cast<f32x4*>(dst) = v;
             }
           }

@@ -68,7 +68,7 @@ template <typename T> __device__ __forceinline__ uint32_t okp_pack2(float a, flo
   v[0] = (T)a; v[1] = (T)b;
   return __builtin_bit_cast(uint32_t, v);
 }
-inline int okp_esz(int dtype) { return dtype == OKP_F32 ? 4 : 2; }
+inline int okp_esz(int dtype) { return (dtype == OKP_F32 || dtype == OKP_F32X3) ? 4 : 2; }
 inline bool okp_is16(int dtype) { return dtype == OKP_BF16 || dtype == OKP_F16; }
 
 // One K-slice of the implicit GEMM = 128 bytes of K per row (64 bf16 / 32 fp32):
@@ -105,6 +105,7 @@ struct OkpIgemmParams {
   uint32_t w_bytes;
   int32_t cout_pad;
   const float* bias;       // [cout_pad]
+  const float* oscale;     // OKP_F32X3: per-output-channel factor applied to the accumulator before the bias (NULL otherwise)
   const OkpSlice* slices;
   int32_t n_slices;
   int32_t n_taps;
@@ -194,6 +195,7 @@ struct okp_conv {
   void* weights_dev;
   uint32_t w_bytes;
   float* bias_dev;
+  float* oscale_dev;       // OKP_F32X3 plans: 1 / (power-of-two scale the channel's weights were multiplied with before the fp16 split)
   OkpSlice* slices_dev;
   // patch-resident kernel (okp_igemm_patch.hip): step table + per-source patch geometry, or patch_steps_dev == NULL
   OkpPatchStep* patch_steps_dev;

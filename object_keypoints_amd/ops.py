@@ -10,10 +10,43 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import OKP_BF16, OKP_F16, OKP_F32, ACT_NONE, ACT_RELU, ACT_SIGMOID, OkpError
+from ._lib import OKP_BF16, OKP_F16, OKP_F32, OKP_F32X3, ACT_NONE, ACT_RELU, ACT_SIGMOID, OkpError
 
 _DTYPES = {torch.float32: OKP_F32, torch.bfloat16: OKP_BF16, torch.float16: OKP_F16}
 HALF_DTYPES = (torch.bfloat16, torch.float16)     # 16-bit activations / weights, fp32 accumulate: the MFMA throughput precisions
+
+
+# "float32x3": fp32 tensors everywhere, but the convolution plans multiply on the fp16 matrix pipe as a three-term split of the
+# fp32 operands (OKP_F32X3, include/okp.h): fp32-grade results at a multiple of the exact-fp32 kernels' speed.  The mode is a property
+# of a PLAN (chosen when the plan is built); activations are plain torch.float32 tensors in both fp32 modes.
+F32X3 = "float32x3"
+F32_SPLIT = False       # plans built for torch.float32 while this is set are OKP_F32X3 plans (see f32_split())
+
+
+class f32_split:
+    """Context manager: convolution plans built inside are split-product plans (KeypointNet(compute_dtype=ops.F32X3) wraps its passes in it)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global F32_SPLIT
+        self.prev, F32_SPLIT = F32_SPLIT, self.enabled
+
+    def __exit__(self, *exc):
+        global F32_SPLIT
+        F32_SPLIT = self.prev
+
+
+def parse_compute_dtype(compute_dtype):
+    """-> (torch dtype of the activations, split-product flag) for torch.float32 / bfloat16 / float16 or ops.F32X3."""
+    if isinstance(compute_dtype, str):
+        if compute_dtype.lower() in (F32X3, "f32x3"):
+            return torch.float32, True
+        compute_dtype = getattr(torch, compute_dtype, compute_dtype)
+    if compute_dtype not in _DTYPES:
+        raise OkpError(f"unsupported compute dtype {compute_dtype}; use torch.float32, torch.bfloat16, torch.float16 or '{F32X3}'")
+    return compute_dtype, False
 
 
 def okp_dtype(torch_dtype):
@@ -103,6 +136,7 @@ class ConvPlan:
     def __init__(self, dtype, cins, strides, cout, taps, bias=None, relu=False, alg_k=None):
         L = _lib.lib()
         self.dtype = dtype
+        self.split = bool(F32_SPLIT and dtype == torch.float32)      # OKP_F32X3: fp32 tensors, products on the fp16 matrix pipe
         self.cout = cout
         self.n_src = len(cins)
         self.cins = list(cins)
@@ -125,7 +159,7 @@ class ConvPlan:
                 raise OkpError("bias shape")
         cin_arr = (ctypes.c_int32 * 2)(*(list(cins) + [0])[:2])
         st_arr = (ctypes.c_int32 * 2)(*(list(strides) + [1])[:2])
-        self._h = L.okp_conv_create(okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t,
+        self._h = L.okp_conv_create(OKP_F32X3 if self.split else okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t,
                                     b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if b is not None else None,
                                     ACT_RELU if relu else ACT_NONE)
         if not self._h:

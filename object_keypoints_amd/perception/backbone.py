@@ -72,6 +72,7 @@ class _HipModule(nn.Module):
     def _plan(self, key, build):
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
+        key = (key, ops.F32_SPLIT)          # fp32 plans exist in two forms: exact fp32 MFMAs / split products (ops.F32X3)
         p = self._plans.get(key)
         if p is None:
             p = build()

@@ -81,7 +81,10 @@ class KeypointNet(_HipModule):
 
     `compute_dtype` selects the activation/weight precision of the HIP path: torch.float32
     (parity configuration), torch.bfloat16 or torch.float16 (MFMA throughput configurations, fp32 accumulate;
-    float16 keeps three more mantissa bits than bfloat16 at the same rate, with a range of +-65504).
+    float16 keeps three more mantissa bits than bfloat16 at the same rate, with a range of +-65504), or
+    `ops.F32X3` ("float32x3"): fp32 tensors like torch.float32, every convolution product as a three-term fp16 split on
+    the fp16 matrix pipe - the reference's fp32 tolerances hold (measured heat error 3e-6) at a multiple of the fp32
+    configuration's speed; activations must stay below 65504 in magnitude.
     """
 
     def __init__(self, output_size=None, features=128, heatmaps_out=2, dropout=0.1, compute_dtype=torch.float32):
@@ -93,7 +96,7 @@ class KeypointNet(_HipModule):
         self.dropout = nn.Dropout(p=dropout)       # identity in eval mode; kept for the interface
         self.features = features
         self.heatmaps_out = heatmaps_out
-        self.compute_dtype = compute_dtype
+        self.compute_dtype, self.mfma_split = ops.parse_compute_dtype(compute_dtype)
         # uint8 frames of any other size are resized (shortest side) and centre-cropped to this size on the device, as the
         # reference's data path does (perception/datasets/video.py:63-69,95-96); None = uint8 frames are taken as they are
         self.raw_frame_size = 511
@@ -116,6 +119,10 @@ class KeypointNet(_HipModule):
         return l1, l2, torch.from_numpy(w3).to(device), torch.from_numpy(b3).to(device)
 
     def _run_heads(self, stack, cnv, sigmoid):
+        with ops.f32_split(self.mfma_split):
+            return self._run_heads_(stack, cnv, sigmoid)
+
+    def _run_heads_(self, stack, cnv, sigmoid):
         l1, l2, w3, b3 = self._plan(("heads", stack, cnv.dtype), lambda: self._build_heads(stack, cnv.dtype, cnv.t.device))
         K = self.heatmaps_out
         n, h, w = cnv.n, cnv.h, cnv.w
@@ -136,6 +143,10 @@ class KeypointNet(_HipModule):
         return heat, depth, centers.reshape(n, K - 1, 2, h, w)
 
     def _features(self, x):
+        with ops.f32_split(self.mfma_split):
+            return self._features_(x)
+
+    def _features_(self, x):
         ops.require_cuda(x, "frames")
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from object_keypoints_amd import ops, synth
 from object_keypoints_amd.perception.models import KeypointNet
-dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": ops.F32X3}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ops.SIDE_STREAMS = False
 net = KeypointNet(features=128, heatmaps_out=3, compute_dtype=dtype)
@@ -31,7 +31,7 @@ REP = 5
 for _ in range(REP): net.deployed(x)
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-esz = 2 if dtype == torch.bfloat16 else 4
+esz = 2 if dtype in (torch.bfloat16, torch.float16) else 4
 for cins, cout, k, (nn, ho, wo, dw, res, ncls), tile, macs, e0, e1 in h.rec:
     key = (cins, cout, k, ho, wo, dw, res, ncls, tile)
     a = agg.setdefault(key, [0, 0.0, macs])

@@ -1,0 +1,181 @@
+"""TEST INFRASTRUCTURE (CPU): rounding-point emulation of the HIP network on top of the oracle's weights.
+
+The HIP path differs from the fp32 reference only in WHERE values are rounded to a 16-bit type: the BN-folded
+weights of every MFMA convolution, and every activation tensor a kernel stores (= the next kernel's MFMA operand).
+Products of two 16-bit values are exact in fp32 and the MFMA accumulates in fp32, so an fp32 CPU convolution on
+rounded operands reproduces the device arithmetic up to summation order (1e-6).  That makes precision questions
+answerable without a GPU: `EmuNet.forward(x, policy)` runs the deployed network with `policy.act(name, t)` applied to
+every stored tensor and `policy.weight(name, w)` to every folded MFMA weight.  Used by attribute.py (which tensor / which
+layer's weights the 16-bit error comes from) and by tests/test_precision_emulation.py (the mixed-precision
+configuration of object_keypoints_amd keeps exactly the tensors in fp32 that this model says it must).
+
+Reference arithmetic restated: oracle/net.py (itself pinned to the reference); the fusion / folding points follow
+object_keypoints_amd/perception/backbone.py and models.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def rnd(t, dtype):
+    return t if dtype is None else t.to(dtype).to(torch.float32)
+
+
+class Policy:
+    """dtype per rounding point.  `acts` / `weights`: dict name -> torch dtype or None (keep fp32); `default` applies to
+    names that are in neither dict.  Names are the module paths of oracle.net.KeypointNet ("backbone.pre.1", ...) with
+    the suffixes below for tensors inside a fused block."""
+
+    def __init__(self, default=None, acts=None, weights=None, x3=False):
+        self.default, self.acts, self.weights = default, dict(acts or {}), dict(weights or {})
+        self.seen_acts, self.seen_weights = [], []
+        self.x3 = x3                    # MFMA products as the three-term fp16 split of fp32 operands (activations stay fp32)
+
+    def conv(self, x, w, b, fn=F.conv2d, **kw):
+        return conv_x3(x, w, b, fn, **kw) if self.x3 else fn(x, w, b, **kw)
+
+    def act(self, name, t):
+        if name not in self.seen_acts:
+            self.seen_acts.append(name)
+        return rnd(t, self.acts.get(name, self.default))
+
+    def weight(self, name, w):
+        if name not in self.seen_weights:
+            self.seen_weights.append(name)
+        return rnd(w, self.weights.get(name, self.default))
+
+
+def split16(t, dtype=torch.float16):
+    """fp32 -> (hi, lo) with hi = round16(t), lo = round16(t - hi), both returned as fp32 values."""
+    hi = t.to(dtype).to(torch.float32)
+    lo = (t - hi).to(dtype).to(torch.float32)
+    return hi, lo
+
+
+def conv_x3(x, w, b, fn=F.conv2d, **kw):
+    """The f32x3 product of the HIP path (okp_igemm_kernel, OKP_F32X3): fp32 operands split into fp16 hi + lo halves,
+    hi*hi + lo*hi + hi*lo on the fp16 MFMA with fp32 accumulation (lo*lo, 2^-22 relative, is dropped)."""
+    xh, xl = split16(x)
+    wh, wl = split16(w)
+    return fn(xh, wh, b, **kw) + fn(xl, wh, None, **kw) + fn(xh, wl, None, **kw)
+
+
+def _fold(w, bn, prefix, sd, conv_bias=None):
+    w = w.double()
+    if bn is not None:
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+        shift = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+    else:
+        scale, shift = torch.ones(w.shape[0], dtype=torch.float64), torch.zeros(w.shape[0], dtype=torch.float64)
+    b = shift if conv_bias is None else shift + conv_bias.double() * scale
+    return (w * scale.view(-1, 1, 1, 1)).float(), b.float()
+
+
+class EmuNet:
+    def __init__(self, net):
+        """net: oracle.net.KeypointNet in eval mode."""
+        self.sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        self.K = self.sd["heatmap_head.output_head2.2.weight"].shape[0]
+
+    # ---- blocks --------------------------------------------------------------------------------------------
+    def _conv(self, p, name, x, stride=1, relu=True, bn="bn", conv="conv", res=None):
+        sd = self.sd
+        w, b = _fold(sd[f"{name}.{conv}.weight"], f"{name}.{bn}" if bn else None, name, sd, sd.get(f"{name}.{conv}.bias"))
+        w = p.weight(f"{name}.{conv}", w)
+        y = p.conv(x, w, b, stride=stride, padding=(w.shape[2] - 1) // 2)
+        if res is not None:
+            y = y + res
+        return F.relu(y) if relu else y
+
+    def _residual(self, p, name, x, stride):
+        sd = self.sd
+        w1, b1 = _fold(sd[f"{name}.conv1.weight"], f"{name}.bn1", name, sd)
+        t = p.act(f"{name}.t", F.relu(p.conv(x, p.weight(f"{name}.conv1", w1), b1, stride=stride, padding=1)))
+        w2, b2 = _fold(sd[f"{name}.conv2.weight"], f"{name}.bn2", name, sd)
+        y = p.conv(t, p.weight(f"{name}.conv2", w2), b2, padding=1)
+        if f"{name}.skip.0.weight" in sd:
+            ws, bs = _fold(sd[f"{name}.skip.0.weight"], f"{name}.skip.1", name, sd)
+            y = y + p.conv(x, p.weight(f"{name}.skip", ws), bs, stride=stride)
+        else:
+            y = y + x
+        return p.act(name, F.relu(y))
+
+    def _fire(self, p, name, x, stride, skip):
+        sd = self.sd
+        w1, b1 = _fold(sd[f"{name}.conv1.weight"], f"{name}.bn1", name, sd)
+        s = p.act(f"{name}.s", p.conv(x, p.weight(f"{name}.conv1", w1), b1))
+        half = sd[f"{name}.conv_1x1.weight"].shape[0]
+        scale2 = sd[f"{name}.bn2.weight"].double() / torch.sqrt(sd[f"{name}.bn2.running_var"].double() + 1e-5)
+        shift2 = (sd[f"{name}.bn2.bias"].double() - sd[f"{name}.bn2.running_mean"].double() * scale2).float()
+        wa = (sd[f"{name}.conv_1x1.weight"].double() * scale2[:half].view(-1, 1, 1, 1)).float()
+        wd = (sd[f"{name}.conv_3x3.weight"].double() * scale2[half:].view(-1, 1, 1, 1)).float()     # depth-wise: fp32 weights on the vector ALUs
+        ya = p.conv(s, p.weight(f"{name}.conv_1x1", wa), shift2[:half], stride=stride)
+        yd = F.conv2d(s, wd, shift2[half:], stride=stride, padding=1, groups=s.shape[1])
+        y = torch.cat([ya, yd], dim=1)
+        if skip:
+            y = y + x
+        return p.act(name, F.relu(y))
+
+    def _fires(self, p, name, x, dims, first_stride=1):
+        for i, (a, b) in enumerate(dims):
+            st = first_stride if i == 0 else 1
+            x = self._fire(p, f"{name}.{i}", x, st, st == 1 and a == b)
+        return x
+
+    def _hg_module(self, p, name, x, n, dims, modules):
+        cur, nxt = dims[0], dims[1]
+        up1 = self._fires(p, f"{name}.up1", x, [(cur, cur)] * modules[0])
+        low1 = self._fires(p, f"{name}.low1", x, [(cur, nxt)] + [(nxt, nxt)] * (modules[0] - 1), first_stride=2)
+        if n > 1:
+            low2 = self._hg_module(p, f"{name}.low2", low1, n - 1, dims[1:], modules[1:])
+        else:
+            low2 = self._fires(p, f"{name}.low2", low1, [(nxt, nxt)] * modules[1])
+        low3 = self._fires(p, f"{name}.low3", low2, [(nxt, nxt)] * (modules[0] - 1) + [(nxt, cur)])
+        w = p.weight(f"{name}.up2", self.sd[f"{name}.up2.weight"])
+        y = p.conv(low3, w, self.sd[f"{name}.up2.bias"], fn=F.conv_transpose2d, stride=2, padding=1) + up1
+        return p.act(name, y)
+
+    def _head(self, p, name, x, sigmoid):
+        sd = self.sd
+        w1, b1 = _fold(sd[f"{name}.0.conv.weight"], f"{name}.0.bn", name, sd)
+        h1 = p.act(f"{name}.h1", F.relu(p.conv(x, p.weight(f"{name}.0", w1), b1)))
+        w2, b2 = _fold(sd[f"{name}.1.conv.weight"], f"{name}.1.bn", name, sd)
+        h2 = p.act(f"{name}.h2", F.relu(p.conv(h1, p.weight(f"{name}.1", w2), b2)))
+        y = F.conv2d(h2, sd[f"{name}.2.weight"], sd[f"{name}.2.bias"])          # last 1x1: fp32 weights on the vector ALUs
+        return torch.sigmoid(y) if sigmoid else y
+
+    # ---- whole network (deployed wrapper: stack-2 heads, sigmoid on the heat map) -----------------------------
+    def forward(self, x, p, want_logits=False):
+        DIMS, MODS = [256, 256, 384, 384, 512], [2, 2, 2, 2, 4]
+        with torch.no_grad():
+            x = p.act("frames", x)
+            inter = p.act("backbone.pre.0", self._conv(p, "backbone.pre.0", x, stride=2))
+            inter = self._residual(p, "backbone.pre.1", inter, 2)
+            inter = self._residual(p, "backbone.pre.2", inter, 2)
+            cnv = None
+            for i in range(2):
+                h = self._hg_module(p, f"backbone.hgs.{i}", inter, 4, DIMS, MODS)
+                cnv = p.act(f"backbone.cnvs.{i}", self._conv(p, f"backbone.cnvs.{i}", h))
+                if i == 0:
+                    sd = self.sd
+                    wa, ba = _fold(sd["backbone.inters_.0.0.weight"], "backbone.inters_.0.1", "", sd)
+                    wb, bb = _fold(sd["backbone.cnvs_.0.0.weight"], "backbone.cnvs_.0.1", "", sd)
+                    m = p.conv(inter, p.weight("backbone.inters_.0", wa), ba) + p.conv(cnv, p.weight("backbone.cnvs_.0", wb), bb)
+                    merged = p.act("backbone.merge.0", F.relu(m))
+                    inter = self._residual(p, "backbone.inters.0", merged, 1)
+            heat = self._head(p, "heatmap_head.output_head2", cnv, not want_logits)
+            depth = self._head(p, "depth_head.output_head2", cnv, False)
+            centers = self._head(p, "center_head.output_head2", cnv, False)
+            n, _, hh, ww = centers.shape
+            return heat, depth, centers.reshape(n, self.K - 1, 2, hh, ww)
+
+
+def build(heatmaps_out=3, weight_seed=0):
+    import os
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from oracle import net as onet
+    net = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=heatmaps_out), seed=weight_seed)
+    return net, EmuNet(net)

@@ -1,0 +1,190 @@
+"""The split-product configuration (ops.F32X3 / OKP_F32X3: fp32 tensors, every convolution product as a three-term fp16
+split on the fp16 matrix pipe) against the same references and with the same ABSOLUTE bounds as the exact-fp32
+configuration: plain PyTorch fp32 convolutions on the CPU, the reference's golden block and whole-network outputs
+(north_star: heat maps within 1e-3, peak indices bit-exact), plus the cases the split itself adds - operands whose low
+halves are fp16 subnormals, and the exact-fp32 kernel as a second checker."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed):
+    from object_keypoints_amd import synth
+    return torch.from_numpy(synth.normal_like(f"x3test{seed}", shape, seed))
+
+
+def _tol(ref):
+    """The fp32 kernels' own bound (tests/test_gpu_conv.py): accumulation-order noise.  The split keeps 22 significant bits
+    per operand, so it has to meet it too."""
+    return 2e-4 + 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("k,stride,cin,cout,n,h,w", [
+    (3, 1, 64, 256, 2, 20, 24),     # many K slices, several co tiles
+    (3, 2, 32, 64, 3, 17, 15),      # stride 2, odd sizes
+    (1, 1, 192, 96, 2, 9, 7),       # 1x1, cout not a multiple of 64
+    (1, 2, 16, 8, 1, 8, 8),         # partial K slice
+    (3, 1, 8, 16, 1, 5, 5),         # one partial slice per tap
+    (1, 1, 256, 256, 4, 32, 32),    # a whole 256 x 256 tile per workgroup, several tiles
+])
+def test_split_conv_matches_torch_fp32(tile, k, stride, cin, cout, n, h, w):
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps, conv_out_size
+    dev = torch.device("cuda:0")
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2) * (1.0 / np.sqrt(cin * k * k))
+    b = _rand((cout,), 3) * 0.1
+    pad = (k - 1) // 2
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)).float()
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [cin], [stride], cout, conv_taps(wt.numpy()), b.numpy(), relu=True)
+    assert plan.split
+    xa = ops.Act.from_nchw(x.to(dev), torch.float32)
+    ho, wo = conv_out_size(h, k, stride, pad), conv_out_size(w, k, stride, pad)
+    out = ops.Act.empty(n, ho, wo, cout, torch.float32, dev)
+    plan([xa], out, ho, wo, tile=tile)
+    got = out.to_nchw().cpu()
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref), f"max err {err}"
+    # ... and far inside what a single fp16 rounding of the operands would give (2^-11 relative per product)
+    assert err <= 2e-5 * (1.0 + float(ref.abs().max())), f"max err {err}: the low halves are not being used"
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-3, 1.0), (1.0, 1e-3), (3e-2, 3e-2), (200.0, 0.5), (1e-4, 1e-4)])
+def test_split_conv_with_subnormal_low_halves(xs, ws):
+    """Operands below 0.12 have low halves in the fp16 subnormal range (scripts/hwtests/mfma_f16_denorm.hip: the matrix pipe
+    keeps them).  Relative accuracy must not depend on the operands' scale down to where the low halves vanish
+    (|x| ~ 1e-4: the product is then a plain fp16 product of tiny numbers, whose absolute error is far below any bound)."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = torch.device("cuda:0")
+    n, cin, cout, h, w = 2, 128, 64, 12, 12
+    x = _rand((n, cin, h, w), 21) * xs
+    wt = _rand((cout, cin, 3, 3), 22) * (ws / np.sqrt(cin * 9))
+    ref = F.conv2d(x.double(), wt.double(), padding=1).float()
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [cin], [1], cout, conv_taps(wt.numpy()), None, relu=False)
+    out = ops.Act.empty(n, h, w, cout, torch.float32, dev)
+    plan([ops.Act.from_nchw(x.to(dev), torch.float32)], out, h, w)
+    err = float((out.to_nchw().cpu() - ref).abs().max())
+    scale = float(ref.abs().max())
+    # weights: scaled per output channel at plan creation, so their magnitude does not matter.  Activations: the low half of a
+    # value below 0.12 is an fp16 subnormal (quantum 6e-8): an absolute floor of 3e-8 per element, i.e. ~1e-7 * |w| per output
+    assert err <= 3e-6 * scale + 2e-7 * ws, f"max err {err} at scale {scale}"
+
+
+def test_split_two_source_residual_and_subpixel_classes():
+    """The fused forms of the network in split mode: conv2 + projected skip (two sources), residual epilogue, and the four
+    sub-pixel classes of the transposed convolution."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps, unpool_merge
+    dev = torch.device("cuda:0")
+    n, c0, c1, cout, h, w = 2, 32, 16, 64, 10, 12
+    t = _rand((n, c0, h, w), 4); x = _rand((n, c1, 2 * h, 2 * w), 5); r = _rand((n, cout, h, w), 9)
+    w2 = _rand((cout, c0, 3, 3), 6) / np.sqrt(c0 * 9); ws = _rand((cout, c1, 1, 1), 7) / np.sqrt(c1)
+    b = _rand((cout,), 8) * 0.1
+    ref = F.relu(F.conv2d(t, w2, b, padding=1) + F.conv2d(x, ws, stride=2) + r)
+    taps = conv_taps(w2.numpy()) + [(1, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))]
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [c0, c1], [1, 2], cout, taps, b.numpy(), relu=True)
+    out = ops.Act.empty(n, h, w, cout, torch.float32, dev)
+    f32 = torch.float32
+    plan([ops.Act.from_nchw(t.to(dev), f32), ops.Act.from_nchw(x.to(dev), f32)], out, h, w, res=ops.Act.from_nchw(r.to(dev), f32))
+    assert float((out.to_nchw().cpu() - ref).abs().max()) <= _tol(ref)
+
+    c = 16
+    m = unpool_merge(c).eval()
+    with torch.no_grad():
+        m.weight.copy_(_rand((c, c, 4, 4), 12) / np.sqrt(4 * c)); m.bias.copy_(_rand((c,), 13) * 0.1)
+    low = _rand((n, c, 5, 7), 14); up1 = _rand((n, c, 10, 14), 15)
+    ref = up1 + F.conv_transpose2d(low, m.weight.detach(), m.bias.detach(), stride=2, padding=1)
+    with ops.f32_split():
+        got = m(ops.Act.from_nchw(low.to(dev), f32), ops.Act.from_nchw(up1.to(dev), f32)).to_nchw().cpu()
+    assert float((got - ref).abs().max()) <= _tol(ref)
+
+
+@pytest.mark.parametrize("name", sorted(cases.BLOCK_CASES))
+def test_block_split_matches_reference_golden(name):
+    """Every block golden of the reference, with the fp32 configuration's bounds (tests/test_gpu_blocks.py)."""
+    import test_gpu_blocks as tb
+    from object_keypoints_amd import ops
+    with ops.f32_split():
+        got = tb._run(name, torch.float32)
+    ref = gu.golden_blocks()[name]
+    err = np.abs(got - ref).max()
+    assert err <= 1e-3 and err <= 2e-4 * max(1.0, np.abs(ref).max()), f"{name}: max |err| {err}"
+
+
+def _net(case, compute_dtype):
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception.models import KeypointNet
+    net = KeypointNet(features=128, heatmaps_out=case["heatmaps_out"], compute_dtype=compute_dtype)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    vals = synth.fill_state_dict(shapes, seed=case["weight_seed"])
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in vals.items()})
+    return net.eval().cuda()
+
+
+@pytest.mark.parametrize("name", sorted(cases.NET_CASES))
+def test_split_network_meets_the_fp32_bars(name):
+    """Whole network in split mode against the reference's golden outputs: the north_star tolerances, absolute -
+    heat maps within 1e-3 (measured 3e-6), the peak index sets of the heat maps IDENTICAL to those of the golden maps,
+    3D points at those peaks within 1e-4 m."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    import os
+    case = cases.NET_CASES[name]
+    net = _net(case, ops.F32X3)
+    assert net.mfma_split and net.compute_dtype == torch.float32
+    x = torch.from_numpy(synth.frames(1, seed=case["frame_seed"], start=case["frame_index"])).cuda()
+    ops.COUNTERS["macs"] = 0
+    heat, depth, centers = net.deployed(x)
+    g = gu.golden_net(name)
+    e_heat = np.abs(heat.cpu().numpy() - g["heat"]).max()
+    e_depth = np.abs(depth.cpu().numpy() - g["depth"]).max()
+    e_cent = np.abs(centers.cpu().numpy() - g["centers"]).max()
+    print(f"{name} f32x3: heat err {e_heat:.2e} depth err {e_depth:.2e} centers err {e_cent:.2e}")
+    assert e_heat <= 1e-3 and e_heat <= 5e-5                  # north_star bar; and fp32-grade, not fp16-grade (2e-3)
+    assert e_depth <= 1e-4 * max(1.0, np.abs(g["depth"]).max())
+    assert e_cent <= 1e-4 * max(1.0, np.abs(g["centers"]).max())
+    if case["heatmaps_out"] == 3:
+        assert ops.COUNTERS["macs"] == 37_282_609_152
+    count, yx, xyc = ops.peak_nms(heat, cap=4096)
+    gcount, gyx, gxyc = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
+    assert torch.equal(count, gcount)
+    for k in range(heat.shape[1]):
+        c = int(count[0, k])
+        assert torch.equal(yx[0, k, :c], gyx[0, k, :c])        # bit-exact peak indices
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p_ = cu.load_calibration_params(os.path.join(repo, "config", "calibration.yaml"))
+    cam = cu.FisheyeCamera(p_["K"], p_["D"], p_["image_size"]).scale(511 / 720)
+    cam = cam.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511).okp()
+    pts = ops.lift_peaks(cam, count, xyc, depth, 63, 63).cpu().numpy()
+    gpts = ops.lift_peaks(cam, gcount, gxyc, torch.from_numpy(g["depth"]).cuda(), 63, 63).cpu().numpy()
+    worst = 0.0
+    for k in range(heat.shape[1]):
+        c = int(count[0, k])
+        worst = max(worst, float(np.abs(pts[0, k, :c, :3] - gpts[0, k, :c, :3]).max()))
+    print(f"{name} f32x3: 3D points max |err| {worst:.2e} m")
+    assert worst <= 1e-4                                       # north_star: triangulated / lifted 3D points within 1e-4 m
+
+
+def test_split_network_equals_exact_fp32_network_closely_and_is_deterministic():
+    from object_keypoints_amd import ops, synth
+    case = cases.NET_CASES["valve_k3"]
+    x = torch.from_numpy(synth.frames(3, seed=5)).cuda()
+    a = _net(case, ops.F32X3).deployed(x)
+    b = _net(case, torch.float32).deployed(x)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 5e-5 * max(1.0, float(v.abs().max()))
+    net = _net(case, ops.F32X3)
+    h3 = net.deployed(x)[0]
+    assert torch.equal(h3, net.deployed(x)[0])                 # run to run
+    assert torch.equal(h3[1:2], net.deployed(x[1:2])[0])       # frames are independent: same bits at any batch
