@@ -36,7 +36,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 GFLOP_PER_FRAME = 74.565218304          # 37 282 609 152 MACs x 2 (deployed path, K=3)
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x3": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# f32x3 (ops.F32X3): fp32 tensors, every product as three fp16 MFMA terms.  `achieved` counts the ALGORITHMIC FLOPs once, the peak is
+# the fp16 pipe's: a perfect kernel of this kind would read frac = 1/3 (roofline.mfma_terms says so in the line).
 ERR_FRAMES = 4                          # frames of the cpu_baseline sample on which every precision is compared with the oracle
 
 
@@ -46,8 +48,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16", help="precision of the headline line")
-    ap.add_argument("--extra-dtypes", default="f32,f16", help="N=1: further precisions reported as extra objects ('' = none)")
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32", "f32x3"], default="bf16", help="precision of the headline line")
+    ap.add_argument("--extra-dtypes", default="f32x3,f32,f16", help="N=1: further precisions reported as extra objects ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (tests)")
@@ -74,14 +76,37 @@ def needs_launcher(args, environ):
     return "WORLD_SIZE" not in environ and (args.gpus > 1 or args.spawn)
 
 
+def gpu_count_without_hip(environ=os.environ, sysfs="/sys/class/kfd/kfd/topology/nodes", dri="/dev/dri"):
+    """GPUs this process could use, counted WITHOUT the HIP / HSA runtime: the launcher parent forks + execs torchrun, and a
+    process that has initialised the GPU must not exec on this pool.  KFD topology nodes with SIMDs are GPUs (CPU nodes have
+    simd_count 0); /dev/dri/renderD* is the fall-back; *_VISIBLE_DEVICES lists cap the count."""
+    import glob
+    import re
+    n = 0
+    for path in glob.glob(os.path.join(sysfs, "*", "properties")):
+        try:
+            m = re.search(r"^simd_count\s+(\d+)", open(path).read(), re.M)
+        except OSError:
+            continue
+        n += 1 if m and int(m.group(1)) > 0 else 0
+    if n == 0:
+        n = len(glob.glob(os.path.join(dri, "renderD*")))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def self_launch(args, argv, device_count, popen=subprocess.Popen, out=sys.stdout, err=sys.stderr):
-    """Start the ranks as a child process, relay rank 0's JSON line, return the exit code.  `device_count` is
-    torch.cuda.device_count() (counting devices does not initialise the GPU)."""
+    """Start the ranks as a child process, relay rank 0's JSON line, return the exit code.  `device_count` comes from
+    gpu_count_without_hip(): this process never touches the HIP runtime."""
     if device_count < args.gpus:
         print(f"bench.py --gpus {args.gpus} needs {args.gpus} devices, {device_count} visible", file=err)
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("NCCL_DEBUG", "VERSION")               # one "RCCL version ..." line per run in the log (stderr)
     proc = popen(launcher_command(args, argv, free_port()), stdout=subprocess.PIPE, text=True, env=env)
     relayed = 0
     for line in proc.stdout:
@@ -135,14 +160,20 @@ class KernelTimer:
         return len(self.records), ms, flops
 
 
-def committed_counters(kernel_sig):
-    """Counter figures of the dominant kernel from the committed PMC passes of this same command (bench.py cannot run
-    the profiler on itself): HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950) and, when present, MFMA-busy / LDS-wait fractions from the SQ
-    pass (profiles/r*_sq_counters.json).  Null when absent."""
+def committed_counters(kernel_sig, precision="bf16"):
+    """Counter figures of the dominant kernel from the committed PMC passes of this same command at this precision (bench.py
+    cannot run the profiler on itself): HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and, when present, MFMA-busy / LDS-wait fractions from
+    the SQ pass.  Files: profiles/r*_pmc_hbm_traffic.json / r*_sq_counters.json for the bf16 headline,
+    profiles/r*_<precision>_pmc_hbm_traffic.json / ..._sq_counters.json for the others (scripts/profile_r03.sh).  Null when absent."""
     import glob
+    import re
     res = {"traffic": None, "traffic_source": None, "mfma_busy": None, "lds_wait": None, "hbm_GBps": None, "counter_source": None}
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))
+    tag = "" if precision == "bf16" else precision + "_"
+    pat = re.compile(r"^r\d+[a-z]*_" + tag + r"(pmc_hbm_traffic|sq_counters)\.json$")
+    def newest(kind):
+        return sorted(f for f in glob.glob(os.path.join(REPO, "profiles", f"r*_{tag}{kind}.json")) if pat.match(os.path.basename(f)))
+    files = newest("pmc_hbm_traffic")
     if files:
         with open(files[-1]) as f:
             data = json.load(f)
@@ -151,7 +182,7 @@ def committed_counters(kernel_sig):
                 res["traffic"] = (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6
                 res["traffic_source"] = os.path.basename(files[-1])
                 break
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_sq_counters.json")))
+    files = newest("sq_counters")
     if files:
         with open(files[-1]) as f:
             data = json.load(f)
@@ -228,10 +259,12 @@ def cpu_baseline(seconds):
             keep["heat"])
 
 
-TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32"}
-KERNEL_SIG = {"bf16": "okp_igemm_patch_kernel", "f16": "okp_igemm_patch_kernel", "f32": "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"}
+TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32"}
+OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3"}
+KERNEL_SIG = {"bf16": "okp_igemm_patch_kernel", "f16": "okp_igemm_patch_kernel", "f32": "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E",
+              "f32x3": "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"}
 KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
-               "f32": "okp_igemm_kernel<f32,256x256,src1>"}
+               "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>"}
 
 
 def bump_maps(start, count, dev, keypoint_config=(1, 3)):
@@ -252,18 +285,18 @@ def run_precision(name, ctx, steps, warmup):
     from object_keypoints_amd.perception.pipeline import BatchedKeypointPipeline
     dev, world, batch = ctx["dev"], ctx["world"], ctx["batch"]
     dtype = getattr(torch, TORCH_DTYPES[name])
-    net = build_net(dtype).to(dev)
+    net = build_net(ops.F32X3 if name == "f32x3" else dtype).to(dev)
     pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, ctx["camera"], capacity=64)
     frames = ctx["frames"]
     b_heat, b_depth, b_centers, n_peaks = ctx["bumps"]
     # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile
-    timer = KernelTimer(dtype, (3,) if name == "f32" else (13,), 1 if name == "f32" else None)
+    timer = KernelTimer(dtype, (3,) if name in ("f32", "f32x3") else (13,), 1 if name in ("f32", "f32x3") else None)
     ops.LAUNCH_HOOK = timer
 
     def step():
         net.deployed(frames)                                          # heat / depth / centre maps of the network (in full)
         out = pipe.postprocess_device(b_heat, b_depth, b_centers)     # peaks -> 3D -> objects on the injected scenes
-        return out, dist_.all_gather_keypoints(out["points"])
+        return out, dist_.all_gather_keypoints(out["points"], total_frames=batch * world)
 
     with torch.no_grad():
         for _ in range(warmup):
@@ -288,7 +321,7 @@ def run_precision(name, ctx, steps, warmup):
     n_launch, k_ms, k_flops = timer.summary()
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[name]
-    ctr = committed_counters(KERNEL_SIG[name]) if name != "f16" else committed_counters("\0")
+    ctr = committed_counters(KERNEL_SIG[name], name)
     res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
            "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
            "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[name], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -297,6 +330,8 @@ def run_precision(name, ctx, steps, warmup):
                         "hbm_GBps": ctr["hbm_GBps"], "counter_source": ctr["counter_source"],
                         "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
                         "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}}
+    if name == "f32x3":
+        res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
     del pipe, net
     torch.cuda.empty_cache()
     return res, sample_heat
@@ -356,15 +391,16 @@ def rank_main(args):
     if world == 1:
         for name in [d for d in args.extra_dtypes.split(",") if d and d != args.dtype]:
             # fp32 runs ~12x longer per step (157 TFLOP/s MFMA peak): fewer steps keep the default run within minutes
-            steps = max(3, args.steps // 10) if name == "f32" else max(5, args.steps // 2)
+            # (with the driver's --steps 20 every precision still times at least 10 steps)
+            steps = max(10, args.steps // 10) if name == "f32" else max(10, args.steps // (4 if name == "f32x3" else 2))
             res, extra_heat[name] = run_precision(name, ctx, steps, min(args.warmup, 2))
             res["workload"] = workload_string(args.batch, name, world)
-            result[{"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[name]] = res
+            result[OBJECT_KEY[name]] = res
     if with_cpu:
         result["cpu_baseline"], oracle_heat = cpu_baseline(args.cpu_seconds)
         result["heat_err_vs_oracle"] = heat_error(head_heat, oracle_heat)
         for name, h in extra_heat.items():
-            result[{"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[name]]["heat_err_vs_oracle"] = heat_error(h, oracle_heat)
+            result[OBJECT_KEY[name]]["heat_err_vs_oracle"] = heat_error(h, oracle_heat)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if torch.distributed.is_initialized():
@@ -375,8 +411,7 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if needs_launcher(args, os.environ):
-        import torch                                      # device_count() only: no HIP initialisation in the parent
-        return self_launch(args, argv, torch.cuda.device_count())
+        return self_launch(args, argv, gpu_count_without_hip())     # no torch import, no HIP call in the launcher parent
     rank_main(args)
     return 0
 

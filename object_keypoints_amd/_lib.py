@@ -135,8 +135,12 @@ def torch_ops():
         if os.environ.get("OKP_TORCH_OPS", "1") != "0" and os.path.exists(TORCH_LIB_PATH) and not os.environ.get("OKP_LIB"):
             lib()                                   # libokp_hip.so first (and torch's HIP runtime before it)
             import torch
-            torch.ops.load_library(TORCH_LIB_PATH)
-            _torch_ops = torch.ops.okp
+            try:
+                torch.ops.load_library(TORCH_LIB_PATH)
+                _torch_ops = torch.ops.okp
+            except (OSError, RuntimeError) as e:    # a shim built against another torch: fall back to ctypes, loudly
+                import warnings
+                warnings.warn(f"{TORCH_LIB_PATH} does not load ({e}); using the ctypes binding of libokp_hip.so")
     return _torch_ops
 
 

@@ -92,6 +92,9 @@ def build(force=False, verbose=False):
         results = list(ex.map(_compile, srcs))
     objs = [o for o, _, _ in results]
     rebuilt = any(r for _, r, _ in results)
+    for f in os.listdir(OBJ_DIR):                 # objects (and flag stamps) of sources that no longer exist
+        if f.endswith((".o", ".o.flags")) and os.path.join(OBJ_DIR, f.split(".o")[0] + ".o") not in objs:
+            os.remove(os.path.join(OBJ_DIR, f))
     if verbose:
         for _, _, err in results:
             if err.strip():
@@ -101,7 +104,12 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    build_torch_ops(verbose)
+    try:
+        build_torch_ops(verbose)
+    except Exception as e:        # the dispatcher shim is optional: the ctypes binding serves every launch without it
+        if os.path.exists(TORCH_LIB_PATH):
+            os.remove(TORCH_LIB_PATH)          # never leave a stale shim built against another torch / ABI
+        print(f"warning: libokp_torch.so (torch.ops.okp.*) not built, the ctypes binding will be used: {e}", file=sys.stderr)
     return LIB_PATH
 
 

@@ -19,7 +19,7 @@ int launch_tile(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStre
 int launch_tile_x3(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
     case 4: return launch_cfg<F32S, 128, 256, 2, 2, 3, 64>(plan, p, stream);
-    case 3: case 6: return launch_cfg<F32S, 256, 256, 4, 2, 2, 128>(plan, p, stream);
+    case 3: case 6: return launch_cfg<F32S, 256, 256, 2, 4, 2, 128>(plan, p, stream);   // 128 x 64 wave tiles: a wave splits two pixel fragments per four weight fragments
     case 2: return launch_cfg<F32S, 128, 128, 2, 2, 2, 128>(plan, p, stream);
     default: return launch_cfg<F32S, 64, 64, 2, 2, 4, 128>(plan, p, stream);
   }

@@ -39,16 +39,27 @@ static_assert(sizeof(F32S) == 4, "fp32 storage");
 
 // 8 fp32 of K held by a lane (two 16-byte chunks) -> its fp16 hi / lo fragments
 __device__ __forceinline__ void okp_split8(const u32x4& r0, const u32x4& r1, u32x4& hi, u32x4& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
   const f32x4 x0 = __builtin_bit_cast(f32x4, r0), x1 = __builtin_bit_cast(f32x4, r1);
-  f16x8 h, l;
+  // per pair of elements: v_cvt_pk_f16_f32 (hi), two v_fma_mix_f32 (x - hi, exact, reading the packed half directly), v_cvt_pk_f16_f32 (lo):
+  // 4 VALU instructions per 2 elements (hipcc's own lowering of the same arithmetic takes 6: cvt_pk, 2 cvt_f32_f16, 2 sub, cvt_pk)
+  f16x2 hp[4], lp[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 a = (_Float16)x0[e], b = (_Float16)x1[e];
-    h[e] = a; h[4 + e] = b;
-    l[e] = (_Float16)__builtin_fmaf((float)a, -1.0f, x0[e]); l[4 + e] = (_Float16)__builtin_fmaf((float)b, -1.0f, x1[e]);    // one v_fma_mix_f32 each
+  for (int q = 0; q < 4; ++q) {
+    const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+    f16x2 h2; h2[0] = (_Float16)xa; h2[1] = (_Float16)xb;
+    const uint32_t hw = __builtin_bit_cast(uint32_t, h2);
+    float da, db;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(da) : "v"(hw), "v"(xa));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(db) : "v"(hw), "v"(xb));
+    f16x2 l2; l2[0] = (_Float16)da; l2[1] = (_Float16)db;
+    hp[q] = h2; lp[q] = l2;
   }
-  hi = __builtin_bit_cast(u32x4, h);
-  lo = __builtin_bit_cast(u32x4, l);
+  hi = u32x4{__builtin_bit_cast(uint32_t, hp[0]), __builtin_bit_cast(uint32_t, hp[1]), __builtin_bit_cast(uint32_t, hp[2]), __builtin_bit_cast(uint32_t, hp[3])};
+  lo = u32x4{__builtin_bit_cast(uint32_t, lp[0]), __builtin_bit_cast(uint32_t, lp[1]), __builtin_bit_cast(uint32_t, lp[2]), __builtin_bit_cast(uint32_t, lp[3])};
+#else
+  hi = r0; lo = r1;
+#endif
 }
 
 template <typename T, int MT> struct Mma;
@@ -188,7 +199,8 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   static_assert(NS >= 2, "ring depth");
   constexpr int PASSES = (BPX * BCO * ESZ > LDS_BYTES) ? 2 : 1;   // epilogue staging holds the tile in the output type
   static_assert(RPP % 16 == 0, "loader swizzle assumes the pass height keeps (row>>1)&7");
-  static_assert(PASSES == 1 || WPX == 2, "two-pass epilogue splits pixels by wave column");
+  static_assert(WPX % PASSES == 0, "a two-pass epilogue splits the pixels by wave column");
+  constexpr int WPP = WPX / PASSES;           // wave columns staged per epilogue pass
   static_assert(BPX * BCO * ESZ / PASSES <= LDS_BYTES, "epilogue staging must fit");
   constexpr int PX_PER_PASS = BPX / PASSES;
   using x4_t = typename Vt<T>::x4;                 // 4 / 8 elements of the 16-bit types (unused for fp32)
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
   {
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
-    if (PASSES == 1 || wpx == pass) {
+    if (PASSES == 1 || wpx / WPP == pass) {
 #pragma unroll
       for (int i = 0; i < TCO; ++i) {
 #pragma unroll
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
           if constexpr (X3) sv = *reinterpret_cast<const f32x4*>(bias_lds + 1024 + co_l * 4);
 #pragma unroll
           for (int j = 0; j < TPX; ++j) {
-            const int prow = ((PASSES == 1 ? wpx * TPX : 0) + j) * MT + fr;
+            const int prow = ((wpx % WPP) * TPX + j) * MT + fr;
             char* dst = smem + prow * PITCH + ((((co_l * ESZ) >> 4) ^ (prow & 7)) << 4) + ((co_l * ESZ) & 15);
             if constexpr (ESZ == 2) {
               x4_t o;

@@ -16,10 +16,18 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def launched_by_torchrun():
+    """True under `python -m torch.distributed.run` (any world size): the rendezvous variables are all there."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world)."""
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world).
+    A process group is created whenever the process was started by torchrun - also at world size 1, so that a single-GPU
+    box exercises the same RCCL communicator set-up and the same collectives as the 8-GPU node; a plain `python` process
+    (no rendezvous variables) stays without one and the helpers below pass through."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or launched_by_torchrun()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -45,13 +53,18 @@ def all_gather_keypoints(points, total_frames=None):
     contiguous blocks of `shard`.  ONE collective.  `all_gather_into_tensor` needs the same shape on every rank:
     with `total_frames` given (the global frame count the blocks were cut from with `shard`) and not divisible by the
     world size, every rank pads its block with NaN rows (NaN = unused slot, as inside the payload) to the largest block
-    and the padding rows are dropped after the gather; without it the blocks must be equal (checked)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    and the padding rows are dropped after the gather.  `total_frames` is REQUIRED when more than one rank takes part: a rank
+    cannot know from its own block whether the others hold the same number of frames, and ranks that enter the collective
+    with different shapes hang or corrupt the output on RCCL."""
+    if not dist.is_initialized():
         return points
     world, rank = dist.get_world_size(), dist.get_rank()
     points = points.contiguous()
     if total_frames is None:
-        total_frames = world * points.shape[0]
+        if world > 1:
+            raise ValueError("all_gather_keypoints: total_frames (the global frame count the blocks were cut from with shard()) "
+                             "is required when world size > 1")
+        total_frames = points.shape[0]
     counts = [shard(total_frames, r, world)[1] for r in range(world)]
     if points.shape[0] != counts[rank]:
         raise ValueError(f"rank {rank} holds {points.shape[0]} frames, shard({total_frames}, {rank}, {world}) says {counts[rank]}; "
@@ -68,12 +81,12 @@ def all_gather_keypoints(points, total_frames=None):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

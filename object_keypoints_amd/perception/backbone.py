@@ -377,7 +377,9 @@ class hg_module(nn.Module):
         below.  A stream of its own per hg_module (eight of them, HIP deals streams round-robin onto its four hardware queues) put
         one of the side branches of the second hourglass on the MAIN stream's queue, i.e. back into the critical chain (step +0.7 %
         with the shared three; GPU_MAX_HW_QUEUES above its default of 4 costs 30 %, below it 1-5 %)."""
-        key = (device.type, device.index, min(4 - self.n, 2) if self.n <= 4 else 0)
+        # keyed by the MAIN stream as well: a pass that runs (or is being captured) on another stream - another host thread, a
+        # second pipeline's hipGraph capture - gets its own side streams instead of recording into a foreign capture
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, min(4 - self.n, 2) if self.n <= 4 else 0)
         st = _SIDE_STREAMS.get(key)
         if st is None:
             st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)

@@ -38,23 +38,72 @@ def _is_torchscript_archive(path):
     return any(n.endswith("/constants.pkl") for n in names) and any("/code/" in n for n in names)
 
 
-def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
-    """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
-    TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet."""
-    device = device or _device()
-    if isinstance(model, models.KeypointNet):
-        return model.to(device).eval()
-    if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
-        if _is_torchscript_archive(model):                   # scripts/package_model.py:40-42 saves a torch.jit.trace
-            sd = torch.jit.load(model, map_location="cpu").state_dict()
-        else:                                                # torch.save'd state_dict or Lightning checkpoint: tensors only
-            sd = torch.load(model, map_location="cpu", weights_only=True)
-            if isinstance(sd, dict) and "state_dict" in sd:
-                sd = sd["state_dict"]
+class _OpaqueGlobal:
+    """Stand-in for a pickled global that is not a tensor-building function: callable, constructible, stateless.  Nothing of
+    the module the pickle names is imported or run."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, *args, **kwargs):
+        return _OpaqueGlobal()
+
+    def __setstate__(self, state):
+        pass
+
+
+def _tolerant_pickle_module():
+    """A pickle module for torch.load whose Unpickler resolves the globals torch's own weights-only unpickler allows (tensor
+    and storage rebuilders, OrderedDict, torch.Size, dtypes ...) and replaces EVERY other global by an inert stub class.
+    Needed for the reference's training checkpoints: pytorch-lightning 1.2.1 (requirements.txt) keys the `callbacks` dict of
+    a checkpoint by the callback CLASS (ModelCheckpoint, scripts/train.py:170) and stores hyper-parameter objects - globals
+    that `weights_only=True` rejects outright and that an unrestricted load would import and execute."""
+    import pickle
+    import types
+    from torch import _weights_only_unpickler as wo
+    allowed = dict(wo._get_allowed_globals())
+    stubs = {}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            key = f"{module}.{name}"
+            if key in allowed:
+                return allowed[key]
+            if key not in stubs:
+                stubs[key] = type(name, (_OpaqueGlobal,), {"__module__": "okp_opaque." + module})
+            return stubs[key]
+
+    mod = types.ModuleType("okp_tolerant_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.__dict__.update({k: getattr(pickle, k) for k in ("UnpicklingError", "PickleError", "HIGHEST_PROTOCOL", "dumps", "loads", "dump", "Pickler")})
+    return mod
+
+
+def read_checkpoint_state_dict(path):
+    """Tensors of a model file: TorchScript archive (scripts/package_model.py:40-42), torch.save'd state_dict, or a
+    (pytorch-lightning) training checkpoint {"state_dict": ..., "callbacks": ..., ...}.  Never executes pickled code: the
+    weights-only loader first; a checkpoint that carries other globals is re-read with those replaced by inert stubs
+    (_tolerant_pickle_module) and only its tensors are kept.  Returns {name: tensor} with the module prefixes stripped."""
+    import pickle
+    if _is_torchscript_archive(path):
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
     else:
-        sd = model
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            try:
+                sd = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle_module())
+            except Exception as e:
+                raise OkpError(f"{path}: not a state_dict, Lightning checkpoint or TorchScript archive this loader can read ({e})") from e
+        if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):
+            sd = sd["state_dict"]
     if not isinstance(sd, dict):
-        raise OkpError("cannot interpret model argument")
+        raise OkpError(f"{path}: no state_dict found in the file")
+    return strip_module_prefixes({k: v for k, v in sd.items() if isinstance(k, str) and isinstance(v, torch.Tensor)})
+
+
+def strip_module_prefixes(sd):
     clean = {}
     for k, v in sd.items():
         for prefix in ("model.model.", "model."):          # TorchScript wrapper / Lightning module prefixes
@@ -62,10 +111,34 @@ def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
                 k = k[len(prefix):]
                 break
         clean[k] = v
+    return clean
+
+
+def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
+    """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
+    TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet.
+    Entries of the file that are not KeypointNet parameters (loss buffers, metrics of the Lightning module) are ignored;
+    a missing network tensor is an error."""
+    device = device or _device()
+    if isinstance(model, models.KeypointNet):
+        return model.to(device).eval()
+    if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
+        clean = read_checkpoint_state_dict(model)
+    elif isinstance(model, dict):
+        clean = strip_module_prefixes(model)
+    else:
+        raise OkpError("cannot interpret model argument")
+    for need in ("heatmap_head.output_head2.2.weight", "heatmap_head.output_head2.0.conv.weight"):
+        if need not in clean:
+            raise OkpError(f"model file holds no KeypointNet: '{need}' is missing")
     heat_out = clean["heatmap_head.output_head2.2.weight"].shape[0]
     features = clean["heatmap_head.output_head2.0.conv.weight"].shape[0]
     net = models.KeypointNet(features=features, heatmaps_out=heat_out, compute_dtype=compute_dtype)
-    net.load_state_dict(clean)
+    own = net.state_dict()
+    missing = [k for k in own if k not in clean]
+    if missing:
+        raise OkpError(f"model file lacks {len(missing)} KeypointNet tensors, e.g. '{missing[0]}'")
+    net.load_state_dict({k: clean[k] for k in own})
     return net.to(device).eval()
 
 
@@ -76,7 +149,7 @@ def load_cornernet_backbone(net, pretrained):
     corner heads (`module.tl_*`, `module.br_*`, ...) are not part of KeypointNet and are skipped.
     `pretrained`: a state_dict or a path to a torch.save'd one.  Returns the number of tensors copied."""
     if isinstance(pretrained, (str, bytes)) or hasattr(pretrained, "__fspath__"):
-        pretrained = torch.load(pretrained, map_location="cpu")
+        pretrained = torch.load(pretrained, map_location="cpu", weights_only=True)      # tensors only: never runs pickled code
     own = net.backbone.state_dict()
     picked = {}
     for k, v in pretrained.items():

@@ -105,12 +105,19 @@ class StereoCamera:
         self.T_LR = linalg.inv_transform(T_RL)
         self.F = fundamental_matrix(T_RL, self.left_camera.K, self.right_camera.K)
 
-    def triangulate(self, left_keypoints, right_keypoints, correct_matches=True):
+    def triangulate(self, left_keypoints, right_keypoints, correct_matches=True, per_camera_model=False):
+        """Like the reference (camera_utils.py:92-110) the key points are undistorted with the FISHEYE (equidistant) model and the
+        cameras' K / D whatever class the two cameras are - the reference calls cv2.fisheye.undistortPoints unconditionally.
+        per_camera_model=True (not in the reference) undistorts each view with its own camera's model instead."""
         dev = _device()
         l = torch.from_numpy(np.ascontiguousarray(left_keypoints, dtype=np.float32)).to(dev)
         r = torch.from_numpy(np.ascontiguousarray(right_keypoints, dtype=np.float32)).to(dev)
-        out = ops.triangulate_dlt(self.left_camera.okp(), self.right_camera.okp(), self.T_RL, l, r,
-                                  F=self.F if correct_matches else None)
+        if per_camera_model:
+            cam_l, cam_r = self.left_camera.okp(), self.right_camera.okp()
+        else:
+            cam_l = ops.make_camera(self.left_camera.K, self.left_camera.D)       # CAM_EQUIDISTANT
+            cam_r = ops.make_camera(self.right_camera.K, self.right_camera.D)
+        out = ops.triangulate_dlt(cam_l, cam_r, self.T_RL, l, r, F=self.F if correct_matches else None)
         return out.cpu().numpy()
 
     @classmethod

@@ -58,6 +58,61 @@ def test_allgather_world2_gloo(total):
     assert sum(d.shard(511, r, 8)[1] for r in range(8)) == 511
 
 
+def _worker_ws1(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from object_keypoints_amd import distributed as d
+    assert d.launched_by_torchrun()
+    r, _, w = d.init(backend="gloo")
+    pts = torch.arange(2 * 3 * 4 * 4, dtype=torch.float64).reshape(2, 3, 4, 4)
+    out = d.all_gather_keypoints(pts, total_frames=2)                 # a real collective on a one-rank group
+    d.barrier()
+    q.put((w, dist.is_initialized(), out is not pts, bool(torch.equal(out, pts)), d.max_over_ranks(1.25, torch.device("cpu"))))
+    dist.destroy_process_group()
+
+
+def test_torchrun_world_size_1_goes_through_the_process_group():
+    """Under torchrun a single rank still creates its process group and calls the collectives (on the GPU box: RCCL) - the
+    one-GPU rehearsal of the 8-GPU path (bench.py --gpus 1 --spawn)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_ws1, args=(_free_port(), q))
+    p.start()
+    world, initialised, copied, equal, slowest = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert world == 1 and initialised and copied and equal and slowest == 1.25
+
+
+def _worker_missing_total(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from object_keypoints_amd import distributed as d
+    d.init(backend="gloo")
+    try:
+        d.all_gather_keypoints(torch.zeros(2 + rank, 3, 4, 4, dtype=torch.float64))      # uneven blocks, no total_frames
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, str(e)))
+    d.barrier()
+
+
+def test_uneven_blocks_without_total_frames_are_refused_before_the_collective():
+    """Ranks with different block sizes must never reach all_gather_into_tensor (a hang on RCCL): with more than one rank
+    total_frames is mandatory and every rank raises locally."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_missing_total, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("total_frames" in got[r] and "required" in got[r] for r in range(world))
+
+
 def test_single_process_is_passthrough():
     from object_keypoints_amd import distributed as d
     x = torch.zeros(2, 3, 4, 4)

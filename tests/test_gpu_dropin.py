@@ -31,6 +31,10 @@ class _Packaged(torch.nn.Module):
         return torch.sigmoid(heatmap[-1]), depth[-1], centers[-1]
 
 
+class _ModelCheckpoint:          # stands in for pytorch_lightning.callbacks.ModelCheckpoint inside the checkpoint fixture
+    pass
+
+
 @pytest.fixture(scope="module")
 def oracle_case():
     from object_keypoints_amd import synth
@@ -53,7 +57,10 @@ def _model_file(kind, net, tmp_path):
             traced = torch.jit.trace(_Packaged(net).eval(), torch.zeros(1, 3, 511, 511))
         traced.save(path)
     elif kind == "lightning":
-        torch.save({"state_dict": {"model." + k: v for k, v in net.state_dict().items()}, "epoch": 3}, path)
+        # shaped like a pytorch-lightning 1.2.1 checkpoint (the reference's trainer, scripts/train.py:170): `callbacks` keyed by the
+        # callback CLASS - a global the weights-only loader refuses; the product re-reads such files with inert stubs
+        torch.save({"state_dict": {"model." + k: v for k, v in net.state_dict().items()}, "epoch": 3, "pytorch-lightning_version": "1.2.1",
+                    "callbacks": {_ModelCheckpoint: {"best_model_score": torch.tensor(0.25)}}, "hyper_parameters": _ModelCheckpoint()}, path)
     else:
         torch.save(net.state_dict(), path)
     return path

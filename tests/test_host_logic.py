@@ -252,6 +252,29 @@ def test_bench_launcher_starts_ranks_and_relays_one_json_line():
     assert "needs 8 devices, 1 visible" in err.getvalue() and not seen
 
 
+def test_launcher_counts_gpus_without_the_hip_runtime(tmp_path):
+    """The launcher parent must not initialise the GPU before it starts torchrun: devices are counted from the KFD topology
+    (nodes with SIMDs), with /dev/dri/renderD* as fall-back and the *_VISIBLE_DEVICES lists as caps."""
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):            # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    for n in ("card0", "renderD128", "renderD129"):
+        (dri / n).write_text("")
+    assert bench.gpu_count_without_hip({}, str(nodes), str(dri)) == 3
+    assert bench.gpu_count_without_hip({"HIP_VISIBLE_DEVICES": "0,2"}, str(nodes), str(dri)) == 2
+    assert bench.gpu_count_without_hip({"ROCR_VISIBLE_DEVICES": ""}, str(nodes), str(dri)) == 0
+    assert bench.gpu_count_without_hip({}, str(tmp_path / "absent"), str(dri)) == 2          # no KFD topology: render nodes
+    assert bench.gpu_count_without_hip({}, str(tmp_path / "absent"), str(tmp_path / "absent2")) == 0
+    import inspect
+    src = inspect.getsource(bench.main)
+    assert "import torch" not in src.split("rank_main")[0]          # nothing in the launcher branch imports torch
+
+
 def test_capacity_default_is_uncapped_like_the_reference():
     from object_keypoints_amd.perception.pipeline import KeypointExtractionComponent
     comp = KeypointExtractionComponent({"keypoint_config": [1, 3]}, [64, 64])
@@ -333,3 +356,61 @@ def test_evaluation_results_match_the_reference_table():
     assert abs(s["missing"] - float(row["missing"].rstrip("%"))) < 0.006          # the reference prints two decimals
     for col in ("mean", "mean xy", "std", "< 3cm", "25th percentile", "75th percentile"):
         assert abs(s[col] - float(row[col])) < 1e-9, col
+
+
+def test_reads_a_pytorch_lightning_1_2_1_shaped_checkpoint_without_running_its_pickle(tmp_path):
+    """The reference trains with pytorch-lightning==1.2.1 (requirements.txt; scripts/train.py:170 adds a ModelCheckpoint):
+    such a checkpoint keys `callbacks` by the callback CLASS and carries hyper-parameter objects.  torch's weights-only
+    loader rejects those globals; the loader must still return the tensors, without importing or executing anything the
+    pickle names, and ignore non-tensor / non-network entries."""
+    import sys
+    import types
+    import torch
+    from object_keypoints_amd.perception import pipeline as pp
+
+    mod = types.ModuleType("pytorch_lightning_fake_model_checkpoint")
+
+    class ModelCheckpoint:                                  # stands in for pytorch_lightning.callbacks.ModelCheckpoint
+        pass
+
+    class HParams:                                          # an argparse.Namespace-like hyper-parameter object
+        def __init__(self):
+            self.lr = 1e-3
+
+    class Tripwire:                                         # reconstructing this would run arbitrary code
+        def __reduce__(self):
+            return (mod.boom, ())
+
+    def boom():
+        raise AssertionError("the loader executed a pickled callable")
+
+    for obj in (ModelCheckpoint, HParams, Tripwire):
+        obj.__module__ = mod.__name__
+        obj.__qualname__ = obj.__name__
+        setattr(mod, obj.__name__, obj)
+    boom.__module__, boom.__qualname__ = mod.__name__, "boom"
+    mod.boom = boom
+    sys.modules[mod.__name__] = mod
+    tensors = {"model.heatmap_head.output_head2.2.weight": torch.arange(12.).reshape(3, 4, 1, 1), "model.backbone.pre.0.conv.weight": torch.ones(2, 3, 7, 7),
+               "loss.weights": torch.zeros(3)}
+    ckpt = {"epoch": 7, "global_step": 1234, "pytorch-lightning_version": "1.2.1",
+            "callbacks": {ModelCheckpoint: {"best_model_score": torch.tensor(0.5), "best_model_path": "x.ckpt"}},
+            "optimizer_states": [{"state": {0: {"exp_avg": torch.zeros(2)}}, "param_groups": [{"lr": 1e-3}]}], "lr_schedulers": [],
+            "hyper_parameters": HParams(), "extra": Tripwire(), "state_dict": tensors}
+    path = str(tmp_path / "epoch=7.ckpt")
+    torch.save(ckpt, path)
+    del sys.modules[mod.__name__]                           # the loading side has no pytorch_lightning at all
+
+    import pickle
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)          # what the plain safe loader does with this file
+    sd = pp.read_checkpoint_state_dict(path)
+    assert set(sd) == {"heatmap_head.output_head2.2.weight", "backbone.pre.0.conv.weight", "loss.weights"}
+    assert torch.equal(sd["heatmap_head.output_head2.2.weight"], tensors["model.heatmap_head.output_head2.2.weight"])
+    # a plain state_dict and a {"state_dict": ...} dict go through the weights-only loader as before
+    torch.save({"a.weight": torch.ones(2)}, str(tmp_path / "sd.pt"))
+    assert set(pp.read_checkpoint_state_dict(str(tmp_path / "sd.pt"))) == {"a.weight"}
+    with open(tmp_path / "junk.pt", "wb") as f:
+        f.write(b"not a checkpoint")
+    with pytest.raises((pp.OkpError, pickle.UnpicklingError, RuntimeError)):
+        pp.read_checkpoint_state_dict(str(tmp_path / "junk.pt"))
