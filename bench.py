@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (tests)")
+    ap.add_argument("--workload", choices=["batch64", "stream8"], default="batch64",
+                    help="stream8: print only the BASELINE configs[4] object (the default run carries it as `stream8` next to the headline)")
+    ap.add_argument("--no-stream8", action="store_true", help="N=1: skip the configs[4] object")
     return ap.parse_args(argv)
 
 
@@ -178,7 +181,7 @@ def committed_counters(kernel_sig, precision="bf16"):
         with open(files[-1]) as f:
             data = json.load(f)
         for name, row in data.items():
-            if kernel_sig in name:
+            if any(sig in name for sig in kernel_sig):
                 res["traffic"] = (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6
                 res["traffic_source"] = os.path.basename(files[-1])
                 break
@@ -187,7 +190,7 @@ def committed_counters(kernel_sig, precision="bf16"):
         with open(files[-1]) as f:
             data = json.load(f)
         for name, row in data.items():
-            if kernel_sig in name:
+            if any(sig in name for sig in kernel_sig):
                 res["mfma_busy"] = row.get("mfma_busy_frac")
                 res["lds_wait"] = row.get("lds_wait_frac")
                 res["hbm_GBps"] = row.get("hbm_GBps")
@@ -261,8 +264,10 @@ def cpu_baseline(seconds):
 
 TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32"}
 OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3"}
-KERNEL_SIG = {"bf16": "okp_igemm_patch_kernel", "f16": "okp_igemm_patch_kernel", "f32": "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E",
-              "f32x3": "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"}
+# substrings of the dominant kernel's name in the rocprofv3 CSVs (mangled where the tool's demangler gives up on _Float16 / __bf16)
+KERNEL_SIG = {"bf16": ("okp_igemm_patch_kernel",), "f16": ("okp_igemm_patch_kernel",),
+              "f32": ("okp_igemm_kernel<float, 256, 256, 4, 2, 2, 128, 32, 1>", "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"),
+              "f32x3": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E")}
 KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
                "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>"}
 
@@ -337,6 +342,81 @@ def run_precision(name, ctx, steps, warmup):
     return res, sample_heat
 
 
+def run_stream8(ctx, ticks=200, warmup=10):
+    """BASELINE configs[4] as a measurement (never the headline): 8 camera streams = 4 stereo pairs, one TICK = the 8 frames of
+    one instant (resident in HBM) -> fp16 network as one batch -> peak-NMS on all maps -> left/right association -> ONE DLT
+    triangulation launch -> 3D points on the host (StereoStreamPipeline; reference harness: scripts/eval_model.py:274-293, one
+    frame of one camera per call, capped at 30 Hz).  Reports the per-tick latency eager and with the network pass replayed from a
+    captured hipGraph, and the sustained rate against the 8 x 30 Hz requirement.  As in the main workload the stages behind the
+    heads run on injected maps (random weights give flat heat maps): Gaussian bumps rendered from known 3D points through the
+    left and right camera of every pair, so the triangulated points can be checked against those points in the same run."""
+    import numpy as np
+    import torch
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    dev = ctx["dev"]
+    params = cu.load_calibration_params(os.path.join(REPO, "config", "calibration.yaml"))
+    offset = np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])
+    left = cu.FisheyeCamera(params["K"], params["D"], params["image_size"]).scale(511 / 720).cut(offset).scale(64 / 511)
+    right = cu.FisheyeCamera(params["Kp"], params["Dp"], params["image_size"]).scale(511 / 720).cut(offset).scale(64 / 511)
+    stereo = cu.StereoCamera(left, right, params["T_RL"])
+    net = build_net(torch.float16).to(dev)
+    cfg = {"keypoint_config": [1, 3]}
+    pipe = pp.StereoStreamPipeline(net, stereo, cfg, capacity=16, max_distance=1.5)
+    n_pairs, K, size = 4, 3, 64
+    ys, xs = np.meshgrid(np.arange(size, dtype=np.float32), np.arange(size, dtype=np.float32), indexing="ij")
+    # per pair: 1 centre, 1 point of type 1, 3 points of type 2, 0.45-0.7 m in front of the rig, well apart in the image
+    base = {0: [[0.00, 0.00, 0.55]], 1: [[0.12, -0.10, 0.60]], 2: [[-0.16, 0.12, 0.50], [0.14, 0.04, 0.65], [-0.12, -0.16, 0.70]]}
+    heat = np.zeros((2 * n_pairs, K, size, size), np.float32)
+    truth = []
+    for p in range(n_pairs):
+        t = {}
+        for k, pts in base.items():
+            X = np.array(pts) * np.array([1.0 - 0.05 * p, 1.0 + 0.04 * p, 1.0]) + np.array([0.01 * p, -0.01 * p, 0.03 * p])
+            t[k] = X
+            for side, (cam, T) in enumerate(((left, np.eye(4)), (right, params["T_RL"]))):
+                for px, py in cam.project(X, T):
+                    heat[2 * p + side, k] += np.exp(-((xs - px) ** 2 + (ys - py) ** 2) / 4.0)
+        truth.append(t)
+    heat_dev = torch.from_numpy(np.clip(heat, 0.0, 1.0)).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(99)
+    frames = torch.randn((2 * n_pairs, 3, 511, 511), generator=gen, device=dev, dtype=torch.float32)
+    pipe.capture(frames)
+
+    def timed(use_graph):
+        for _ in range(warmup):
+            out = pipe.tick(frames, heat_override=heat_dev, use_graph=use_graph)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(ticks):
+            t0 = time.perf_counter()
+            out = pipe.tick(frames, heat_override=heat_dev, use_graph=use_graph)      # ends with the D2H copy of the 3D points
+            lat.append((time.perf_counter() - t0) * 1e3)
+        return np.array(lat), out
+
+    lat_e, out = timed(False)
+    lat_g, out_g = timed(True)
+    worst, matched = 0.0, 0
+    for p in range(n_pairs):
+        for k in range(K):
+            got, want = out[p][k], truth[p][k]
+            assert got.shape == want.shape, (p, k, got.shape, want.shape)                # every point of every pair triangulated
+            assert np.array_equal(got, out_g[p][k])                                        # graph replay = eager, bit for bit
+            d = np.linalg.norm(got[:, None] - want[None], axis=2).min(axis=1)
+            worst = max(worst, float(d.max())); matched += got.shape[0]
+    # 64 x 64 maps and a 6.2 cm baseline: depth moves 13 cm per pixel of disparity at 0.7 m, and the reference's centroid (5 x 5 window
+    # around the peak, pipeline.py:53-61) is biased by up to ~0.3 px between pixel centres - centimetres, by construction of the path
+    assert worst < 0.06, worst
+    med_g = float(np.median(lat_g))
+    return {"workload": "BASELINE configs[4]: 8 camera streams (4 stereo pairs) x 30 fps, fp16 convolutions + fp32/fp64 geometry: 8 frames per tick "
+                        "(HBM-resident) -> hourglass + heads -> peak-NMS -> left/right association -> one DLT triangulation launch -> 3D points on the host",
+            "ticks": ticks, "frames_per_tick": 2 * n_pairs,
+            "tick_ms_eager": {"median": float(np.median(lat_e)), "p99": float(np.quantile(lat_e, 0.99))},
+            "tick_ms_graph": {"median": med_g, "p99": float(np.quantile(lat_g, 0.99))},
+            "sustained_fps": 2 * n_pairs * 1e3 / med_g, "required_fps": 240.0, "tick_budget_ms": 1e3 / 30.0,
+            "headroom_x": (1e3 / 30.0) / med_g, "points_per_tick": matched, "triangulation_err_m_max": worst}
+
+
 def heat_error(got, want):
     import numpy as np
     e = np.abs(got.astype(np.float64) - want.astype(np.float64)).ravel()
@@ -376,6 +456,11 @@ def rank_main(args):
            "bumps": bump_maps(start, args.batch, dev),
            "err_frames": torch.from_numpy(synth.frames(ERR_FRAMES, seed=1)).to(dev) if with_cpu else None}
 
+    if args.workload == "stream8":
+        print(json.dumps({"metric": "stream8 tick latency (BASELINE configs[4])", "stream8": run_stream8(ctx)}), flush=True)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     head, head_heat = run_precision(args.dtype, ctx, args.steps, args.warmup)
     result = {
         "metric": "frames/sec keypoint inference (511x511 -> heatmaps+3D)",
@@ -396,6 +481,8 @@ def rank_main(args):
             res, extra_heat[name] = run_precision(name, ctx, steps, min(args.warmup, 2))
             res["workload"] = workload_string(args.batch, name, world)
             result[OBJECT_KEY[name]] = res
+    if world == 1 and not args.no_stream8:
+        result["stream8"] = run_stream8(ctx)
     if with_cpu:
         result["cpu_baseline"], oracle_heat = cpu_baseline(args.cpu_seconds)
         result["heat_err_vs_oracle"] = heat_error(head_heat, oracle_heat)

@@ -67,7 +67,12 @@ class _HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plans = {}
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._plans.clear())
+        self._plan_epoch = 0          # bumped whenever the cached plans are dropped (weights reloaded / moved): CapturedStep.stale()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_plans())
+
+    def _drop_plans(self):
+        self._plans.clear()
+        self._plan_epoch += 1
 
     def _plan(self, key, build):
         if self.training:
@@ -80,7 +85,7 @@ class _HipModule(nn.Module):
         return p
 
     def _apply(self, fn, *a, **k):          # .to()/.cuda() moves parameters: device constants must follow
-        self._plans.clear()
+        self._drop_plans()
         return super()._apply(fn, *a, **k)
 
 

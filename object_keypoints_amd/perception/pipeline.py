@@ -438,10 +438,12 @@ class CapturedStep:
     def __init__(self, net, graph, static_in, static_out):
         self.net, self.graph, self.static_in, self.static_out = net, graph, static_in, static_out
         self._pinned = _live_plans(net)
+        # every module that caches plans, with its plan epoch at capture time: the per-replay staleness test is ~150 integer
+        # compares (walking and comparing the plan objects themselves cost a replay ~0.4 ms of host time)
+        self._epochs = [(m, m._plan_epoch) for m in net.modules() if hasattr(m, "_plan_epoch")]
 
     def stale(self):
-        now = _live_plans(self.net)
-        return len(now) != len(self._pinned) or any(a is not b for a, b in zip(now, self._pinned))
+        return any(m._plan_epoch != e for m, e in self._epochs)
 
     def replay(self, frames=None):
         if self.stale():
@@ -581,3 +583,93 @@ class BatchedKeypointPipeline:
                 world.append(np.stack(rows))
             objects.append({'p_centers': obj['p_centers'], 'keypoints': groups, 'p_C': world})
         return objects
+
+
+class StereoStreamPipeline:
+    """BASELINE configs[4] / SURVEY 8(d) config 5: a rig of stereo cameras streamed frame-synchronously.  One TICK takes the 2P
+    frames of P stereo pairs (left frame of pair p at index 2p, right at 2p + 1) through the network as ONE batch, finds the heat-map
+    peaks of all 2P x K maps in one launch, matches left and right peaks per pair and key-point type (AssociationComponent's
+    epipolar assignment, test/test_pipeline.py:208-261), and triangulates every matched pair of the tick in ONE
+    okp_triangulate_dlt launch (StereoCamera.triangulate, camera_utils.py:92-110).  The reference's harness processes one frame
+    of one camera per call at a 30 Hz cap (scripts/eval_model.py:274-293).  Geometry is fp32 / fp64 whatever the network's
+    compute dtype.
+
+    tick(frames) -> list over pairs of {type k: (n_k, 3) float64 points in the left camera frame}, plus timing-free device work:
+    three small device -> host copies per tick (peaks, undistorted peaks, 3D points)."""
+
+    def __init__(self, net, stereo_camera, keypoint_config, capacity=16, max_distance=3.0):
+        self.net = net
+        self.stereo = stereo_camera
+        self.config = [1] + list(keypoint_config["keypoint_config"])
+        self.capacity = capacity
+        self.assoc = AssociationComponent(max_distance=max_distance)
+        self.assoc.reset(stereo_camera)
+        self.cam_l = ops.make_camera(stereo_camera.left_camera.K, stereo_camera.left_camera.D)      # fisheye model, as the reference
+        self.cam_r = ops.make_camera(stereo_camera.right_camera.K, stereo_camera.right_camera.D)
+        self._graph = None
+
+    def capture(self, frames):
+        """Capture the network pass of a tick for this frame shape into a hipGraph (one graph launch instead of ~66)."""
+        static_in = frames.clone()
+        for _ in range(2):
+            self.net.deployed(static_in)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        keep, ops.SIDE_STREAMS = ops.SIDE_STREAMS, ops.SIDE_STREAMS and GRAPH_SIDE_STREAMS
+        try:
+            with torch.cuda.graph(graph):
+                static_out = self.net.deployed(static_in)
+        finally:
+            ops.SIDE_STREAMS = keep
+        self._graph = CapturedStep(self.net, graph, static_in, static_out)
+        return self._graph
+
+    def tick(self, frames, heat_override=None, use_graph=False):
+        if frames.shape[0] % 2:
+            raise OkpError("a tick holds the left and right frame of every stereo pair: an even number of frames")
+        with torch.no_grad():
+            if use_graph:
+                if self._graph is None:
+                    raise OkpError("capture() the tick first")
+                heat, depth, centers = self._graph.replay(frames)
+            else:
+                heat, depth, centers = self.net.deployed(frames)
+            if heat_override is not None:
+                heat = heat_override
+            count, _, xyc = ops.peak_nms(heat, cap=self.capacity)
+            count_h = count.cpu().numpy()                                   # D2H 1 (tiny)
+            if int(count_h.max(initial=0)) > self.capacity:
+                raise OkpError("peak capacity exceeded in a tick; raise `capacity`")
+            n_pairs, K = frames.shape[0] // 2, heat.shape[1]
+            # undistort every left and every right peak of the tick in two launches (the cost of the assignment needs them)
+            xy = xyc[..., :2].reshape(n_pairs, 2, K, self.capacity, 2)
+            ul = ops.camera_undistort(self.cam_l, xy[:, 0].reshape(-1, 2))
+            ur = ops.camera_undistort(self.cam_r, xy[:, 1].reshape(-1, 2))
+            und = torch.stack([ul, ur]).cpu().numpy().reshape(2, n_pairs, K, self.capacity, 2)      # D2H 2
+            raw = xy.cpu().numpy()
+        F = self.stereo.F
+        left_sel, right_sel, owner = [], [], []
+        from scipy.optimize import linear_sum_assignment
+        for p in range(n_pairs):
+            for k in range(K):
+                cl, cr = int(count_h[2 * p, k]), int(count_h[2 * p + 1, k])
+                if cl == 0 or cr == 0:
+                    continue
+                hl = np.concatenate([und[0, p, k, :cl], np.ones((cl, 1))], axis=1)
+                hr = np.concatenate([und[1, p, k, :cr], np.ones((cr, 1))], axis=1)
+                lines_r, lines_l = hl @ F.T, hr @ F
+                num = np.abs(lines_r @ hr.T)
+                cost = 0.5 * (num / np.maximum(np.linalg.norm(lines_r[:, :2], axis=1), 1e-300)[:, None]
+                              + num / np.maximum(np.linalg.norm(lines_l[:, :2], axis=1), 1e-300)[None, :])
+                rows, cols = linear_sum_assignment(np.where(cost <= self.assoc.max_distance, cost, 1e6))
+                keep = cost[rows, cols] <= self.assoc.max_distance
+                for i, j in zip(rows[keep], cols[keep]):
+                    left_sel.append(raw[p, 0, k, i]); right_sel.append(raw[p, 1, k, j]); owner.append((p, k))
+        result = [{k: np.zeros((0, 3)) for k in range(K)} for _ in range(n_pairs)]
+        if left_sel:
+            dev = frames.device
+            pts = ops.triangulate_dlt(self.cam_l, self.cam_r, self.stereo.T_RL, torch.from_numpy(np.stack(left_sel)).to(dev),
+                                      torch.from_numpy(np.stack(right_sel)).to(dev), F=F).cpu().numpy()          # D2H 3
+            for (p, k), X in zip(owner, pts):
+                result[p][k] = np.concatenate([result[p][k], X[None]])
+        return result

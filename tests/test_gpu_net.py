@@ -56,15 +56,21 @@ def test_full_forward_returns_both_stacks():
 
 @pytest.mark.parametrize("name", sorted(cases.NET_CASES))
 @pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("f16", torch.float16)])
-def test_16bit_network_within_twice_the_recorded_error(name, tag, dtype):
-    """The throughput precisions against the reference's golden outputs.  The bound is 2x the error MEASURED on MI355X and
-    committed in tests/golden/precision_measured.json (scripts/record_precision_error.py): heat, depth and centre maps (max
-    and mean), and the agreement of the peak sets found on the heat maps (the reference's bit-exact index contract holds
-    for fp32 only: 16-bit heat maps move box sums across the 0.5 gate / the 5x5 ties for a few percent of the ~100 peaks
-    a random-weight map has)."""
+def test_16bit_network_within_absolute_bounds(name, tag, dtype):
+    """The throughput precisions against the reference's golden outputs, with ABSOLUTE bounds per precision
+    (tests/precision/bounds.py: twice what a CPU model of the path's 16-bit rounding points predicts, pinned on the CPU by
+    tests/test_precision_emulation.py - not a multiple of this implementation's own measurement): heat, depth and centre maps
+    (max and mean), the agreement of the peak sets found on the heat maps (the reference's bit-exact index contract holds for
+    fp32 only: 16-bit heat maps move box sums across the 0.5 gate / the 5x5 ties for a few percent of the ~100 peaks a
+    random-weight map has), and the 3D points at the peaks both maps have.  The figures measured on MI355X are recorded in
+    tests/golden/precision_measured.json (scripts/record_precision_error.py) and must of course sit inside the same bounds."""
     import json
     import os
+    import sys
     from object_keypoints_amd import ops, synth
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision"))
+    from bounds import BOUNDS
+    b = BOUNDS[tag]
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "precision_measured.json")) as f:
         rec = json.load(f)[name][tag]
     case = cases.NET_CASES[name]
@@ -74,34 +80,37 @@ def test_16bit_network_within_twice_the_recorded_error(name, tag, dtype):
     g = gu.golden_net(name)
     for key, got in (("heat", heat), ("depth", depth), ("centers", centers)):
         err = np.abs(got.cpu().numpy().astype(np.float64) - g[key])
-        print(f"{name} {tag} {key}: max {err.max():.3e} mean {err.mean():.3e} (recorded {rec[key]['max']:.3e} / {rec[key]['mean']:.3e})")
-        assert err.max() <= 2.0 * rec[key]["max"] and err.mean() <= 2.0 * rec[key]["mean"]
+        print(f"{name} {tag} {key}: max {err.max():.3e} mean {err.mean():.3e} (bounds {b[key + '_max']:.1e} / {b[key + '_mean']:.1e})")
+        assert err.max() <= b[key + "_max"] and err.mean() <= b[key + "_mean"]
+        assert rec[key]["max"] <= b[key + "_max"] and rec[key]["mean"] <= b[key + "_mean"]      # the committed record, too
     count, yx, _ = ops.peak_nms(heat, cap=4096)
     gcount, gyx, _ = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
     inter = union = 0
     for k in range(heat.shape[1]):
         a = {tuple(p) for p in yx[0, k, :int(count[0, k])].cpu().numpy().tolist()}
-        b = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
-        inter += len(a & b); union += len(a | b)
-    assert inter / union >= 1.0 - 2.0 * (1.0 - rec["peaks"]["jaccard"]) - 0.01
+        c = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
+        inter += len(a & c); union += len(a | c)
+    assert inter / union >= b["jaccard_min"]
     # 3D points at the peaks both maps agree on (the depth head is O(1-5) on these weights: metres)
-    import os as _os
     from object_keypoints_amd.perception.utils import camera_utils as cu
-    repo = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
-    p_ = cu.load_calibration_params(_os.path.join(repo, "config", "calibration.yaml"))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p_ = cu.load_calibration_params(os.path.join(repo, "config", "calibration.yaml"))
     cam = cu.FisheyeCamera(p_["K"], p_["D"], p_["image_size"]).scale(511 / 720)
     cam = cam.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511).okp()
     _, _, xyc = ops.peak_nms(heat, cap=4096)
     _, _, gxyc = ops.peak_nms(torch.from_numpy(g["heat"]).cuda(), cap=4096)
     pts = ops.lift_peaks(cam, count, xyc, depth, 63, 63).cpu().numpy()
     gpts = ops.lift_peaks(cam, gcount, gxyc, torch.from_numpy(g["depth"]).cuda(), 63, 63).cpu().numpy()
-    worst = 0.0
+    d3 = []
     for k in range(heat.shape[1]):
         a = {tuple(p): i for i, p in enumerate(yx[0, k, :int(count[0, k])].cpu().numpy().tolist())}
-        b = {tuple(p): i for i, p in enumerate(gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist())}
-        for key in a.keys() & b.keys():
-            worst = max(worst, float(np.abs(pts[0, k, a[key], :3] - gpts[0, k, b[key], :3]).max()))
-    assert worst <= 2.0 * rec["peaks"]["p_C_max_m_at_common_peaks"]
+        c = {tuple(p): i for i, p in enumerate(gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist())}
+        for key in a.keys() & c.keys():
+            d3.append(float(np.abs(pts[0, k, a[key], :3] - gpts[0, k, c[key], :3]).max()))
+    print(f"{name} {tag} p_C at common peaks: max {max(d3):.3e} m, mean {np.mean(d3):.3e} m")
+    assert np.mean(d3) <= b["p_C_mean_m"]
+    if b["p_C_max_m"] is not None:
+        assert max(d3) <= b["p_C_max_m"]
 
 
 def test_batch_independence_and_eval_only():
