@@ -36,7 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 GFLOP_PER_FRAME = 74.565218304          # 37 282 609 152 MACs x 2 (deployed path, K=3)
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x3": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x3": 2500.0, "f32mix": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 # f32x3 (ops.F32X3): fp32 tensors, every product as three fp16 MFMA terms.  `achieved` counts the ALGORITHMIC FLOPs once, the peak is
 # the fp16 pipe's: a perfect kernel of this kind would read frac = 1/3 (roofline.mfma_terms says so in the line).
 ERR_FRAMES = 4                          # frames of the cpu_baseline sample on which every precision is compared with the oracle
@@ -48,8 +48,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16", "f16", "f32", "f32x3"], default="bf16", help="precision of the headline line")
-    ap.add_argument("--extra-dtypes", default="f32x3,f32,f16", help="N=1: further precisions reported as extra objects ('' = none)")
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32", "f32x3", "f32mix"], default="bf16", help="precision of the headline line")
+    ap.add_argument("--extra-dtypes", default="f32mix,f32x3,f32,f16", help="N=1: further precisions reported as extra objects ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (tests)")
@@ -262,14 +262,16 @@ def cpu_baseline(seconds):
             keep["heat"])
 
 
-TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32"}
-OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3"}
+TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32", "f32mix": "float32"}
+OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3", "f32mix": "f32mix"}
 # substrings of the dominant kernel's name in the rocprofv3 CSVs (mangled where the tool's demangler gives up on _Float16 / __bf16)
 KERNEL_SIG = {"bf16": ("okp_igemm_patch_kernel",), "f16": ("okp_igemm_patch_kernel",),
               "f32": ("okp_igemm_kernel<float, 256, 256, 4, 2, 2, 128, 32, 1>", "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"),
-              "f32x3": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E")}
+              "f32x3": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"),
+              "f32mix": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E")}
 KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
-               "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>"}
+               "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>",
+               "f32mix": "okp_igemm_kernel<f32 split, 1 or 3 fp16 MFMA terms per tap,256x256,src1>"}
 
 
 def bump_maps(start, count, dev, keypoint_config=(1, 3)):
@@ -290,12 +292,13 @@ def run_precision(name, ctx, steps, warmup):
     from object_keypoints_amd.perception.pipeline import BatchedKeypointPipeline
     dev, world, batch = ctx["dev"], ctx["world"], ctx["batch"]
     dtype = getattr(torch, TORCH_DTYPES[name])
-    net = build_net(ops.F32X3 if name == "f32x3" else dtype).to(dev)
+    net = build_net({"f32x3": ops.F32X3, "f32mix": ops.F32MIX}.get(name, dtype)).to(dev)
     pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, ctx["camera"], capacity=64)
     frames = ctx["frames"]
     b_heat, b_depth, b_centers, n_peaks = ctx["bumps"]
     # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile
-    timer = KernelTimer(dtype, (3,) if name in ("f32", "f32x3") else (13,), 1 if name in ("f32", "f32x3") else None)
+    gather = name in ("f32", "f32x3", "f32mix")
+    timer = KernelTimer(dtype, (3,) if gather else (13,), 1 if gather else None)
     ops.LAUNCH_HOOK = timer
 
     def step():
@@ -337,6 +340,8 @@ def run_precision(name, ctx, steps, warmup):
                         "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
+    if name == "f32mix":
+        res["roofline"]["mfma_terms"] = "1 (3x3 convolutions inside residual blocks) or 3 per tap"
     del pipe, net
     torch.cuda.empty_cache()
     return res, sample_heat
@@ -477,7 +482,7 @@ def rank_main(args):
         for name in [d for d in args.extra_dtypes.split(",") if d and d != args.dtype]:
             # fp32 runs ~12x longer per step (157 TFLOP/s MFMA peak): fewer steps keep the default run within minutes
             # (with the driver's --steps 20 every precision still times at least 10 steps)
-            steps = max(10, args.steps // 10) if name == "f32" else max(10, args.steps // (4 if name == "f32x3" else 2))
+            steps = max(10, args.steps // 10) if name == "f32" else max(10, args.steps // (4 if name in ("f32x3", "f32mix") else 2))
             res, extra_heat[name] = run_precision(name, ctx, steps, min(args.warmup, 2))
             res["workload"] = workload_string(args.batch, name, world)
             result[OBJECT_KEY[name]] = res

@@ -79,6 +79,14 @@ typedef struct okp_conv okp_conv;   /* opaque plan: packed weights + bias + slic
 okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride,
                           int32_t cout, int32_t n_taps, const okp_tap* taps,
                           const float* bias /* HOST [cout] or NULL */, int act);
+/* OKP_F32X3 plans with a term count PER TAP (the sensitivity-guided mixed configuration): tap_terms[t] = 3 multiplies tap t's
+ * products as the three-term split (fp32-grade), tap_terms[t] = 1 as the single fp16 product x_hi * w_hi (both operands rounded to
+ * fp16 for that product only - the tensors stay fp32), at a third of the matrix-pipe time.  Meant for convolutions whose rounding
+ * error reaches the output attenuated - the 3x3 convolutions inside residual blocks (py_utils/utils.py:158-185: conv1, conv2), behind
+ * a BatchNorm-scaled branch - while the taps of the skip path keep three terms; tests/precision/attribute.py prices a choice on given
+ * weights.  tap_terms == NULL: all taps three terms (= okp_conv_create(OKP_F32X3, ...)). */
+okp_conv* okp_conv_create_x3(int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout, int32_t n_taps,
+                             const okp_tap* taps, const uint8_t* tap_terms, const float* bias, int act);
 void okp_conv_destroy(okp_conv* plan);
 
 typedef struct okp_tensor {        /* an NHWC view */
@@ -159,6 +167,11 @@ int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv
 int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride,
                           const okp_tensor* src, const float* w_dev, const float* bias_dev,
                           const okp_tensor* res, const okp_tensor* out, int act, void* stream);
+
+/* Element type conversion of a contiguous tensor of `count` elements (OKP_F32 <-> OKP_F16 / OKP_BF16, round to nearest even): the
+ * boundary between the fp32 skip stream and an fp16 sub-network in the mixed configuration (KeypointNet(compute_dtype="float32mix")
+ * runs the innermost hourglass levels, modules.py:25-66, in fp16). */
+int okp_cast(int src_dtype, const void* src_dev, int dst_dtype, void* dst_dev, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Frame packing for the 7x7/s2 stem: NCHW fp32 (n,3,h,w) -> NHWC4 `dtype` with a zero halo,

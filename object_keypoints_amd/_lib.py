@@ -61,7 +61,9 @@ SIGNATURES = [
     ("okp_device_count", c_int, []),
     ("okp_device_arch", c_int, [c_int, c_char_p, c_int]),
     ("okp_conv_create", c_void_p, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(c_float), c_int]),
+    ("okp_conv_create_x3", c_void_p, [c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(ctypes.c_uint8), POINTER(c_float), c_int]),
     ("okp_conv_destroy", None, [c_void_p]),
+    ("okp_cast", c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),

@@ -61,8 +61,24 @@ extern "C" int okp_device_arch(int dev, char* buf, int buflen) {
   return OKP_OK;
 }
 
+static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
+                             int32_t n_taps, const okp_tap* taps, const uint8_t* tap_terms, const float* bias, int act);
+
 extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
                                      int32_t n_taps, const okp_tap* taps, const float* bias, int act) {
+  return conv_create(dtype, n_src, cin, conv_stride, cout, n_taps, taps, nullptr, bias, act);
+}
+
+extern "C" okp_conv* okp_conv_create_x3(int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout, int32_t n_taps,
+                                        const okp_tap* taps, const uint8_t* tap_terms, const float* bias, int act) {
+  if (tap_terms)
+    for (int t = 0; t < n_taps && t < OKP_MAX_TAPS; ++t)
+      if (tap_terms[t] != 1 && tap_terms[t] != 3) { okp_set_error("okp_conv_create_x3: tap_terms[%d] = %d, must be 1 or 3", t, (int)tap_terms[t]); return nullptr; }
+  return conv_create(OKP_F32X3, n_src, cin, conv_stride, cout, n_taps, taps, tap_terms, bias, act);
+}
+
+static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout,
+                             int32_t n_taps, const okp_tap* taps, const uint8_t* tap_terms, const float* bias, int act) {
   if (dtype != OKP_F32 && dtype != OKP_F32X3 && !okp_is16(dtype)) { okp_set_error("okp_conv_create: bad dtype %d", dtype); return nullptr; }
   if (n_src < 1 || n_src > 2 || !cin || !conv_stride || !taps) { okp_set_error("okp_conv_create: bad sources"); return nullptr; }
   if (n_taps < 1 || n_taps > OKP_MAX_TAPS) { okp_set_error("okp_conv_create: n_taps %d not in [1,%d]", n_taps, OKP_MAX_TAPS); return nullptr; }
@@ -97,7 +113,7 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
     }
     for (int c0 = 0; c0 < c; c0 += KE) {
       const int chunks = ((c - c0) * esz + 15) / 16;
-      OkpSlice sl{(uint8_t)t, (uint8_t)t, (uint8_t)s, (uint8_t)(chunks > 8 ? 8 : chunks), c0, c0 + KE / 2, 0};
+      OkpSlice sl{(uint8_t)t, (uint8_t)t, (uint8_t)s, (uint8_t)(chunks > 8 ? 8 : chunks), c0, c0 + KE / 2, (tap_terms && tap_terms[t] == 1) ? 1 : 0};
       slices.push_back(sl);
     }
     ++t;
@@ -158,6 +174,16 @@ extern "C" okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, c
       if (a.c0_lo != b.c0_lo) return a.c0_lo < b.c0_lo;
       return tap_geom[a.tap_lo] < tap_geom[b.tap_lo];          // the taps of one patch geometry follow each other
     });
+  }
+  // split-product plans with per-tap term counts: the single-term slices go first (the kernel runs them as a loop of their own)
+  plan->n_single_slices = 0;
+  if (tap_terms) {
+    for (const OkpSlice& sl : slices) plan->n_single_slices += sl.pad == 1 ? 1 : 0;
+    if (plan->n_single_slices && (n_taps % 4 == 0 && n_taps >= 8) && plan->n_single_slices != (int)slices.size()) {
+      // (four equal tap groups are the sub-pixel classes of a transposed convolution: each class is a K range of its own)
+      okp_set_error("okp_conv_create_x3: plans with four tap groups (sub-pixel classes) take one term count for all taps"); delete plan; return nullptr;
+    }
+    std::stable_partition(slices.begin(), slices.end(), [](const OkpSlice& sl) { return sl.pad == 1; });
   }
   plan->n_slices = (int)slices.size();
   if (plan->n_slices > 256) { okp_set_error("okp_conv_create: %d K-slices exceed the 256-entry in-LDS slice table", plan->n_slices); delete plan; return nullptr; }
@@ -393,6 +419,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
     if ((a->ho - 1) * 2 + a->out_oy + 1 >= a->out.h || (a->wo - 1) * 2 + a->out_ox + 1 >= a->out.w) { okp_set_error("okp_conv_forward: sub-pixel classes do not fit out"); return OKP_EINVAL; }
   }
   p.slices_per_class = plan->n_slices / p.n_classes;
+  p.n_single_slices = plan->n_single_slices / p.n_classes;
   if (a->dw_w_dev) {
     if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
     if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }

@@ -62,6 +62,15 @@ __device__ __forceinline__ void okp_split8(const u32x4& r0, const u32x4& r1, u32
 #endif
 }
 
+// the high halves alone (single-term slices)
+__device__ __forceinline__ u32x4 okp_hi8(const u32x4& r0, const u32x4& r1) {
+  const f32x4 x0 = __builtin_bit_cast(f32x4, r0), x1 = __builtin_bit_cast(f32x4, r1);
+  f16x8 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { h[e] = (_Float16)x0[e]; h[4 + e] = (_Float16)x1[e]; }
+  return __builtin_bit_cast(u32x4, h);
+}
+
 template <typename T, int MT> struct Mma;
 template <> struct Mma<F32S, 32> {
   using acc_t = f32x16;
@@ -177,7 +186,7 @@ constexpr int kMetaMax = 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <typename T, int BCO, int BPX, int WCO, int WPX, int NS, int KB, int MT, int NSRC>
-__global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgemmParams p) {
+__global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 : 1)) void okp_igemm_kernel(const OkpIgemmParams p) {     // split-product tiles: two waves per SIMD (<= 256 registers)
   constexpr int NT = 64 * WCO * WPX;
   constexpr int ESZ = (int)sizeof(T);
   static_assert(KB == 128 || KB == 64, "LDS row = one 128-byte K-slice or half of one");
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     m.d_lo = ((p.taps[sl.tap_lo].dy * W + p.taps[sl.tap_lo].dx) * ps + sl.c0_lo) * ESZ;
     m.d_hi = ((p.taps[sl.tap_hi].dy * W + p.taps[sl.tap_hi].dx) * ps + sl.c0_hi) * ESZ;
     m.packed = (uint32_t)sl.tap_lo | ((uint32_t)sl.tap_hi << 8) | ((uint32_t)sl.nvalid << 16) | ((uint32_t)src << 24);
-    m.pad = 0;
+    m.pad = (uint32_t)sl.pad;                    // split-product plans: 1 = single-term slice
     meta[s] = m;
   }
 
@@ -411,7 +420,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
     constexpr int SUB = KB / 64;
     int st_c = 0, st_i = NS - 1;
     SliceMeta m = meta[sbase + (NS - 1 < T_ ? NS - 1 : 0) / HPS];
-    for (int t = 0; t < T_; ++t) {
+    // One ring step.  SINGLE (okp_conv_create_x3, tap_terms = 1): only x_hi * w_hi - no low halves are read, split or multiplied.
+    // The plan puts its single-term slices first, so the K loop is two loops over the same ring, each with one straight body
+    // (a per-step branch between the two bodies made hipcc spill 450 registers).
+    auto ring_step = [&](int t, auto single_tag) {
+      constexpr bool SINGLE = decltype(single_tag)::value;
       const int nxt = t + NS - 1;
       const bool more = nxt < T_;
       if (NS > 2 && t + NS - 2 < T_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NDMA) : "memory");
@@ -434,23 +447,33 @@ __global__ __launch_bounds__(64 * WCO * WPX) void okp_igemm_kernel(const OkpIgem
         for (int i = 0; i < TCO; ++i) {
           const int row = (wco * TCO + i) * MT + fr;
           ah[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>(row, 4 * mm + fh));
-          al[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>(row, 4 * mm + 2 + fh));
+          if constexpr (!SINGLE) al[i] = *reinterpret_cast<const u32x4*>(wt + swz<KB>(row, 4 * mm + 2 + fh));
         }
         if (mm == 0 && more) issue_w(nxt, st_i);
         if (mm == SUB - 1 && more) issue_x(nxt, m, st_i);
 #pragma unroll
         for (int j = 0; j < TPX; ++j) {
           if (j + 1 < TPX) read_b(j + 1, (j + 1) & 1);
-          u32x4 bh, bl;
-          okp_split8(r0[j & 1], r1[j & 1], bh, bl);
+          if constexpr (SINGLE) {
+            const u32x4 bh = okp_hi8(r0[j & 1], r1[j & 1]);
 #pragma unroll
-          for (int i = 0; i < TCO; ++i) Mma<F32S, 32>::run3(ah[i], al[i], bh, bl, acc[i][j]);
+            for (int i = 0; i < TCO; ++i) acc[i][j] = H16<_Float16>::mfma32(ah[i], bh, acc[i][j]);
+          } else {
+            u32x4 bh, bl;
+            okp_split8(r0[j & 1], r1[j & 1], bh, bl);
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) Mma<F32S, 32>::run3(ah[i], al[i], bh, bl, acc[i][j]);
+          }
         }
       }
       m = meta[sbase + (nxt + 1 < T_ ? nxt + 1 : T_ - 1) / HPS];
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
       st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-    }
+    };
+    const int T1 = p.n_single_slices * HPS;          // ring steps of the leading single-term slices (0 for all-three-term plans)
+    int t = 0;
+    for (; t < T1; ++t) ring_step(t, std::integral_constant<bool, true>{});
+    for (; t < T_; ++t) ring_step(t, std::integral_constant<bool, false>{});
   } else if constexpr (XB) {
     auto mma_half = [&](const u32x4 (&a)[TCO], const u32x4 (&b)[TPX], auto half) {     // first / second half of the rows
       constexpr int I0 = decltype(half)::value ? (TCO + 1) / 2 : 0;

@@ -76,7 +76,7 @@ inline bool okp_is16(int dtype) { return dtype == OKP_BF16 || dtype == OKP_F16; 
 struct OkpSlice {
   uint8_t tap_lo, tap_hi, src, nvalid;   // nvalid: number of 16-B chunks that carry data (1..8)
   int32_t c0_lo, c0_hi;                  // first channel (elements) of each half
-  int32_t pad;
+  int32_t pad;                           // OKP_F32X3 plans: 1 = this slice's products are single-term (x_hi * w_hi), 0 = three terms
 };
 
 struct OkpTapDev {
@@ -126,6 +126,7 @@ struct OkpIgemmParams {
   int32_t dw_out_pix_stride, dw_res_pix_stride;
   int32_t n_tiles;
   int32_t n_classes, tiles_per_class, slices_per_class;
+  int32_t n_single_slices; // OKP_F32X3: leading single-term K-slices (the plan sorts them first)
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 
@@ -191,6 +192,7 @@ struct okp_conv {
   int32_t n_taps;
   OkpTapDev taps[OKP_MAX_TAPS];
   int32_t n_slices;
+  int32_t n_single_slices;   // OKP_F32X3 plans built with tap_terms: leading K-slices whose products are single-term
   int act;
   void* weights_dev;
   uint32_t w_bytes;

@@ -1,6 +1,8 @@
 // HBM-bound kernels around the implicit GEMM: depth-wise 3x3 (fire-module tail), frame packing
 // for the stem, and the final 1x1 of the heads (NHWC -> NCHW fp32 + sigmoid).
 // All of them move 16 bytes per lane per access and keep channels contiguous across lanes.
+#include <algorithm>
+
 #include "okp_internal.h"
 
 namespace {
@@ -357,6 +359,45 @@ extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t co
   else if (dtype == OKP_F16) hipLaunchKernelGGL(okp_dwconv3x3_kernel<_Float16>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
   else hipLaunchKernelGGL(okp_dwconv3x3_kernel<float>, dim3(grid), dim3(256), 9 * c * sizeof(float), (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_dwconv3x3 launch");
+}
+
+namespace {
+// 8 elements per thread and iteration: 32 + 16 bytes per lane, grid-stride
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void okp_cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n8, long count) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long e0 = i * 8;
+    if (e0 + 8 <= count) {
+      typedef S sv8 __attribute__((ext_vector_type(8)));
+      typedef D dv8 __attribute__((ext_vector_type(8)));
+      const sv8 v = *reinterpret_cast<const sv8*>(src + e0);
+      dv8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (D)(float)v[e];
+      *reinterpret_cast<dv8*>(dst + e0) = o;
+    } else {
+      for (long e = e0; e < count; ++e) dst[e] = (D)(float)src[e];
+    }
+  }
+}
+template <typename S, typename D>
+void launch_cast(const void* src, void* dst, long count, hipStream_t stream) {
+  const long n8 = (count + 7) / 8;
+  const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
+  hipLaunchKernelGGL((okp_cast_kernel<S, D>), dim3(grid), dim3(256), 0, stream, static_cast<const S*>(src), static_cast<D*>(dst), n8, count);
+}
+}  // namespace
+
+extern "C" int okp_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t count, void* stream) {
+  if (!src || !dst || count < 1) { okp_set_error("okp_cast: null / empty argument"); return OKP_EINVAL; }
+  if (((uintptr_t)src) % 16 || ((uintptr_t)dst) % 16) { okp_set_error("okp_cast: tensors must be 16-byte aligned"); return OKP_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == OKP_F32 && dst_dtype == OKP_F16) launch_cast<float, _Float16>(src, dst, count, st);
+  else if (src_dtype == OKP_F32 && dst_dtype == OKP_BF16) launch_cast<float, __bf16>(src, dst, count, st);
+  else if (src_dtype == OKP_F16 && dst_dtype == OKP_F32) launch_cast<_Float16, float>(src, dst, count, st);
+  else if (src_dtype == OKP_BF16 && dst_dtype == OKP_F32) launch_cast<__bf16, float>(src, dst, count, st);
+  else { okp_set_error("okp_cast: unsupported conversion %d -> %d (fp32 <-> fp16 / bf16)", src_dtype, dst_dtype); return OKP_EINVAL; }
+  return okp_check_hip(hipGetLastError(), "okp_cast launch");
 }
 
 extern "C" int okp_pack_frames(int dtype, const float* frames, int32_t n, int32_t h, int32_t w, void* out, int32_t out_w, void* stream) {

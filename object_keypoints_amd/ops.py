@@ -20,33 +20,48 @@ HALF_DTYPES = (torch.bfloat16, torch.float16)     # 16-bit activations / weights
 # fp32 operands (OKP_F32X3, include/okp.h): fp32-grade results at a multiple of the exact-fp32 kernels' speed.  The mode is a property
 # of a PLAN (chosen when the plan is built); activations are plain torch.float32 tensors in both fp32 modes.
 F32X3 = "float32x3"
+# "float32mix": the sensitivity-guided mixed configuration on top of float32x3.  The skip stream (every tensor a residual / fire
+# module / merge hands on) stays fp32 and is multiplied with three terms; what reaches the output attenuated is computed cheaper:
+#   * the 3x3 convolutions INSIDE the residual blocks of the trunk (pre.1, pre.2, inters.0: conv1, conv2 - 70 % of the network's MACs,
+#     ~3 % of the fp16 error variance) multiply with the single term x_hi * w_hi (okp_conv_create_x3, tap_terms = 1);
+#   * the innermost MIX_FP16_LEVELS levels of both hourglasses (16 x 16 pixels and below: 1 % of the variance) run entirely in fp16 on
+#     the fused fp16 kernels, between two okp_cast launches.
+# tests/precision/attribute.py measures those shares on given weights (tests/golden/precision_attribution.json for the test network) and
+# tests/precision/emulate.py: mixed_policy() predicts the result on the CPU: heat error 3.9e-4 max on the test networks (bar 1e-3).
+F32MIX = "float32mix"
 F32_SPLIT = False       # plans built for torch.float32 while this is set are OKP_F32X3 plans (see f32_split())
+F32_MIX = False         # ... with single-term taps in the residual branches, and fp16 inner hourglass levels
+MIX_FP16_LEVELS = int(os.environ.get("OKP_MIX_FP16_LEVELS", "2"))    # hg_module levels n <= this run in fp16 (n = 2: the 16 x 16 level)
+MIX_BRANCH_SINGLE = os.environ.get("OKP_MIX_BRANCH_SINGLE", "1") == "1"
 
 
 class f32_split:
-    """Context manager: convolution plans built inside are split-product plans (KeypointNet(compute_dtype=ops.F32X3) wraps its passes in it)."""
+    """Context manager: convolution plans built inside are split-product plans (KeypointNet(compute_dtype=ops.F32X3 / ops.F32MIX) wraps
+    its passes in it)."""
 
-    def __init__(self, enabled=True):
-        self.enabled = bool(enabled)
+    def __init__(self, enabled=True, mixed=False):
+        self.enabled, self.mixed = bool(enabled), bool(enabled and mixed)
 
     def __enter__(self):
-        global F32_SPLIT
-        self.prev, F32_SPLIT = F32_SPLIT, self.enabled
+        global F32_SPLIT, F32_MIX
+        self.prev, F32_SPLIT, F32_MIX = (F32_SPLIT, F32_MIX), self.enabled, self.mixed
 
     def __exit__(self, *exc):
-        global F32_SPLIT
-        F32_SPLIT = self.prev
+        global F32_SPLIT, F32_MIX
+        F32_SPLIT, F32_MIX = self.prev
 
 
 def parse_compute_dtype(compute_dtype):
-    """-> (torch dtype of the activations, split-product flag) for torch.float32 / bfloat16 / float16 or ops.F32X3."""
+    """-> (torch dtype of the stream tensors, split-product flag, mixed flag) for torch.float32 / bfloat16 / float16, ops.F32X3 or ops.F32MIX."""
     if isinstance(compute_dtype, str):
         if compute_dtype.lower() in (F32X3, "f32x3"):
-            return torch.float32, True
+            return torch.float32, True, False
+        if compute_dtype.lower() in (F32MIX, "f32mix"):
+            return torch.float32, True, True
         compute_dtype = getattr(torch, compute_dtype, compute_dtype)
     if compute_dtype not in _DTYPES:
-        raise OkpError(f"unsupported compute dtype {compute_dtype}; use torch.float32, torch.bfloat16, torch.float16 or '{F32X3}'")
-    return compute_dtype, False
+        raise OkpError(f"unsupported compute dtype {compute_dtype}; use torch.float32, torch.bfloat16, torch.float16, '{F32X3}' or '{F32MIX}'")
+    return compute_dtype, False, False
 
 
 def okp_dtype(torch_dtype):
@@ -133,10 +148,12 @@ _NULL_TENSOR = _lib.okp_tensor(None, 0, 0, 0, 0)
 class ConvPlan:
     """One okp_conv plan.  taps: [(src, dy, dx, weight[cout, cin_src] float32)]."""
 
-    def __init__(self, dtype, cins, strides, cout, taps, bias=None, relu=False, alg_k=None):
+    def __init__(self, dtype, cins, strides, cout, taps, bias=None, relu=False, alg_k=None, tap_terms=None):
+        """tap_terms (split-product plans only): per tap 3 (three-term product, the default) or 1 (single fp16 term)."""
         L = _lib.lib()
         self.dtype = dtype
         self.split = bool(F32_SPLIT and dtype == torch.float32)      # OKP_F32X3: fp32 tensors, products on the fp16 matrix pipe
+        self.tap_terms = list(tap_terms) if (tap_terms is not None and self.split) else None
         self.cout = cout
         self.n_src = len(cins)
         self.cins = list(cins)
@@ -159,9 +176,15 @@ class ConvPlan:
                 raise OkpError("bias shape")
         cin_arr = (ctypes.c_int32 * 2)(*(list(cins) + [0])[:2])
         st_arr = (ctypes.c_int32 * 2)(*(list(strides) + [1])[:2])
-        self._h = L.okp_conv_create(OKP_F32X3 if self.split else okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t,
-                                    b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if b is not None else None,
-                                    ACT_RELU if relu else ACT_NONE)
+        bp = b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if b is not None else None
+        if self.tap_terms is not None:
+            if len(self.tap_terms) != n_taps:
+                raise OkpError("tap_terms: one entry per tap")
+            terms = (ctypes.c_uint8 * n_taps)(*self.tap_terms)
+            self._h = L.okp_conv_create_x3(self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, terms, bp, ACT_RELU if relu else ACT_NONE)
+        else:
+            self._h = L.okp_conv_create(OKP_F32X3 if self.split else okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, bp,
+                                        ACT_RELU if relu else ACT_NONE)
         if not self._h:
             raise OkpError("okp_conv_create: " + L.okp_last_error().decode())
 
@@ -293,6 +316,16 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     if stride == 2 and not FUSE_FIRE_S2:
         return False
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
+
+
+def cast(src, dtype):
+    """Act -> Act of another element type (okp_cast: fp32 <-> fp16 / bf16): the boundary of an fp16 sub-network inside the fp32 stream."""
+    if src.c0 != 0 or src.c != src.t.shape[3]:
+        raise OkpError("cast takes a whole tensor, not a channel window")
+    out = Act(torch.empty(src.t.shape, dtype=dtype, device=src.t.device))
+    _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(), stream_handle()), "okp_cast")
+    COUNTERS["launches"] += 1
+    return out
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):

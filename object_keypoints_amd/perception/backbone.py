@@ -77,7 +77,7 @@ class _HipModule(nn.Module):
     def _plan(self, key, build):
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
-        key = (key, ops.F32_SPLIT)          # fp32 plans exist in two forms: exact fp32 MFMAs / split products (ops.F32X3)
+        key = (key, ops.F32_SPLIT, ops.F32_MIX)   # fp32 plans exist in three forms: exact fp32 MFMAs / split products (ops.F32X3) / mixed
         p = self._plans.get(key)
         if p is None:
             p = build()
@@ -155,17 +155,23 @@ class residual(_HipModule):
                                   nn.BatchNorm2d(out_dim)) if self.projected else nn.Sequential()
 
     def _build(self, dtype):
+        # mixed configuration (ops.F32MIX): the two 3x3 convolutions of the branch multiply with ONE fp16 term, the projected skip
+        # (the path the stream takes) keeps three - see ops.F32MIX for the error budget behind this
+        single = ops.F32_MIX and ops.MIX_BRANCH_SINGLE and dtype == torch.float32
         w1, b1 = fold_bn(self.conv1.weight, self.bn1)
-        p1 = ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w1), b1, relu=True)
+        t1 = conv_taps(w1)
+        p1 = ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, t1, b1, relu=True, tap_terms=[1] * len(t1) if single else None)
         w2, b2 = fold_bn(self.conv2.weight, self.bn2)
         taps = conv_taps(w2)
+        terms = [1] * len(taps) if single else None
         if self.projected:
             # conv2 + projected skip + add + relu as ONE GEMM: the 1x1 skip is a tenth tap on a second source
             ws, bs = fold_bn(self.skip[0].weight, self.skip[1])
             taps = taps + [(1, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))]
-            p2 = ConvPlan(dtype, [self.out_dim, self.inp_dim], [1, self.stride], self.out_dim, taps, b2 + bs, relu=True)
+            p2 = ConvPlan(dtype, [self.out_dim, self.inp_dim], [1, self.stride], self.out_dim, taps, b2 + bs, relu=True,
+                          tap_terms=terms + [3] if single else None)
         else:
-            p2 = ConvPlan(dtype, [self.out_dim], [1], self.out_dim, taps, b2, relu=True)
+            p2 = ConvPlan(dtype, [self.out_dim], [1], self.out_dim, taps, b2, relu=True, tap_terms=terms)
         return p1, p2
 
     def forward(self, x):
@@ -357,6 +363,9 @@ class hg_module(nn.Module):
         """up1(x) and the whole low path are independent until the merge.  The low path is a long chain of small,
         latency-bound launches that leave most of the 256 CUs idle, so up1 runs on a side HIP stream and fills
         them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph)."""
+        if ops.F32_MIX and x.dtype == torch.float32 and self.n <= ops.MIX_FP16_LEVELS:
+            # mixed configuration: this level and everything below it run in fp16 on the fused fp16 kernels (ops.F32MIX)
+            return ops.cast(self.forward(ops.cast(x, torch.float16)), torch.float32)
         if not ops.SIDE_STREAMS or self.n < ops.SIDE_MIN_LEVEL or (x.n < ops.SIDE_MIN_BATCH and not torch.cuda.is_current_stream_capturing()):
             up1 = self.up1(x)
             low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)

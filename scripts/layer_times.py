@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from object_keypoints_amd import ops, synth
 from object_keypoints_amd.perception.models import KeypointNet
-dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": ops.F32X3}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": ops.F32X3, "f32mix": ops.F32MIX}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ops.SIDE_STREAMS = False
 net = KeypointNet(features=128, heatmaps_out=3, compute_dtype=dtype)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: profile_r03.sh <tag> [dtype]   (on the GPU box)  ->  gpurun_out/<tag>/   (dtype: bf16 (default) | f16 | f32 | f32x3)
+# usage: profile_r03.sh <tag> [dtype]   (on the GPU box)  ->  gpurun_out/<tag>/   (dtype: bf16 (default) | f16 | f32 | f32x3 | f32mix)
 # The rocprofv3 evidence behind one precision's `roofline` object of bench.py, from the SAME command with --dtype <dtype>:
 #   <p>kernel_stats.csv, <p>last_forward.txt, <p>bench_profiled.json   rocprofv3 --kernel-trace --stats
 #   <p>pmc_hbm_traffic.json        two separate --pmc passes (FETCH_SIZE / WRITE_SIZE)

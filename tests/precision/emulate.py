@@ -26,22 +26,37 @@ class Policy:
     names that are in neither dict.  Names are the module paths of oracle.net.KeypointNet ("backbone.pre.1", ...) with
     the suffixes below for tensors inside a fused block."""
 
-    def __init__(self, default=None, acts=None, weights=None, x3=False):
+    def __init__(self, default=None, acts=None, weights=None, x3=False, modes=None):
         self.default, self.acts, self.weights = default, dict(acts or {}), dict(weights or {})
         self.seen_acts, self.seen_weights = [], []
         self.x3 = x3                    # MFMA products as the three-term fp16 split of fp32 operands (activations stay fp32)
+        self.modes = modes              # optional callable(weight name) -> "x3" | "x1" | "f32": per-layer product mode on fp32 storage
+        self.act_rule = None            # optional callable(tensor name) -> dtype or None, consulted before `acts` / `default`
+        self.enter_rule = None          # optional callable(hg_module name) -> dtype or None: the module's input is cast on entry
+        self._last_weight = None
+
+    def enter(self, name, x):
+        return rnd(x, self.enter_rule(name)) if self.enter_rule is not None else x
 
     def conv(self, x, w, b, fn=F.conv2d, **kw):
-        return conv_x3(x, w, b, fn, **kw) if self.x3 else fn(x, w, b, **kw)
+        mode = self.modes(self._last_weight) if self.modes is not None else ("x3" if self.x3 else "f32")
+        if mode == "x3":
+            return conv_x3(x, w, b, fn, **kw)
+        if mode == "x1":                # single fp16 term: both operands rounded to fp16 for this product only (storage stays fp32)
+            return fn(rnd(x, torch.float16), rnd(w, torch.float16), b, **kw)
+        return fn(x, w, b, **kw)
 
     def act(self, name, t):
         if name not in self.seen_acts:
             self.seen_acts.append(name)
+        if self.act_rule is not None:
+            return rnd(t, self.act_rule(name))
         return rnd(t, self.acts.get(name, self.default))
 
     def weight(self, name, w):
         if name not in self.seen_weights:
             self.seen_weights.append(name)
+        self._last_weight = name        # (every p.weight() call is followed by the p.conv() that consumes it)
         return rnd(w, self.weights.get(name, self.default))
 
 
@@ -124,6 +139,7 @@ class EmuNet:
 
     def _hg_module(self, p, name, x, n, dims, modules):
         cur, nxt = dims[0], dims[1]
+        x = p.enter(name, x)              # an fp16 sub-network casts its input once (okp_cast): skip adds inside see the rounded values
         up1 = self._fires(p, f"{name}.up1", x, [(cur, cur)] * modules[0])
         low1 = self._fires(p, f"{name}.low1", x, [(cur, nxt)] + [(nxt, nxt)] * (modules[0] - 1), first_stride=2)
         if n > 1:
@@ -179,3 +195,37 @@ def build(heatmaps_out=3, weight_seed=0):
     from oracle import net as onet
     net = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=heatmaps_out), seed=weight_seed)
     return net, EmuNet(net)
+
+
+def mixed_policy(fp16_hourglass_levels=2, branch_single_term=True, fire_single_term_levels=0):
+    """The sensitivity-guided mixed configuration of the HIP path (KeypointNet(compute_dtype=ops.F32MIX)): fp32 storage of every
+    tensor of the skip stream, three-term products by default, and
+      * single-term fp16 products (operands rounded for that product only) in the 3x3 convolutions INSIDE the residual blocks of
+        the trunk (pre.1 / pre.2 / inters.0: conv1, conv2), whose outputs enter the stream through a BatchNorm-scaled branch;
+      * the innermost `fp16_hourglass_levels` levels of both hourglasses entirely in fp16 (storage and products).
+    tests/golden/precision_attribution.json prices both: the branch convolutions carry 57 % of the network's MACs and ~3 % of the
+    fp16 error variance, the hourglass levels at 16 x 16 and below 1 %."""
+    deep = ".low2" * (4 - fp16_hourglass_levels)             # hgs.i + ".low2" * k is the hg_module working at 64 / 2^k pixels
+
+    def in_deep(name):
+        return fp16_hourglass_levels > 0 and name.startswith("backbone.hgs.") and deep in name
+
+    def modes(w):
+        if in_deep(w):
+            return "x1"
+        if branch_single_term and any(w == f"backbone.{b}.{c}" for b in ("pre.1", "pre.2", "inters.0") for c in ("conv1", "conv2")):
+            return "x1"
+        return "x3"
+
+    def act_rule(name):
+        if in_deep(name):
+            return torch.float16
+        # a residual block's conv1 output is consumed by its single-term conv2 only: stored in fp16
+        if branch_single_term and name in ("backbone.pre.1.t", "backbone.pre.2.t", "backbone.inters.0.t"):
+            return torch.float16
+        return None
+
+    p = Policy(None, modes=modes)
+    p.act_rule = act_rule
+    p.enter_rule = lambda name: torch.float16 if in_deep(name) else None
+    return p

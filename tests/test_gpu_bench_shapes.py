@@ -282,3 +282,99 @@ def test_config5_stereo_stream_fp16_network_fp32_geometry():
         X_hat = tri(left2d[ok], right2d[match[ok]])
         d = np.linalg.norm(X_hat[:, None] - truth[pair][None], axis=2)
         assert d.min(axis=1).max() < 0.05, d.min(axis=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["conv3x3_64", "conv3x3_s2_128", "residual_s2_skip_128", "unpool_32_to_64"])
+def test_patch_kernel_at_batch64_against_cpu_convolution(case, dtype):
+    """The dominant kernel at the bench's batch of 64 against an INDEPENDENT reference: torch's fp32 CPU convolution of the same
+    (16-bit-rounded) operands on frames 0, 31 and 63 - stride 1 with residual, stride 2 (four parity-class patches), the fused
+    conv2 + strided 1x1 skip, and the transposed convolution's four sub-pixel classes with the merge add.  (The tile-13-equals-
+    tile-6 tests compare two kernels of this build with each other; this one does not.)"""
+    import torch.nn.functional as F
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception.backbone import conv_taps, unpool_merge
+    _need(dtype)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(dtype)
+    q = lambda a: torch.from_numpy(a).to(dtype).float()
+    rw = lambda name, shape, fan: synth.normal_like(name, shape, 60) / np.float32(np.sqrt(fan))
+    n, frames = 64, (0, 31, 63)
+    nchw = lambda t, i: t[i:i + 1].float().permute(0, 3, 1, 2).cpu()
+    if case == "unpool_32_to_64":
+        m = unpool_merge(256).eval()
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(rw("up2", (256, 256, 4, 4), 4 * 256))); m.bias.copy_(torch.from_numpy(synth.normal_like("up2b", (256,), 61) * np.float32(0.1)))
+        low, up1 = rnd(n, 32, 32, 256), rnd(n, 64, 64, 256)
+        ops.LAUNCH_HOOK = hook = _TileSpy()
+        try:
+            got = m(ops.Act(low), ops.Act(up1)).t
+        finally:
+            ops.LAUNCH_HOOK = None
+        assert hook.tiles == [13]
+        wq, bq = m.weight.detach().to(dtype).float(), m.bias.detach().float()
+        for i in frames:
+            ref = nchw(up1, i) + F.conv_transpose2d(nchw(low, i), wq, bq, stride=2, padding=1)
+            err = float((nchw(got, i) - ref).abs().max())
+            assert err <= (0.03 if dtype == torch.bfloat16 else 0.004) * (1.0 + float(ref.abs().max())), (i, err)
+        return
+    if case == "conv3x3_64":
+        h = w = 64
+        wt, b = rw("w64", (256, 256, 3, 3), 256 * 9), synth.normal_like("b64", (256,), 62) * np.float32(0.1)
+        plan = ops.ConvPlan(dtype, [256], [1], 256, conv_taps(wt), b, relu=True)
+        srcs, res = [rnd(n, h, w, 256)], rnd(n, h, w, 256)
+        ref_fn = lambda i: F.relu(F.conv2d(nchw(srcs[0], i), q(wt), torch.from_numpy(b), padding=1) + nchw(res, i))
+    elif case == "conv3x3_s2_128":
+        h = w = 128
+        wt, b = rw("ws2", (256, 128, 3, 3), 128 * 9), synth.normal_like("bs2", (256,), 63) * np.float32(0.1)
+        plan = ops.ConvPlan(dtype, [128], [2], 256, conv_taps(wt), b, relu=True)
+        srcs, res = [rnd(n, 2 * h, 2 * w, 128)], None
+        ref_fn = lambda i: F.relu(F.conv2d(nchw(srcs[0], i), q(wt), torch.from_numpy(b), stride=2, padding=1))
+    else:
+        h = w = 128
+        w2, ws = rw("w2", (256, 256, 3, 3), 256 * 9), rw("wskip", (256, 128, 1, 1), 128)
+        b = synth.normal_like("b2", (256,), 64) * np.float32(0.1)
+        taps = conv_taps(w2) + [(1, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))]
+        plan = ops.ConvPlan(dtype, [256, 128], [1, 2], 256, taps, b, relu=True)
+        srcs, res = [rnd(n, h, w, 256), rnd(n, 2 * h, 2 * w, 128)], None
+        ref_fn = lambda i: F.relu(F.conv2d(nchw(srcs[0], i), q(w2), torch.from_numpy(b), padding=1) + F.conv2d(nchw(srcs[1], i), q(ws), stride=2))
+    out = ops.Act.empty(n, h, w, 256, dtype, dev)
+    plan([ops.Act(s) for s in srcs], out, h, w, res=ops.Act(res) if res is not None else None, tile=13)
+    for i in frames:
+        ref = ref_fn(i)
+        err = float((nchw(out.t, i) - ref).abs().max())
+        assert err <= (0.03 if dtype == torch.bfloat16 else 0.004) * (1.0 + float(ref.abs().max())), (i, err)      # output rounding of O(1-5) values
+
+
+class _TileSpy:
+    def __init__(self):
+        self.tiles = []
+
+    def before(self, plan, tile, macs):
+        self.tiles.append(tile)
+
+    def after(self, token):
+        pass
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_heads_at_batch64_against_the_oracle(dtype):
+    """okp_heads at N=64 against the ORACLE's prediction modules (torch CPU fp32 on the same 16-bit-rounded input) on frames
+    0, 31 and 63: heat (post-sigmoid), depth and centre maps."""
+    from object_keypoints_amd import ops
+    from oracle import net as onet
+    _need(dtype)
+    net = _net(dtype, seed=3)
+    oracle = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=3), seed=3)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    cnv = (torch.randn((64, 64, 64, 256), generator=gen, device="cuda") * 0.7).to(dtype)
+    heat, depth, centers = net._run_heads(1, ops.Act(cnv), sigmoid=True)
+    tol = 0.02 if dtype == torch.bfloat16 else 0.003          # three 16-bit roundings (input, two hidden layers) of O(1) values
+    for i in (0, 31, 63):
+        x = cnv[i:i + 1].float().permute(0, 3, 1, 2).cpu()
+        with torch.no_grad():
+            rh = torch.sigmoid(oracle.heatmap_head.output_head2(x)); rd = oracle.depth_head.output_head2(x); rc = oracle.center_head.output_head2(x)
+        assert float((heat[i:i + 1].cpu() - rh).abs().max()) <= tol
+        assert float((depth[i:i + 1].cpu() - rd).abs().max()) <= tol * (1.0 + float(rd.abs().max()))
+        assert float((centers[i:i + 1].cpu().reshape(rc.shape) - rc).abs().max()) <= tol * (1.0 + float(rc.abs().max()))
