@@ -119,6 +119,12 @@ typedef struct okp_conv_args {
    * parity): with n_classes == 4 the plan's taps are four equal consecutive groups; class k uses group k only and
    * writes to (out_oy + k/2, out_ox + k%2) with out_step 2.  0 or 1 = off. */
   int32_t n_classes;
+  /* OKP_F32X3 plans only (the mixed configuration: fp32 stream, fp16 residual branches).  out16: optional fp16 view with the spatial
+   * mapping of `out` that receives the result rounded to fp16 as well (what a single-term consumer running on the fp16 kernels reads);
+   * with out16 given, out.data may be NULL (h, w, pix_stride still describe the output grid) and only the fp16 copy is written.
+   * res_is_f16 != 0: `res` is an fp16 tensor (a residual branch computed by the fp16 kernels).  Zero / NULL = off. */
+  okp_tensor out16;
+  int32_t res_is_f16;
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
@@ -172,6 +178,10 @@ int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride,
  * boundary between the fp32 skip stream and an fp16 sub-network in the mixed configuration (KeypointNet(compute_dtype="float32mix")
  * runs the innermost hourglass levels, modules.py:25-66, in fp16). */
 int okp_cast(int src_dtype, const void* src_dev, int dst_dtype, void* dst_dev, int64_t count, void* stream);
+
+/* out = act(a + b) on contiguous tensors of `count` elements, a fp16, b and out fp32: the closing add of a residual block whose branch
+ * ran on the fp16 kernels while the skip is the fp32 stream itself (residual without projection, py_utils/utils.py:184-185). */
+int okp_add_f16_f32(const void* a_f16_dev, const float* b_dev, float* out_dev, int64_t count, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Frame packing for the 7x7/s2 stem: NCHW fp32 (n,3,h,w) -> NHWC4 `dtype` with a zero halo,

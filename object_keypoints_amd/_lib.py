@@ -35,7 +35,7 @@ class okp_conv_args(Structure):
                 ("out_step", c_int32), ("out_oy", c_int32), ("out_ox", c_int32),
                 ("res", okp_tensor), ("tile", c_int32),
                 ("dw_w_dev", c_void_p), ("dw_bias_dev", c_void_p), ("dw_out", okp_tensor), ("dw_res", okp_tensor),
-                ("n_classes", c_int32)]
+                ("n_classes", c_int32), ("out16", okp_tensor), ("res_is_f16", c_int32)]
 
 
 class okp_fire_args(Structure):
@@ -64,6 +64,7 @@ SIGNATURES = [
     ("okp_conv_create_x3", c_void_p, [c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(ctypes.c_uint8), POINTER(c_float), c_int]),
     ("okp_conv_destroy", None, [c_void_p]),
     ("okp_cast", c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    ("okp_add_f16_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),

@@ -640,9 +640,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
           const int wo = rem - ho * p.Wo;
           opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
         }
-        const char* rp = static_cast<const char*>(p.res) + (opix * p.res_pix_stride + (ok ? co : 0)) * ESZ;
+        if (X3 && p.res16) {        // fp16 residual of an fp32 plan (the branch output of a residual block in the mixed configuration)
+          rres[u][0] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + (opix * p.res_pix_stride + (ok ? co : 0)) * 2);
+        } else {
+          const char* rp = static_cast<const char*>(p.res) + (opix * p.res_pix_stride + (ok ? co : 0)) * ESZ;
 #pragma unroll
-        for (int h = 0; h < CH8; ++h) rres[u][h] = *reinterpret_cast<const u32x4*>(rp + 16 * h);
+          for (int h = 0; h < CH8; ++h) rres[u][h] = *reinterpret_cast<const u32x4*>(rp + 16 * h);
+        }
       }
     }
 #pragma unroll
@@ -698,6 +702,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
                 const x8_t r8 = __builtin_bit_cast(x8_t, rres[u0 + u][0]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+              } else if (X3 && p.res16) {
+                const f16x8 r8 = __builtin_bit_cast(f16x8, rres[u0 + u][0]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
               } else {
                 const f32x4 ra = __builtin_bit_cast(f32x4, rres[u0 + u][0]), rb = __builtin_bit_cast(f32x4, rres[u0 + u][CH8 - 1]);
 #pragma unroll
@@ -708,7 +716,15 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            Io<T>::store8(v, op);
+            if (!X3 || p.out) Io<T>::store8(v, op);
+            if constexpr (X3) {
+              if (p.out16) {             // fp16 shadow of the result (what a single-term consumer on the fp16 kernels reads)
+                f16x8 o16;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o16[e] = (_Float16)v[e];
+                *reinterpret_cast<f16x8*>(static_cast<char*>(p.out16) + (opix * p.out16_pix_stride + co) * 2) = o16;
+              }
+            }
           }
         }
       }

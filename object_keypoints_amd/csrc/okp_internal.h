@@ -127,6 +127,8 @@ struct OkpIgemmParams {
   int32_t n_tiles;
   int32_t n_classes, tiles_per_class, slices_per_class;
   int32_t n_single_slices; // OKP_F32X3: leading single-term K-slices (the plan sorts them first)
+  void* out16;             // OKP_F32X3: optional fp16 copy of the result (same pixel mapping as out); out may then be NULL
+  int32_t out16_pix_stride, res16;   // res16: the residual tensor is fp16
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 

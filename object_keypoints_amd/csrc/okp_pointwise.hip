@@ -388,6 +388,38 @@ void launch_cast(const void* src, void* dst, long count, hipStream_t stream) {
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void okp_add_f16_f32_kernel(const _Float16* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n8, long count, int relu) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const long e0 = i * 8;
+    if (e0 + 8 <= count) {
+      const f16x8 av = *reinterpret_cast<const f16x8*>(a + e0);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + e0), b1 = *reinterpret_cast<const f32x4*>(b + e0 + 4);
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = (float)av[e] + b0[e]; o1[e] = (float)av[4 + e] + b1[e];
+        if (relu) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
+      }
+      *reinterpret_cast<f32x4*>(out + e0) = o0;
+      *reinterpret_cast<f32x4*>(out + e0 + 4) = o1;
+    } else {
+      for (long e = e0; e < count; ++e) { const float v = (float)a[e] + b[e]; out[e] = relu ? fmaxf(v, 0.f) : v; }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int okp_add_f16_f32(const void* a, const float* b, float* out, int64_t count, int act, void* stream) {
+  if (!a || !b || !out || count < 1) { okp_set_error("okp_add_f16_f32: null / empty argument"); return OKP_EINVAL; }
+  if (((uintptr_t)a) % 16 || ((uintptr_t)b) % 16 || ((uintptr_t)out) % 16) { okp_set_error("okp_add_f16_f32: tensors must be 16-byte aligned"); return OKP_EINVAL; }
+  if (act != OKP_ACT_NONE && act != OKP_ACT_RELU) { okp_set_error("okp_add_f16_f32: activation %d", act); return OKP_EINVAL; }
+  const long n8 = (count + 7) / 8;
+  const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
+  hipLaunchKernelGGL(okp_add_f16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, static_cast<const _Float16*>(a), b, out, n8, (long)count, act == OKP_ACT_RELU ? 1 : 0);
+  return okp_check_hip(hipGetLastError(), "okp_add_f16_f32 launch");
+}
+
 extern "C" int okp_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t count, void* stream) {
   if (!src || !dst || count < 1) { okp_set_error("okp_cast: null / empty argument"); return OKP_EINVAL; }
   if (((uintptr_t)src) % 16 || ((uintptr_t)dst) % 16) { okp_set_error("okp_cast: tensors must be 16-byte aligned"); return OKP_EINVAL; }

@@ -9,6 +9,7 @@
 //
 // Cost per launch from Python: one dispatcher call (~4 us) instead of ~20 us of ctypes struct filling.
 #include <ATen/ATen.h>
+#include <cstring>
 #include <torch/library.h>
 
 #include <vector>
@@ -62,6 +63,7 @@ void conv_forward(int64_t plan, const Tensor& src0, int64_t src0_c0, const optio
                   const optional<Tensor>& dw_w, const optional<Tensor>& dw_b, const optional<Tensor>& dw_out, int64_t dw_out_c0,
                   const optional<Tensor>& dw_res, int64_t dw_res_c0, int64_t stream) {
   okp_conv_args a;
+  std::memset(&a, 0, sizeof(a));
   a.n = (int32_t)out.size(0); a.ho = (int32_t)ho; a.wo = (int32_t)wo;
   a.src[0] = view(src0, src0_c0, "src[0]");
   a.src[1] = src1.has_value() ? view(*src1, src1_c0, "src[1]") : kNull;
@@ -87,6 +89,7 @@ int64_t conv_select_tile(int64_t plan, const Tensor& src0, int64_t src0_c0, cons
                          const Tensor& out, int64_t out_c0, int64_t ho, int64_t wo, int64_t out_step, int64_t oy, int64_t ox,
                          int64_t tile, int64_t n_classes, bool has_dw) {
   okp_conv_args a;
+  std::memset(&a, 0, sizeof(a));
   a.n = (int32_t)out.size(0); a.ho = (int32_t)ho; a.wo = (int32_t)wo;
   a.src[0] = view(src0, src0_c0, "src[0]");
   a.src[1] = src1.has_value() ? view(*src1, src1_c0, "src[1]") : kNull;

@@ -33,6 +33,11 @@ F32_SPLIT = False       # plans built for torch.float32 while this is set are OK
 F32_MIX = False         # ... with single-term taps in the residual branches, and fp16 inner hourglass levels
 MIX_FP16_LEVELS = int(os.environ.get("OKP_MIX_FP16_LEVELS", "2"))    # hg_module levels n <= this run in fp16 (n = 2: the 16 x 16 level)
 MIX_BRANCH_SINGLE = os.environ.get("OKP_MIX_BRANCH_SINGLE", "1") == "1"
+# ... and those single-term branches run on the fp16 kernels proper (the patch-resident 3x3 kernel: half the bytes, no in-loop conversion):
+# the producer of a stream tensor writes an fp16 copy next to it (okp_conv_args.out16), conv1 / conv2 are fp16 plans, and the block
+# closes with the three-term projected skip taking the fp16 branch as its residual (or okp_add_f16_f32).  0 = single-term taps of the
+# split-product kernel on the fp32 tensors (same products, slower).
+MIX_BRANCH_FP16 = os.environ.get("OKP_MIX_BRANCH_FP16", "1") == "1"
 
 
 class f32_split:
@@ -102,10 +107,11 @@ def require_cuda(t, what):
 class Act:
     """NHWC activation view: a contiguous device tensor [N,H,W,Ctot] and a channel window."""
 
-    __slots__ = ("t", "c0", "c", "orig_hw")
+    __slots__ = ("t", "c0", "c", "orig_hw", "shadow")
 
     def __init__(self, t, c0=0, c=None):
         self.orig_hw = None          # set by pack_frames: (H, W) of the un-padded frame
+        self.shadow = None           # mixed configuration: fp16 copy of an fp32 stream tensor, written by its producer (ConvPlan(out16=...))
         require_cuda(t, "activation")
         if t.dim() != 4 or not t.is_contiguous():
             raise OkpError("activation must be a contiguous [N,H,W,C] tensor")
@@ -196,17 +202,27 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
-    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1):
-        """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch."""
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True):
+        """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch.
+        Split-product plans: out16 = fp16 Act that receives the result as well (write_out=False: only that copy is written; `out` then
+        only describes the grid), and `res` may be an fp16 tensor (okp_conv_args.out16 / res_is_f16)."""
         for s in srcs:
             if s.dtype != self.dtype:
                 raise OkpError("source dtype differs from plan dtype")
         if out.dtype != self.dtype or out.c != self.cout:
             raise OkpError(f"out has {out.c} channels / {out.dtype}, plan has {self.cout} / {self.dtype}")
+        res16 = res is not None and self.split and res.dtype == torch.float16
+        if (out16 is not None or res16 or not write_out) and not self.split:
+            raise OkpError("out16 / fp16 residual / write_out=False belong to split-product (ops.F32X3) plans")
+        if out16 is not None and (out16.dtype != torch.float16 or out16.c != self.cout):
+            raise OkpError("out16 must be a float16 activation with the plan's output channels")
+        if not write_out and out16 is None:
+            raise OkpError("write_out=False needs out16")
+        extended = out16 is not None or res16
         macs = out.n * ho * wo * self.cout * self.alg_k
         macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
         tile = tile or FORCE_TILE
-        T = _lib.torch_ops()
+        T = _lib.torch_ops() if not extended else None       # (the dispatcher shim carries the common arguments; the ctypes binding all)
         hook = LAUNCH_HOOK
         if T is not None:
             s1 = srcs[1] if len(srcs) > 1 else None
@@ -230,6 +246,11 @@ class ConvPlan:
             for i, s in enumerate(srcs):
                 a.src[i] = s.view()
             a.out = out.view()
+            if not write_out:
+                a.out.data = None
+            if out16 is not None:
+                a.out16 = out16.view()
+            a.res_is_f16 = 1 if res16 else 0
             a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
             a.res = res.view() if res is not None else _NULL_TENSOR
             a.tile = tile
@@ -324,6 +345,16 @@ def cast(src, dtype):
         raise OkpError("cast takes a whole tensor, not a channel window")
     out = Act(torch.empty(src.t.shape, dtype=dtype, device=src.t.device))
     _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(), stream_handle()), "okp_cast")
+    COUNTERS["launches"] += 1
+    return out
+
+
+def add_f16_f32(a16, b32, relu=True):
+    """relu(a + b): a an fp16 Act, b an fp32 Act of the same shape -> fp32 Act (okp_add_f16_f32)."""
+    if a16.dtype != torch.float16 or b32.dtype != torch.float32 or a16.t.shape != b32.t.shape or a16.c0 or b32.c0 or a16.c != a16.t.shape[3] or b32.c != b32.t.shape[3]:
+        raise OkpError("add_f16_f32 takes whole float16 / float32 tensors of one shape")
+    out = Act(torch.empty_like(b32.t))
+    _lib.check(_lib.lib().okp_add_f16_f32(a16.t.data_ptr(), b32.t.data_ptr(), out.t.data_ptr(), out.t.numel(), ACT_RELU if relu else ACT_NONE, stream_handle()), "okp_add_f16_f32")
     COUNTERS["launches"] += 1
     return out
 

@@ -113,18 +113,18 @@ class convolution(_HipModule):
             return ConvPlan(dtype, [32], [2], self.out_dim, taps, b, relu=True, alg_k=147)
         return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
 
-    def forward_frames(self, frames, dtype):
+    def forward_frames(self, frames, dtype, shadow=False):
         """The stem on raw fp32 NCHW frames.  bf16: one launch of the dedicated kernel reading the frames directly;
-        otherwise pack (ops.pack_frames) + the generic path."""
+        otherwise pack (ops.pack_frames) + the generic path.  shadow (split-product plans): also write the fp16 copy."""
         if self.inp_dim == 3 and dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
             plan = self._plan(("p", dtype), lambda: self._build(dtype))
             n, _, h, w = frames.shape
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
             plan.from_nchw(frames, out)
             return out
-        return self.forward(ops.pack_frames(frames, dtype))
+        return self.forward(ops.pack_frames(frames, dtype), shadow=shadow)
 
-    def forward(self, x):
+    def forward(self, x, shadow=False):
         plan = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         if self.inp_dim == 3:       # x is the packed frame tensor [N, H+6, Wp, 4]
             if x.orig_hw is None:
@@ -137,7 +137,9 @@ class convolution(_HipModule):
         if isinstance(plan, StemPlan):
             plan(x, out)
         else:
-            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0)
+            if shadow and plan.split:
+                out.shadow = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, x.t.device)
+            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0, out16=out.shadow)
         return out
 
 
@@ -174,7 +176,42 @@ class residual(_HipModule):
             p2 = ConvPlan(dtype, [self.out_dim], [1], self.out_dim, taps, b2, relu=True, tap_terms=terms)
         return p1, p2
 
-    def forward(self, x):
+    def _build_mixed16(self):
+        """Mixed configuration with the branch on the fp16 kernels (ops.MIX_BRANCH_FP16): conv1 and conv2 as fp16 plans (conv2 without
+        the closing ReLU: its rounded output is the residual of what follows), the projected skip as a three-term plan of its own."""
+        w1, b1 = fold_bn(self.conv1.weight, self.bn1)
+        p1 = ConvPlan(torch.float16, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w1), b1, relu=True)
+        w2, b2 = fold_bn(self.conv2.weight, self.bn2)
+        p2 = ConvPlan(torch.float16, [self.out_dim], [1], self.out_dim, conv_taps(w2), b2, relu=False)
+        ps = None
+        if self.projected:
+            ws, bs = fold_bn(self.skip[0].weight, self.skip[1])
+            ps = ConvPlan(torch.float32, [self.inp_dim], [self.stride], self.out_dim, [(0, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))], bs, relu=True)
+        return p1, p2, ps
+
+    def _forward_mixed16(self, x, shadow):
+        p1, p2, ps = self._plan(("mix16",), self._build_mixed16)
+        ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
+        dev = x.t.device
+        x16 = x.shadow if x.shadow is not None else ops.cast(x, torch.float16)      # (the producer wrote the copy when it knew of this consumer)
+        t16 = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
+        p1([x16], t16, ho, wo)
+        b16 = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
+        p2([t16], b16, ho, wo)
+        if ps is not None:
+            out = Act.empty(x.n, ho, wo, self.out_dim, torch.float32, dev)
+            if shadow:
+                out.shadow = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
+            ps([x], out, ho, wo, res=b16, out16=out.shadow)        # relu(skip(x) + branch): three terms on the stream, fp16 residual
+        else:
+            out = ops.add_f16_f32(b16, x, relu=True)
+            if shadow:
+                out.shadow = ops.cast(out, torch.float16)
+        return out
+
+    def forward(self, x, shadow=False):
+        if ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16 and x.dtype == torch.float32:
+            return self._forward_mixed16(x, shadow)
         p1, p2 = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
         t = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
@@ -431,13 +468,14 @@ class hg(_HipModule):
     def forward(self, x, dtype=None):
         """x: packed frames (ops.pack_frames), or raw fp32 NCHW frames with the compute dtype given (the stem then reads
         them itself where it can).  Returns [cnv0, cnv1] as NHWC activations."""
+        # mixed configuration with fp16 branches: producers write the fp16 copy their consumer's conv1 reads (stem -> pre.1, pre.1 -> pre.2)
+        mix16 = ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16
         if isinstance(x, torch.Tensor):
-            inter = self.pre[0].forward_frames(x, dtype)
-            rest = list(self.pre)[1:]
+            inter = self.pre[0].forward_frames(x, dtype, shadow=mix16 and dtype == torch.float32)
         else:
-            inter, rest = x, list(self.pre)
-        for m in rest:
-            inter = m(inter)
+            inter = self.pre[0](x, shadow=mix16 and x.dtype == torch.float32)
+        inter = self.pre[1](inter, shadow=mix16)
+        inter = self.pre[2](inter)
         cnvs = []
         last = len(self.hgs) - 1
         for i, (hg_, cnv_) in enumerate(zip(self.hgs, self.cnvs)):
@@ -446,6 +484,8 @@ class hg(_HipModule):
             if i < last:
                 merge = self._plan(("m", i, inter.dtype), lambda: self._build_merge(i, inter.dtype))
                 merged = Act.empty(inter.n, inter.h, inter.w, 256, inter.dtype, inter.t.device)
-                merge([inter, cnv], merged, inter.h, inter.w)
+                if mix16 and merge.split:
+                    merged.shadow = Act.empty(inter.n, inter.h, inter.w, 256, torch.float16, inter.t.device)
+                merge([inter, cnv], merged, inter.h, inter.w, out16=merged.shadow)
                 inter = self.inters[i](merged)
         return cnvs

@@ -38,6 +38,11 @@ class Policy:
     def enter(self, name, x):
         return rnd(x, self.enter_rule(name)) if self.enter_rule is not None else x
 
+    def branch(self, name, y):
+        """Output of a residual block's conv2 (+ bn2) before the skip is added: fp32 accumulators in the fused kernels, an fp16 tensor
+        where the branch runs on the fp16 kernels (mixed configuration)."""
+        return rnd(y, self.branch_dtype) if getattr(self, "branch_dtype", None) is not None else y
+
     def conv(self, x, w, b, fn=F.conv2d, **kw):
         mode = self.modes(self._last_weight) if self.modes is not None else ("x3" if self.x3 else "f32")
         if mode == "x3":
@@ -107,7 +112,7 @@ class EmuNet:
         w1, b1 = _fold(sd[f"{name}.conv1.weight"], f"{name}.bn1", name, sd)
         t = p.act(f"{name}.t", F.relu(p.conv(x, p.weight(f"{name}.conv1", w1), b1, stride=stride, padding=1)))
         w2, b2 = _fold(sd[f"{name}.conv2.weight"], f"{name}.bn2", name, sd)
-        y = p.conv(t, p.weight(f"{name}.conv2", w2), b2, padding=1)
+        y = p.branch(name, p.conv(t, p.weight(f"{name}.conv2", w2), b2, padding=1))
         if f"{name}.skip.0.weight" in sd:
             ws, bs = _fold(sd[f"{name}.skip.0.weight"], f"{name}.skip.1", name, sd)
             y = y + p.conv(x, p.weight(f"{name}.skip", ws), bs, stride=stride)
@@ -228,4 +233,5 @@ def mixed_policy(fp16_hourglass_levels=2, branch_single_term=True, fire_single_t
     p = Policy(None, modes=modes)
     p.act_rule = act_rule
     p.enter_rule = lambda name: torch.float16 if in_deep(name) else None
+    p.branch_dtype = torch.float16 if branch_single_term else None
     return p

@@ -297,3 +297,46 @@ def test_mixed_network_meets_the_heat_bar_and_matches_its_cpu_model(name):
         c = {tuple(p) for p in gyx[0, k, :int(gcount[0, k])].cpu().numpy().tolist()}
         inter += len(a & c); union += len(a | c)
     assert inter / union >= 0.99
+
+
+def test_fp16_residual_and_fp16_shadow_output_of_a_split_plan():
+    """The closing launch of a residual block in the mixed configuration: relu(skip(x) + branch) with the three-term skip on the
+    fp32 stream, the branch as an fp16 residual (okp_conv_args.res_is_f16), the result written in fp32 and - for the next block's
+    conv1 - in fp16 (okp_conv_args.out16); with write_out=False only the fp16 copy is written."""
+    from object_keypoints_amd import ops
+    dev = torch.device("cuda:0")
+    n, cin, cout, h, w = 2, 64, 128, 12, 20
+    x = _rand((n, cin, 2 * h, 2 * w), 61)
+    ws = _rand((cout, cin, 1, 1), 62) / np.sqrt(cin)
+    b = _rand((cout,), 63) * 0.1
+    br = (_rand((n, cout, h, w), 64) * 0.5).half()
+    ref = F.relu(F.conv2d(x.double(), ws.double(), b.double(), stride=2) + br.double()).float()
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [cin], [2], cout, [(0, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))], b.numpy(), relu=True)
+    xa = ops.Act.from_nchw(x.to(dev), torch.float32)
+    ra = ops.Act(br.permute(0, 2, 3, 1).contiguous().to(dev))
+    for tile in (1, 2, 3):
+        out = ops.Act(torch.full((n, h, w, cout), -5.0, dtype=torch.float32, device=dev))
+        o16 = ops.Act(torch.zeros((n, h, w, cout), dtype=torch.float16, device=dev))
+        plan([xa], out, h, w, res=ra, out16=o16, tile=tile)
+        got = out.to_nchw().cpu()
+        assert float((got - ref).abs().max()) <= _tol(ref), tile
+        assert torch.equal(o16.t.cpu(), out.t.cpu().half())                  # the copy is the fp16 rounding of what was stored
+        out2 = ops.Act(torch.full((n, h, w, cout), -5.0, dtype=torch.float32, device=dev))
+        o16b = ops.Act(torch.zeros((n, h, w, cout), dtype=torch.float16, device=dev))
+        plan([xa], out2, h, w, res=ra, out16=o16b, write_out=False, tile=tile)
+        assert torch.equal(o16b.t, o16.t) and bool((out2.t == -5.0).all())   # fp32 output untouched
+    with pytest.raises(ops.OkpError):
+        p32 = ops.ConvPlan(torch.float32, [cin], [2], cout, [(0, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))], b.numpy(), relu=True)
+        p32([xa], out, h, w, out16=o16)                                       # exact-fp32 plans have no fp16 side output
+
+
+def test_add_f16_f32():
+    from object_keypoints_amd import ops
+    dev = torch.device("cuda:0")
+    a = (_rand((2, 5, 7, 24), 71)).half().to(dev)
+    b = _rand((2, 5, 7, 24), 72).to(dev)
+    got = ops.add_f16_f32(ops.Act(a), ops.Act(b), relu=True)
+    assert torch.equal(got.t, torch.relu(a.float() + b))
+    got = ops.add_f16_f32(ops.Act(a), ops.Act(b), relu=False)
+    assert torch.equal(got.t, a.float() + b)
