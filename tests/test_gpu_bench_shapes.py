@@ -17,6 +17,8 @@ CALIB = os.path.join(REPO, "config", "calibration.yaml")
 
 def _need(dtype):
     from object_keypoints_amd import ops
+    if isinstance(dtype, str):
+        return
     if dtype not in ops._DTYPES:
         pytest.skip(f"{dtype} is not built into this library")
 
@@ -37,13 +39,13 @@ def _frames(n, seed=77):
     return torch.randn((n, 3, 511, 511), generator=gen, device="cuda", dtype=torch.float32)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, "float32x3", "float32mix"])
 def test_batch64_frame_independence_and_side_stream_determinism(dtype):
     """(a) two eager runs of the 64-frame step with the side streams on are bit-equal; (b) a frame gives the same bits
     wherever it sits in the batch (the batch reversed); (c) frames 0, 17, 63 give the bits they give when run alone."""
     from object_keypoints_amd import ops
     net = _net(dtype)
-    x = _frames(64)
+    x = _frames(64)                     # (the fp32-storage configurations run it as two passes of 32 frames: the 2 GiB view limit)
     assert ops.SIDE_STREAMS
     with torch.no_grad():
         a = [t.clone() for t in net.deployed(x)]
@@ -151,17 +153,19 @@ def test_fused_heads_at_bench_batch(dtype):
         assert float((a - b).abs().max()) <= 2e-2 * scale + 2e-3
 
 
-@pytest.mark.parametrize("side", [False, True])
-def test_graph_replay_equals_eager_at_batch64(side):
-    """hipGraph replays of the 64-frame bf16 step are bit-equal to the eager step, five replays in a row, with the
-    hourglass branches captured serially (default) and forked onto side streams."""
+@pytest.mark.parametrize("side,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (True, "float32mix")])
+def test_graph_replay_equals_eager_at_batch64(side, dtype):
+    """hipGraph replays of the 64-frame step are bit-equal to the eager step, five replays in a row, with the hourglass branches
+    captured serially and forked onto side streams (bf16), and for the mixed configuration (fp16 sub-networks, casts and fp16 side
+    outputs inside the capture; 32 frames: one pass)."""
     from object_keypoints_amd.perception import pipeline as pp
     from object_keypoints_amd.perception.utils import camera_utils as cu
     from oracle import pipeline as op
-    net = _net(torch.bfloat16)
+    net = _net(dtype)
     cam_o = op.eval_camera(CALIB)
     pipe = pp.BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size), capacity=128)
-    x0, x1 = _frames(64, seed=1), _frames(64, seed=2)
+    nfr = 32 if isinstance(dtype, str) else 64
+    x0, x1 = _frames(nfr, seed=1), _frames(nfr, seed=2)
     keep = pp.GRAPH_SIDE_STREAMS
     pp.GRAPH_SIDE_STREAMS = side
     try:

@@ -98,6 +98,33 @@ def test_learned_pipeline_from_a_model_file(kind, oracle_case, tmp_path):
         assert len(o["p_centers"]) == len(w["p_centers"])
 
 
+@pytest.mark.parametrize("mode,kp_tol,pc_tol", [("float32x3", 1e-3, 1e-4), ("float32mix", 2e-2, 5e-3)])
+def test_learned_pipeline_in_the_split_product_configurations(mode, kp_tol, pc_tol, oracle_case, tmp_path):
+    """The reference's production sequence with compute_dtype="float32x3" (the fp32 configuration's bars: heat 1e-3, key points
+    1e-3 px, 3D points 1e-4 m) and "float32mix" (heat 1e-3; centroids and depth follow the 4e-4 heat / 2e-3 depth error)."""
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    c = oracle_case
+    path = _model_file("state_dict", c["net"], tmp_path)
+    pipeline = pp.LearnedKeypointTrackingPipeline(path, True, [64, 64], None, CFG, compute_dtype=mode)
+    cam = c["camera"]
+    pipeline.reset(cu.FisheyeCamera(cam.K, cam.D, cam.image_size))
+    objects, heatmap = pipeline(c["frame"])
+    assert float((heatmap - c["heat"]).abs().max()) <= 1e-3
+    want = c["objects"]
+    assert len(objects) == len(want) > 0
+    for o, w in zip(objects, want):
+        for a, b in zip(o["keypoints"], w["keypoints"]):
+            a, b = np.asarray(a), np.asarray(b)
+            assert a.shape == b.shape
+            if a.size:
+                np.testing.assert_allclose(a, b, rtol=0, atol=kp_tol)
+        for a, b in zip(o["p_C"], w["p_C"]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                np.testing.assert_allclose(a, b, rtol=0, atol=pc_tol)
+
+
 def test_inference_component_from_a_model_file(oracle_case, tmp_path):
     from object_keypoints_amd.perception import pipeline as pp
     c = oracle_case
