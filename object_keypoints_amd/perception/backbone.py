@@ -189,7 +189,7 @@ class residual(_HipModule):
             ps = ConvPlan(torch.float32, [self.inp_dim], [self.stride], self.out_dim, [(0, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))], bs, relu=True)
         return p1, p2, ps
 
-    def _forward_mixed16(self, x, shadow):
+    def _forward_mixed16(self, x, shadow, out=None, out_shadow=None):
         p1, p2, ps = self._plan(("mix16",), self._build_mixed16)
         ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
         dev = x.t.device
@@ -199,24 +199,30 @@ class residual(_HipModule):
         b16 = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
         p2([t16], b16, ho, wo)
         if ps is not None:
-            out = Act.empty(x.n, ho, wo, self.out_dim, torch.float32, dev)
+            if out is None:
+                out = Act.empty(x.n, ho, wo, self.out_dim, torch.float32, dev)
             if shadow:
-                out.shadow = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
+                out.shadow = out_shadow if out_shadow is not None else Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
             ps([x], out, ho, wo, res=b16, out16=out.shadow)        # relu(skip(x) + branch): three terms on the stream, fp16 residual
         else:
+            if out is not None:
+                raise OkpError("residual: a caller-provided destination is supported for projected blocks only")
             out = ops.add_f16_f32(b16, x, relu=True)
             if shadow:
                 out.shadow = ops.cast(out, torch.float16)
         return out
 
-    def forward(self, x, shadow=False):
+    def forward(self, x, shadow=False, out=None, out_shadow=None):
+        """out / out_shadow: optional destination (an Act over a frame range of a larger tensor) of the block's result and of its fp16
+        copy - hg.forward runs the two high-resolution layers in frame chunks and the rest of the network in one pass."""
         if ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16 and x.dtype == torch.float32:
-            return self._forward_mixed16(x, shadow)
+            return self._forward_mixed16(x, shadow, out, out_shadow)
         p1, p2 = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
         t = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
         p1([x], t, ho, wo)
-        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        if out is None:
+            out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
         if self.projected:
             p2([t, x], out, ho, wo)
         else:
@@ -458,6 +464,16 @@ class hg(_HipModule):
         self.inters_ = nn.ModuleList([_MergeMod() for _ in range(stacks - 1)])
         self.cnvs_ = nn.ModuleList([_MergeMod() for _ in range(stacks - 1)])
 
+    @staticmethod
+    def front_chunk(n, h, w, dtype):
+        """Frames per launch of the stem and pre[1] such that the stem output stays under the 2 GiB view limit (include/okp.h), in
+        equal chunks."""
+        esz = 2 if dtype in ops.HALF_DTYPES else 4
+        per_frame = conv_out_size(h, 7, 2, 3) * conv_out_size(w, 7, 2, 3) * 128 * esz
+        limit = max(1, (0x7FFF0000 - 1) // per_frame)
+        parts = -(-n // limit)
+        return -(-n // parts)
+
     def _build_merge(self, i, dtype):
         # relu(inters_[i](inter) + cnvs_[i](cnv)): two 1x1+BN summed = one GEMM over two sources
         wa, ba = fold_bn(self.inters_[i][0].weight, self.inters_[i][1])
@@ -471,10 +487,36 @@ class hg(_HipModule):
         # mixed configuration with fp16 branches: producers write the fp16 copy their consumer's conv1 reads (stem -> pre.1, pre.1 -> pre.2)
         mix16 = ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16
         if isinstance(x, torch.Tensor):
-            inter = self.pre[0].forward_frames(x, dtype, shadow=mix16 and dtype == torch.float32)
+            n, (fh, fw), sdtype = x.shape[0], x.shape[2:4], dtype
+            stem = lambda c0, c1, sh: self.pre[0].forward_frames(x[c0:c1], dtype, shadow=sh)
+        else:                                   # packed frames (ops.pack_frames / pack_frames_u8 / preprocess_u8)
+            n, (fh, fw), sdtype = x.n, x.orig_hw, x.dtype
+
+            def stem(c0, c1, sh):
+                xi = Act(x.t[c0:c1])
+                xi.orig_hw = x.orig_hw
+                return self.pre[0](xi, shadow=sh)
+        want_shadow = mix16 and sdtype == torch.float32
+        chunk = self.front_chunk(n, fh, fw, sdtype)
+        if chunk < n:
+            # fp32 tensors: the stem output (128 channels at half resolution, 33.5 MB per frame) of a whole batch would pass the 2 GiB
+            # view limit of the 32-bit buffer offsets.  Only the stem and pre[1] see that resolution: they run per frame chunk and
+            # pre[1] writes straight into its range of the full batch's tensor; everything behind it runs in ONE pass (the chains of
+            # small launches in the hourglasses cost the same for 32 frames as for 64).
+            inter = None
+            for c0 in range(0, n, chunk):
+                c1 = min(n, c0 + chunk)
+                a = stem(c0, c1, want_shadow)
+                if inter is None:
+                    r = self.pre[1]
+                    ho, wo = conv_out_size(a.h, r.k, r.stride, r.pad), conv_out_size(a.w, r.k, r.stride, r.pad)
+                    inter = Act.empty(n, ho, wo, r.out_dim, sdtype, a.t.device)
+                    if want_shadow:
+                        inter.shadow = Act.empty(n, ho, wo, r.out_dim, torch.float16, a.t.device)
+                sh = Act(inter.shadow.t[c0:c1]) if inter.shadow is not None else None
+                self.pre[1](a, shadow=sh is not None, out=Act(inter.t[c0:c1]), out_shadow=sh)
         else:
-            inter = self.pre[0](x, shadow=mix16 and x.dtype == torch.float32)
-        inter = self.pre[1](inter, shadow=mix16)
+            inter = self.pre[1](stem(0, n, want_shadow), shadow=mix16)
         inter = self.pre[2](inter)
         cnvs = []
         last = len(self.hgs) - 1

@@ -159,10 +159,13 @@ class KeypointNet(_HipModule):
         return self.backbone(x.float(), self.compute_dtype)
 
     def max_frames_per_pass(self, h, w):
-        """Frames per launch sequence such that the largest activation (the stem output, 128 channels at half
-        resolution) stays under the 2 GiB view limit of the 32-bit buffer offsets (include/okp.h)."""
+        """Frames per network pass such that the largest activation behind the two high-resolution layers (pre[1]'s output, 256
+        channels at quarter resolution - as many bytes per frame as the 16-bit stem output) stays under the 2 GiB view limit of the
+        32-bit buffer offsets (include/okp.h).  The stem and pre[1] themselves run in frame chunks inside a pass where the fp32 stem
+        output would pass the limit (hg.forward)."""
         esz = 2 if self.compute_dtype in ops.HALF_DTYPES else 4
-        per_frame = ((h + 1) // 2) * ((w + 1) // 2) * 128 * esz
+        h2, w2 = (h + 1) // 2, (w + 1) // 2
+        per_frame = max(h2 * w2 * 128 * 2, ((h2 + 1) // 2) * ((w2 + 1) // 2) * 256 * esz)
         return max(1, (0x7FFF0000 - 1) // per_frame)
 
     def _chunks(self, x):
