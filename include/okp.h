@@ -125,6 +125,11 @@ typedef struct okp_conv_args {
    * res_is_f16 != 0: `res` is an fp16 tensor (a residual branch computed by the fp16 kernels).  Zero / NULL = off. */
   okp_tensor out16;
   int32_t res_is_f16;
+  /* out_subsample == 2 (needs out16, out_step 1): the fp32 result is kept at even rows and columns of the output grid only, `out` being a
+   * tensor of ceil(ho / 2) x ceil(wo / 2) pixels; out16 (and res) keep the full grid.  For a stream tensor whose only fp32 reader is the
+   * stride-2 projected skip of the next residual block (py_utils/utils.py:177-185: stem -> pre[1], pre[1] -> pre[2]) while the block's
+   * conv1 reads the fp16 copy: three quarters of the fp32 bytes are never read. */
+  int32_t out_subsample;
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);

@@ -35,7 +35,7 @@ class okp_conv_args(Structure):
                 ("out_step", c_int32), ("out_oy", c_int32), ("out_ox", c_int32),
                 ("res", okp_tensor), ("tile", c_int32),
                 ("dw_w_dev", c_void_p), ("dw_bias_dev", c_void_p), ("dw_out", okp_tensor), ("dw_res", okp_tensor),
-                ("n_classes", c_int32), ("out16", okp_tensor), ("res_is_f16", c_int32)]
+                ("n_classes", c_int32), ("out16", okp_tensor), ("res_is_f16", c_int32), ("out_subsample", c_int32)]
 
 
 class okp_fire_args(Structure):

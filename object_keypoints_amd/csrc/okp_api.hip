@@ -384,20 +384,26 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   const bool x3 = plan->dtype == OKP_F32X3;
   if ((a->out16.data || a->res_is_f16) && !x3) { okp_set_error("okp_conv_forward: out16 / res_is_f16 belong to OKP_F32X3 plans"); return OKP_EINVAL; }
   if ((a->out16.data || a->res_is_f16) && (a->dw_w_dev)) { okp_set_error("okp_conv_forward: out16 / res_is_f16 cannot be combined with the depth-wise branch"); return OKP_EINVAL; }
+  const bool sub2 = a->out_subsample == 2;
+  if (a->out_subsample != 0 && a->out_subsample != 1 && !sub2) { okp_set_error("okp_conv_forward: out_subsample %d (0, 1 or 2)", a->out_subsample); return OKP_EINVAL; }
+  if (sub2 && (!x3 || !a->out16.data || a->out_step != 1 || a->out_oy || a->out_ox || a->n_classes > 1 || a->dw_w_dev ||
+               a->out16.h != a->ho || a->out16.w != a->wo || a->out.h != (a->ho + 1) / 2 || a->out.w != (a->wo + 1) / 2)) {
+    okp_set_error("okp_conv_forward: out_subsample 2 needs an OKP_F32X3 plan, a full-grid out16, out_step 1 and out of ceil(ho/2) x ceil(wo/2) pixels"); return OKP_EINVAL;
+  }
   if (a->out16.data) {
     if (int e = check_view("out16", a->out16, 2, true)) return e;
-    if (a->out16.h != a->out.h || a->out16.w != a->out.w || a->out16.pix_stride < plan->cout) { okp_set_error("okp_conv_forward: out16 does not match out"); return OKP_EINVAL; }
+    if ((!sub2 && (a->out16.h != a->out.h || a->out16.w != a->out.w)) || a->out16.pix_stride < plan->cout) { okp_set_error("okp_conv_forward: out16 does not match out"); return OKP_EINVAL; }
     if (!a->out.data && (a->out.h < 1 || a->out.w < 1 || a->out.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out (data NULL) must still describe the output grid"); return OKP_EINVAL; }
   }
   if (a->out.data || !a->out16.data) { if (int e = check_view("out", a->out, esz, true)) return e; }
   if (int e = check_view("res", a->res, a->res_is_f16 ? 2 : esz, false)) return e;
   if (a->out_step < 1 || a->out_oy < 0 || a->out_ox < 0 ||
-      (a->ho - 1) * a->out_step + a->out_oy >= a->out.h || (a->wo - 1) * a->out_step + a->out_ox >= a->out.w) {
+      (!sub2 && ((a->ho - 1) * a->out_step + a->out_oy >= a->out.h || (a->wo - 1) * a->out_step + a->out_ox >= a->out.w))) {
     okp_set_error("okp_conv_forward: output grid %dx%d (step %d, offset %d,%d) does not fit out %dx%d", a->ho, a->wo, a->out_step, a->out_oy, a->out_ox, a->out.h, a->out.w);
     return OKP_EINVAL;
   }
   if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
-  if (a->res.data && (a->res.h != a->out.h || a->res.w != a->out.w)) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
+  if (a->res.data && (a->res.h != (sub2 ? a->out16.h : a->out.h) || a->res.w != (sub2 ? a->out16.w : a->out.w))) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
   if (a->tile < 0 || a->tile > 13 || !((1u << a->tile) & 0x215Fu)) {       // 0 (heuristic), 1, 2, 3, 4, 6, 8, 13
     okp_set_error("okp_conv_forward: tile %d is not one of 0 (heuristic), 1, 2, 3, 4, 6, 8, 13", a->tile); return OKP_EINVAL;
   }
@@ -429,6 +435,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.slices_per_class = plan->n_slices / p.n_classes;
   p.n_single_slices = plan->n_single_slices / p.n_classes;
   p.out16 = a->out16.data; p.out16_pix_stride = a->out16.pix_stride; p.res16 = a->res_is_f16 ? 1 : 0;
+  if (sub2) { p.out_sub2 = 1; p.OH2 = a->out.h; p.OW2 = a->out.w; p.OH = a->out16.h; p.OW = a->out16.w; }
   if (a->dw_w_dev) {
     if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
     if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }

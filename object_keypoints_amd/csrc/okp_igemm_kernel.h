@@ -675,7 +675,20 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
             const int wo = rem - ho * p.Wo;
             opix = ((size_t)n * p.OH + (size_t)(ho * p.out_step + out_oy)) * p.OW + (size_t)(wo * p.out_step + out_ox);
           }
-          char* op = static_cast<char*>(p.out) + (opix * p.out_pix_stride + co) * ESZ;
+          size_t opix32 = opix;                    // pixel index in the fp32 output (differs from the fp16 copy's under out_sub2)
+          bool st32 = true;
+          if constexpr (X3) {
+            st32 = p.out != nullptr;
+            if (p.out_sub2) {                      // fp32 result kept at even rows / columns only, in a tensor of half the size
+              const int n = fastdiv(pix, p.div_howo);
+              const int rem = pix - n * HoWo;
+              const int ho = fastdiv(rem, p.div_wo);
+              const int wo = rem - ho * p.Wo;
+              st32 = st32 && !((ho | wo) & 1);
+              opix32 = ((size_t)n * p.OH2 + (size_t)(ho >> 1)) * p.OW2 + (size_t)(wo >> 1);
+            }
+          }
+          char* op = static_cast<char*>(p.out) + (opix32 * p.out_pix_stride + co) * ESZ;
           if (!p.res && ESZ == 2) {                // no residual: ReLU on the packed 16-bit words, store as read
             u32x4 w = raw[u][0];
             if (p.act == OKP_ACT_RELU) {
@@ -716,7 +729,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (!X3 || p.out) Io<T>::store8(v, op);
+            if (st32) Io<T>::store8(v, op);
             if constexpr (X3) {
               if (p.out16) {             // fp16 shadow of the result (what a single-term consumer on the fp16 kernels reads)
                 f16x8 o16;

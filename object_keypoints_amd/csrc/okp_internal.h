@@ -129,6 +129,7 @@ struct OkpIgemmParams {
   int32_t n_single_slices; // OKP_F32X3: leading single-term K-slices (the plan sorts them first)
   void* out16;             // OKP_F32X3: optional fp16 copy of the result (same pixel mapping as out); out may then be NULL
   int32_t out16_pix_stride, res16;   // res16: the residual tensor is fp16
+  int32_t out_sub2, OH2, OW2;        // OKP_F32X3: the fp32 output keeps even rows / columns only (tensor of OH2 x OW2 pixels); out16 is full size
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 

@@ -38,6 +38,9 @@ MIX_BRANCH_SINGLE = os.environ.get("OKP_MIX_BRANCH_SINGLE", "1") == "1"
 # closes with the three-term projected skip taking the fp16 branch as its residual (or okp_add_f16_f32).  0 = single-term taps of the
 # split-product kernel on the fp32 tensors (same products, slower).
 MIX_BRANCH_FP16 = os.environ.get("OKP_MIX_BRANCH_FP16", "1") == "1"
+# ... and a stream tensor whose only fp32 reader is the next block's stride-2 skip (stem output, pre[1] output) is kept in fp32 at even
+# rows / columns only (okp_conv_args.out_subsample): three quarters of its bytes were written and never read
+MIX_COMPACT = os.environ.get("OKP_MIX_COMPACT", "1") == "1"
 
 
 class f32_split:
@@ -107,11 +110,12 @@ def require_cuda(t, what):
 class Act:
     """NHWC activation view: a contiguous device tensor [N,H,W,Ctot] and a channel window."""
 
-    __slots__ = ("t", "c0", "c", "orig_hw", "shadow")
+    __slots__ = ("t", "c0", "c", "orig_hw", "shadow", "compact")
 
     def __init__(self, t, c0=0, c=None):
         self.orig_hw = None          # set by pack_frames: (H, W) of the un-padded frame
         self.shadow = None           # mixed configuration: fp16 copy of an fp32 stream tensor, written by its producer (ConvPlan(out16=...))
+        self.compact = False         # ... and this fp32 tensor holds the even rows / columns of the grid only (out_subsample=2); shadow: full grid
         require_cuda(t, "activation")
         if t.dim() != 4 or not t.is_contiguous():
             raise OkpError("activation must be a contiguous [N,H,W,C] tensor")
@@ -202,7 +206,7 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
-    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True):
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True, out_subsample=1):
         """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch.
         Split-product plans: out16 = fp16 Act that receives the result as well (write_out=False: only that copy is written; `out` then
         only describes the grid), and `res` may be an fp16 tensor (okp_conv_args.out16 / res_is_f16)."""
@@ -218,6 +222,8 @@ class ConvPlan:
             raise OkpError("out16 must be a float16 activation with the plan's output channels")
         if not write_out and out16 is None:
             raise OkpError("write_out=False needs out16")
+        if out_subsample not in (1, 2) or (out_subsample == 2 and out16 is None):
+            raise OkpError("out_subsample is 1 or 2, and 2 needs out16")
         extended = out16 is not None or res16
         macs = out.n * ho * wo * self.cout * self.alg_k
         macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
@@ -251,6 +257,7 @@ class ConvPlan:
             if out16 is not None:
                 a.out16 = out16.view()
             a.res_is_f16 = 1 if res16 else 0
+            a.out_subsample = out_subsample
             a.out_step, a.out_oy, a.out_ox = out_step, oy, ox
             a.res = res.view() if res is not None else _NULL_TENSOR
             a.tile = tile

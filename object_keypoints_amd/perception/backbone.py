@@ -113,7 +113,7 @@ class convolution(_HipModule):
             return ConvPlan(dtype, [32], [2], self.out_dim, taps, b, relu=True, alg_k=147)
         return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
 
-    def forward_frames(self, frames, dtype, shadow=False):
+    def forward_frames(self, frames, dtype, shadow=False, compact=False):
         """The stem on raw fp32 NCHW frames.  bf16: one launch of the dedicated kernel reading the frames directly;
         otherwise pack (ops.pack_frames) + the generic path.  shadow (split-product plans): also write the fp16 copy."""
         if self.inp_dim == 3 and dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
@@ -122,9 +122,10 @@ class convolution(_HipModule):
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
             plan.from_nchw(frames, out)
             return out
-        return self.forward(ops.pack_frames(frames, dtype), shadow=shadow)
+        return self.forward(ops.pack_frames(frames, dtype), shadow=shadow, compact=compact)
 
-    def forward(self, x, shadow=False):
+    def forward(self, x, shadow=False, compact=False):
+        """shadow / compact (split-product plans): also write the fp16 copy; keep the fp32 result at even rows / columns only."""
         plan = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         if self.inp_dim == 3:       # x is the packed frame tensor [N, H+6, Wp, 4]
             if x.orig_hw is None:
@@ -133,13 +134,18 @@ class convolution(_HipModule):
             ho, wo = conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3)
         else:
             ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
-        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
+        out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device) if not (compact and shadow and getattr(plan, "split", False)) else None
         if isinstance(plan, StemPlan):
             plan(x, out)
         else:
+            sub = 1
             if shadow and plan.split:
-                out.shadow = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, x.t.device)
-            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0, out16=out.shadow)
+                sh = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, x.t.device)
+                if compact:
+                    out = Act.empty(x.n, (ho + 1) // 2, (wo + 1) // 2, self.out_dim, x.dtype, x.t.device)
+                    out.compact, sub = True, 2
+                out.shadow = sh
+            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0, out16=out.shadow, out_subsample=sub)
         return out
 
 
@@ -176,7 +182,7 @@ class residual(_HipModule):
             p2 = ConvPlan(dtype, [self.out_dim], [1], self.out_dim, taps, b2, relu=True, tap_terms=terms)
         return p1, p2
 
-    def _build_mixed16(self):
+    def _build_mixed16(self, compact_in=False):
         """Mixed configuration with the branch on the fp16 kernels (ops.MIX_BRANCH_FP16): conv1 and conv2 as fp16 plans (conv2 without
         the closing ReLU: its rounded output is the residual of what follows), the projected skip as a three-term plan of its own."""
         w1, b1 = fold_bn(self.conv1.weight, self.bn1)
@@ -186,24 +192,30 @@ class residual(_HipModule):
         ps = None
         if self.projected:
             ws, bs = fold_bn(self.skip[0].weight, self.skip[1])
-            ps = ConvPlan(torch.float32, [self.inp_dim], [self.stride], self.out_dim, [(0, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))], bs, relu=True)
+            # (a compact input already holds exactly the pixels a stride-2 skip samples: read with stride 1)
+            ps = ConvPlan(torch.float32, [self.inp_dim], [1 if compact_in else self.stride], self.out_dim, [(0, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))], bs, relu=True)
         return p1, p2, ps
 
-    def _forward_mixed16(self, x, shadow, out=None, out_shadow=None):
-        p1, p2, ps = self._plan(("mix16",), self._build_mixed16)
-        ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
-        dev = x.t.device
+    def _forward_mixed16(self, x, shadow, out=None, out_shadow=None, compact=False):
+        if x.compact and not (self.projected and self.stride == 2 and x.shadow is not None):
+            raise OkpError("residual: a compact input needs its fp16 copy and a stride-2 projected block")
+        p1, p2, ps = self._plan(("mix16", x.compact), lambda: self._build_mixed16(x.compact))
         x16 = x.shadow if x.shadow is not None else ops.cast(x, torch.float16)      # (the producer wrote the copy when it knew of this consumer)
+        ho, wo = conv_out_size(x16.h, self.k, self.stride, self.pad), conv_out_size(x16.w, self.k, self.stride, self.pad)
+        dev = x.t.device
         t16 = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
         p1([x16], t16, ho, wo)
         b16 = Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
         p2([t16], b16, ho, wo)
         if ps is not None:
+            compact = compact and shadow
             if out is None:
-                out = Act.empty(x.n, ho, wo, self.out_dim, torch.float32, dev)
+                out = Act.empty(x.n, (ho + 1) // 2 if compact else ho, (wo + 1) // 2 if compact else wo, self.out_dim, torch.float32, dev)
+            out.compact = compact
             if shadow:
                 out.shadow = out_shadow if out_shadow is not None else Act.empty(x.n, ho, wo, self.out_dim, torch.float16, dev)
-            ps([x], out, ho, wo, res=b16, out16=out.shadow)        # relu(skip(x) + branch): three terms on the stream, fp16 residual
+            # relu(skip(x) + branch): three terms on the stream, fp16 residual
+            ps([x], out, ho, wo, res=b16, out16=out.shadow, out_subsample=2 if compact else 1)
         else:
             if out is not None:
                 raise OkpError("residual: a caller-provided destination is supported for projected blocks only")
@@ -212,11 +224,13 @@ class residual(_HipModule):
                 out.shadow = ops.cast(out, torch.float16)
         return out
 
-    def forward(self, x, shadow=False, out=None, out_shadow=None):
+    def forward(self, x, shadow=False, out=None, out_shadow=None, compact=False):
         """out / out_shadow: optional destination (an Act over a frame range of a larger tensor) of the block's result and of its fp16
-        copy - hg.forward runs the two high-resolution layers in frame chunks and the rest of the network in one pass."""
+        copy - hg.forward runs the two high-resolution layers in frame chunks and the rest of the network in one pass.
+        compact (mixed configuration, with shadow): the fp32 result is kept at even rows / columns only (its one fp32 reader is the
+        next block's stride-2 skip)."""
         if ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16 and x.dtype == torch.float32:
-            return self._forward_mixed16(x, shadow, out, out_shadow)
+            return self._forward_mixed16(x, shadow, out, out_shadow, compact)
         p1, p2 = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
         t = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
@@ -465,10 +479,10 @@ class hg(_HipModule):
         self.cnvs_ = nn.ModuleList([_MergeMod() for _ in range(stacks - 1)])
 
     @staticmethod
-    def front_chunk(n, h, w, dtype):
+    def front_chunk(n, h, w, dtype, compact=False):
         """Frames per launch of the stem and pre[1] such that the stem output stays under the 2 GiB view limit (include/okp.h), in
-        equal chunks."""
-        esz = 2 if dtype in ops.HALF_DTYPES else 4
+        equal chunks.  compact: its fp32 form holds a quarter of the pixels, the full-grid fp16 copy is the largest tensor."""
+        esz = 2 if (dtype in ops.HALF_DTYPES or compact) else 4
         per_frame = conv_out_size(h, 7, 2, 3) * conv_out_size(w, 7, 2, 3) * 128 * esz
         limit = max(1, (0x7FFF0000 - 1) // per_frame)
         parts = -(-n // limit)
@@ -486,18 +500,20 @@ class hg(_HipModule):
         them itself where it can).  Returns [cnv0, cnv1] as NHWC activations."""
         # mixed configuration with fp16 branches: producers write the fp16 copy their consumer's conv1 reads (stem -> pre.1, pre.1 -> pre.2)
         mix16 = ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16
+        # ... and keep the fp32 stream at even pixels only where its single fp32 reader is the next block's stride-2 skip
+        cp = [mix16 and ops.MIX_COMPACT and r.projected and r.stride == 2 for r in (self.pre[1], self.pre[2])]
         if isinstance(x, torch.Tensor):
             n, (fh, fw), sdtype = x.shape[0], x.shape[2:4], dtype
-            stem = lambda c0, c1, sh: self.pre[0].forward_frames(x[c0:c1], dtype, shadow=sh)
+            stem = lambda c0, c1, sh: self.pre[0].forward_frames(x[c0:c1], dtype, shadow=sh, compact=sh and cp[0])
         else:                                   # packed frames (ops.pack_frames / pack_frames_u8 / preprocess_u8)
             n, (fh, fw), sdtype = x.n, x.orig_hw, x.dtype
 
             def stem(c0, c1, sh):
                 xi = Act(x.t[c0:c1])
                 xi.orig_hw = x.orig_hw
-                return self.pre[0](xi, shadow=sh)
+                return self.pre[0](xi, shadow=sh, compact=sh and cp[0])
         want_shadow = mix16 and sdtype == torch.float32
-        chunk = self.front_chunk(n, fh, fw, sdtype)
+        chunk = self.front_chunk(n, fh, fw, sdtype, compact=want_shadow and cp[0])
         if chunk < n:
             # fp32 tensors: the stem output (128 channels at half resolution, 33.5 MB per frame) of a whole batch would pass the 2 GiB
             # view limit of the 32-bit buffer offsets.  Only the stem and pre[1] see that resolution: they run per frame chunk and
@@ -509,14 +525,17 @@ class hg(_HipModule):
                 a = stem(c0, c1, want_shadow)
                 if inter is None:
                     r = self.pre[1]
-                    ho, wo = conv_out_size(a.h, r.k, r.stride, r.pad), conv_out_size(a.w, r.k, r.stride, r.pad)
-                    inter = Act.empty(n, ho, wo, r.out_dim, sdtype, a.t.device)
+                    ah, aw = (a.shadow.h, a.shadow.w) if a.compact else (a.h, a.w)
+                    ho, wo = conv_out_size(ah, r.k, r.stride, r.pad), conv_out_size(aw, r.k, r.stride, r.pad)
+                    c2 = want_shadow and cp[1]
+                    inter = Act.empty(n, (ho + 1) // 2 if c2 else ho, (wo + 1) // 2 if c2 else wo, r.out_dim, sdtype, a.t.device)
+                    inter.compact = c2
                     if want_shadow:
                         inter.shadow = Act.empty(n, ho, wo, r.out_dim, torch.float16, a.t.device)
                 sh = Act(inter.shadow.t[c0:c1]) if inter.shadow is not None else None
-                self.pre[1](a, shadow=sh is not None, out=Act(inter.t[c0:c1]), out_shadow=sh)
+                self.pre[1](a, shadow=sh is not None, out=Act(inter.t[c0:c1]), out_shadow=sh, compact=inter.compact)
         else:
-            inter = self.pre[1](stem(0, n, want_shadow), shadow=mix16)
+            inter = self.pre[1](stem(0, n, want_shadow), shadow=mix16, compact=want_shadow and cp[1])
         inter = self.pre[2](inter)
         cnvs = []
         last = len(self.hgs) - 1

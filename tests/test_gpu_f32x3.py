@@ -340,3 +340,31 @@ def test_add_f16_f32():
     assert torch.equal(got.t, torch.relu(a.float() + b))
     got = ops.add_f16_f32(ops.Act(a), ops.Act(b), relu=False)
     assert torch.equal(got.t, a.float() + b)
+
+
+@pytest.mark.parametrize("h,w", [(12, 20), (13, 9)])
+def test_subsampled_fp32_output_keeps_the_even_grid(h, w):
+    """okp_conv_args.out_subsample = 2: the fp32 result at even rows / columns only (what the next block's stride-2 skip reads), the fp16
+    copy on the full grid - against the same launch without subsampling, bit for bit; odd grid sizes included."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    dev = torch.device("cuda:0")
+    n, cin, cout = 3, 32, 64
+    x = _rand((n, cin, h, w), 81)
+    wt = _rand((cout, cin, 3, 3), 82) / np.sqrt(cin * 9)
+    b = _rand((cout,), 83) * 0.1
+    r16 = ops.Act((_rand((n, h, w, cout), 84) * 0.5).half().to(dev))
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [cin], [1], cout, conv_taps(wt.numpy()), b.numpy(), relu=True)
+    xa = ops.Act.from_nchw(x.to(dev), torch.float32)
+    for tile in (1, 2, 3):
+        full = ops.Act.empty(n, h, w, cout, torch.float32, dev)
+        f16 = ops.Act.empty(n, h, w, cout, torch.float16, dev)
+        plan([xa], full, h, w, res=r16, out16=f16, tile=tile)
+        sub = ops.Act(torch.full((n, (h + 1) // 2, (w + 1) // 2, cout), -3.0, dtype=torch.float32, device=dev))
+        s16 = ops.Act.empty(n, h, w, cout, torch.float16, dev)
+        plan([xa], sub, h, w, res=r16, out16=s16, out_subsample=2, tile=tile)
+        assert torch.equal(sub.t, full.t[:, ::2, ::2, :].contiguous()), tile
+        assert torch.equal(s16.t, f16.t)
+    with pytest.raises(ops.OkpError):
+        plan([xa], sub, h, w, out_subsample=2)                    # needs the full-grid fp16 copy
