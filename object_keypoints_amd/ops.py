@@ -29,8 +29,20 @@ F32X3 = "float32x3"
 # tests/precision/attribute.py measures those shares on given weights (tests/golden/precision_attribution.json for the test network) and
 # tests/precision/emulate.py: mixed_policy() predicts the result on the CPU: heat error 3.9e-4 max on the test networks (bar 1e-3).
 F32MIX = "float32mix"
-F32_SPLIT = False       # plans built for torch.float32 while this is set are OKP_F32X3 plans (see f32_split())
-F32_MIX = False         # ... with single-term taps in the residual branches, and fp16 inner hourglass levels
+# ops.F32_SPLIT: plans built for torch.float32 while it is set are OKP_F32X3 plans; ops.F32_MIX: ... with single-term residual branches and
+# fp16 inner hourglass levels.  Both are PER-THREAD state set by the f32_split() context manager (module __getattr__ below): two networks of
+# different configurations may run on two host threads.
+import threading
+_MODE = threading.local()
+
+
+def __getattr__(name):
+    if name == "F32_SPLIT":
+        return getattr(_MODE, "split", False)
+    if name == "F32_MIX":
+        return getattr(_MODE, "mix", False)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
 MIX_FP16_LEVELS = int(os.environ.get("OKP_MIX_FP16_LEVELS", "2"))    # hg_module levels n <= this run in fp16 (n = 2: the 16 x 16 level)
 MIX_BRANCH_SINGLE = os.environ.get("OKP_MIX_BRANCH_SINGLE", "1") == "1"
 # ... and those single-term branches run on the fp16 kernels proper (the patch-resident 3x3 kernel: half the bytes, no in-loop conversion):
@@ -51,12 +63,11 @@ class f32_split:
         self.enabled, self.mixed = bool(enabled), bool(enabled and mixed)
 
     def __enter__(self):
-        global F32_SPLIT, F32_MIX
-        self.prev, F32_SPLIT, F32_MIX = (F32_SPLIT, F32_MIX), self.enabled, self.mixed
+        self.prev = (getattr(_MODE, "split", False), getattr(_MODE, "mix", False))
+        _MODE.split, _MODE.mix = self.enabled, self.mixed
 
     def __exit__(self, *exc):
-        global F32_SPLIT, F32_MIX
-        F32_SPLIT, F32_MIX = self.prev
+        _MODE.split, _MODE.mix = self.prev
 
 
 def parse_compute_dtype(compute_dtype):
@@ -162,7 +173,8 @@ class ConvPlan:
         """tap_terms (split-product plans only): per tap 3 (three-term product, the default) or 1 (single fp16 term)."""
         L = _lib.lib()
         self.dtype = dtype
-        self.split = bool(F32_SPLIT and dtype == torch.float32)      # OKP_F32X3: fp32 tensors, products on the fp16 matrix pipe
+        self.split = bool(getattr(_MODE, "split", False) and dtype == torch.float32)      # OKP_F32X3: fp32 tensors, products on the fp16 matrix pipe
+        self.allow_compact = False       # set by the one consumer that knows how to read an even-pixels-only source (residual's skip plan)
         self.tap_terms = list(tap_terms) if (tap_terms is not None and self.split) else None
         self.cout = cout
         self.n_src = len(cins)
@@ -213,6 +225,8 @@ class ConvPlan:
         for s in srcs:
             if s.dtype != self.dtype:
                 raise OkpError("source dtype differs from plan dtype")
+            if s.compact and not self.allow_compact:
+                raise OkpError("source keeps the even rows / columns of its grid only (out_subsample): this plan does not expect that")
         if out.dtype != self.dtype or out.c != self.cout:
             raise OkpError(f"out has {out.c} channels / {out.dtype}, plan has {self.cout} / {self.dtype}")
         res16 = res is not None and self.split and res.dtype == torch.float16

@@ -194,6 +194,7 @@ class residual(_HipModule):
             ws, bs = fold_bn(self.skip[0].weight, self.skip[1])
             # (a compact input already holds exactly the pixels a stride-2 skip samples: read with stride 1)
             ps = ConvPlan(torch.float32, [self.inp_dim], [1 if compact_in else self.stride], self.out_dim, [(0, 0, 0, np.ascontiguousarray(ws[:, :, 0, 0]))], bs, relu=True)
+            ps.allow_compact = compact_in
         return p1, p2, ps
 
     def _forward_mixed16(self, x, shadow, out=None, out_shadow=None, compact=False):

@@ -414,3 +414,27 @@ def test_reads_a_pytorch_lightning_1_2_1_shaped_checkpoint_without_running_its_p
         f.write(b"not a checkpoint")
     with pytest.raises((pp.OkpError, pickle.UnpicklingError, RuntimeError)):
         pp.read_checkpoint_state_dict(str(tmp_path / "junk.pt"))
+
+
+def test_compute_mode_is_per_thread_and_parses():
+    """ops.f32_split() (what KeypointNet wraps its passes in for "float32x3" / "float32mix") sets per-thread state: a network of another
+    configuration running on a second host thread is not affected."""
+    import threading
+    import torch
+    from object_keypoints_amd import ops
+    assert ops.parse_compute_dtype("float32x3") == (torch.float32, True, False)
+    assert ops.parse_compute_dtype(ops.F32MIX) == (torch.float32, True, True)
+    assert ops.parse_compute_dtype(torch.float16) == (torch.float16, False, False) and ops.parse_compute_dtype("bfloat16")[0] == torch.bfloat16
+    with pytest.raises(ops.OkpError):
+        ops.parse_compute_dtype(torch.float64)
+    assert (ops.F32_SPLIT, ops.F32_MIX) == (False, False)
+    seen = []
+    with ops.f32_split(True, True):
+        assert (ops.F32_SPLIT, ops.F32_MIX) == (True, True)
+        with ops.f32_split(True, False):
+            assert (ops.F32_SPLIT, ops.F32_MIX) == (True, False)
+        assert ops.F32_MIX
+        t = threading.Thread(target=lambda: seen.append((ops.F32_SPLIT, ops.F32_MIX)))
+        t.start(); t.join()
+    assert seen == [(False, False)] and (ops.F32_SPLIT, ops.F32_MIX) == (False, False)
+    assert not ops.f32_split(False, True).mixed                   # mixed implies split
