@@ -156,16 +156,15 @@ def test_fused_heads_at_bench_batch(dtype):
 @pytest.mark.parametrize("side,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (True, "float32mix")])
 def test_graph_replay_equals_eager_at_batch64(side, dtype):
     """hipGraph replays of the 64-frame step are bit-equal to the eager step, five replays in a row, with the hourglass branches
-    captured serially and forked onto side streams (bf16), and for the mixed configuration (fp16 sub-networks, casts and fp16 side
-    outputs inside the capture; 32 frames: one pass)."""
+    captured serially and forked onto side streams (bf16), and for the mixed configuration (fp16 sub-networks, casts, fp16 side
+    outputs and the chunked high-resolution front inside the capture)."""
     from object_keypoints_amd.perception import pipeline as pp
     from object_keypoints_amd.perception.utils import camera_utils as cu
     from oracle import pipeline as op
     net = _net(dtype)
     cam_o = op.eval_camera(CALIB)
     pipe = pp.BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size), capacity=128)
-    nfr = 32 if isinstance(dtype, str) else 64
-    x0, x1 = _frames(nfr, seed=1), _frames(nfr, seed=2)
+    x0, x1 = _frames(64, seed=1), _frames(64, seed=2)
     keep = pp.GRAPH_SIDE_STREAMS
     pp.GRAPH_SIDE_STREAMS = side
     try:
