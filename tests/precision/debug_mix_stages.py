@@ -1,7 +1,7 @@
-"""Stage-by-stage comparison of the mixed configuration (GPU) with its CPU rounding-point model (needs the oracle: a debugging aid,
-run by hand).  usage: debug_mix_stages.py [valve_k3|cups_k4]"""
+"""TEST INFRASTRUCTURE (GPU + oracle): stage-by-stage comparison of the mixed configuration on the device with its CPU rounding-point
+model - a debugging aid, run by hand on the GPU box.  usage: python tests/precision/debug_mix_stages.py [valve_k3|cups_k4]"""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, os.path.join(REPO, "tests", "golden")); sys.path.insert(0, os.path.join(REPO, "tests", "precision"))
 import numpy as np, torch
 import cases, emulate
