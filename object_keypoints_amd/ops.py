@@ -53,6 +53,9 @@ MIX_BRANCH_FP16 = os.environ.get("OKP_MIX_BRANCH_FP16", "1") == "1"
 # ... and a stream tensor whose only fp32 reader is the next block's stride-2 skip (stem output, pre[1] output) is kept in fp32 at even
 # rows / columns only (okp_conv_args.out_subsample): three quarters of its bytes were written and never read
 MIX_COMPACT = os.environ.get("OKP_MIX_COMPACT", "1") == "1"
+# ... and the stem then runs as two launches: the fp16 stem kernel writes the full-grid fp16 tensor (read by pre[1].conv1 only: a branch
+# input), a stride-4 three-term launch the fp32 values at even pixels (read by pre[1]'s skip: the stream) - a quarter of the three-term work
+MIX_STEM_FP16 = os.environ.get("OKP_MIX_STEM_FP16", "1") == "1"
 
 
 class f32_split:

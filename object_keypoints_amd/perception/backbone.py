@@ -97,12 +97,13 @@ class convolution(_HipModule):
         self.conv = nn.Conv2d(inp_dim, out_dim, (k, k), padding=(pad, pad), stride=(stride, stride), bias=not with_bn)
         self.bn = nn.BatchNorm2d(out_dim) if with_bn else nn.Sequential()
 
-    def _build(self, dtype):
+    def _build(self, dtype, stride=None):
+        """stride: conv stride of the generic stem plan (4 = every second output pixel and row of the 7x7/s2 stem)."""
         w, b = fold_bn(self.conv.weight, self.bn, self.conv.bias)
         if self.inp_dim == 3:
             if self.k != 7 or self.stride != 2:
                 raise OkpError("3-channel input is supported for the 7x7/s2 stem only")
-            if dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL:
+            if dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and stride is None:
                 return StemPlan(w, b, dtype)
             # one tap per kernel row: 8 pixels x 4 channels of the packed frame = 32 contiguous elements
             taps = []
@@ -110,7 +111,7 @@ class convolution(_HipModule):
                 m = np.zeros((self.out_dim, 8, 4), dtype=np.float32)
                 m[:, :7, :3] = np.transpose(w[:, :, r, :], (0, 2, 1))
                 taps.append((0, r, 0, m.reshape(self.out_dim, 32)))
-            return ConvPlan(dtype, [32], [2], self.out_dim, taps, b, relu=True, alg_k=147)
+            return ConvPlan(dtype, [32], [stride or 2], self.out_dim, taps, b, relu=True, alg_k=147)
         return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
 
     def forward_frames(self, frames, dtype, shadow=False, compact=False):
@@ -121,6 +122,20 @@ class convolution(_HipModule):
             n, _, h, w = frames.shape
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
             plan.from_nchw(frames, out)
+            return out
+        if (shadow and compact and ops.F32_MIX and ops.MIX_STEM_FP16 and dtype == torch.float32 and self.inp_dim == 3 and self.out_dim == 128
+                and STEM_KERNEL and STEM_DIRECT):
+            # mixed configuration, two launches (ops.MIX_STEM_FP16): full-grid fp16 tensor by the fp16 stem kernel, fp32 at even pixels by a
+            # stride-4 three-term launch
+            n, _, h, w = frames.shape
+            ho, wo = conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3)
+            p16 = self._plan(("p", torch.float16), lambda: self._build(torch.float16))
+            sh = Act.empty(n, ho, wo, self.out_dim, torch.float16, frames.device)
+            p16.from_nchw(frames, sh)
+            p4 = self._plan(("s4", dtype), lambda: self._build(dtype, stride=4))
+            out = Act.empty(n, (ho + 1) // 2, (wo + 1) // 2, self.out_dim, dtype, frames.device)
+            p4([ops.pack_frames(frames, dtype)], out, out.h, out.w, tile=STEM_TILE)
+            out.compact, out.shadow = True, sh
             return out
         return self.forward(ops.pack_frames(frames, dtype), shadow=shadow, compact=compact)
 

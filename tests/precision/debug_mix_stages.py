@@ -15,7 +15,7 @@ net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.fill_sta
 net.eval().cuda()
 xh = synth.frames(1, seed=case["frame_seed"], start=case["frame_index"])
 _, emu = emulate.build(case["heatmaps_out"], case["weight_seed"])
-pol = emulate.mixed_policy(ops.MIX_FP16_LEVELS, ops.MIX_BRANCH_SINGLE)
+pol = emulate.mixed_policy(ops.MIX_FP16_LEVELS, ops.MIX_BRANCH_SINGLE, ops.MIX_STEM_FP16)
 trace = {}
 orig_act = pol.act
 def act(n, t):

@@ -107,10 +107,11 @@ class EmuNet:
             y = y + res
         return F.relu(y) if relu else y
 
-    def _residual(self, p, name, x, stride):
+    def _residual(self, p, name, x, stride, branch_in=None):
+        """branch_in: what conv1 reads when that is not (the rounding of) x - the fp16 stem kernel's output in the mixed configuration."""
         sd = self.sd
         w1, b1 = _fold(sd[f"{name}.conv1.weight"], f"{name}.bn1", name, sd)
-        t = p.act(f"{name}.t", F.relu(p.conv(x, p.weight(f"{name}.conv1", w1), b1, stride=stride, padding=1)))
+        t = p.act(f"{name}.t", F.relu(p.conv(x if branch_in is None else branch_in, p.weight(f"{name}.conv1", w1), b1, stride=stride, padding=1)))
         w2, b2 = _fold(sd[f"{name}.conv2.weight"], f"{name}.bn2", name, sd)
         y = p.branch(name, p.conv(t, p.weight(f"{name}.conv2", w2), b2, padding=1))
         if f"{name}.skip.0.weight" in sd:
@@ -171,7 +172,11 @@ class EmuNet:
         with torch.no_grad():
             x = p.act("frames", x)
             inter = p.act("backbone.pre.0", self._conv(p, "backbone.pre.0", x, stride=2))
-            inter = self._residual(p, "backbone.pre.1", inter, 2)
+            stem16 = None
+            if getattr(p, "stem_fp16_shadow", False):      # mixed configuration: pre.1's conv1 reads the output of the fp16 stem kernel
+                w0, b0 = _fold(self.sd["backbone.pre.0.conv.weight"], "backbone.pre.0.bn", "", self.sd)
+                stem16 = rnd(F.relu(F.conv2d(rnd(x, torch.float16), rnd(w0, torch.float16), b0, stride=2, padding=3)), torch.float16)
+            inter = self._residual(p, "backbone.pre.1", inter, 2, branch_in=stem16)
             inter = self._residual(p, "backbone.pre.2", inter, 2)
             cnv = None
             for i in range(2):
@@ -202,7 +207,7 @@ def build(heatmaps_out=3, weight_seed=0):
     return net, EmuNet(net)
 
 
-def mixed_policy(fp16_hourglass_levels=2, branch_single_term=True, fire_single_term_levels=0):
+def mixed_policy(fp16_hourglass_levels=2, branch_single_term=True, stem_fp16=True):
     """The sensitivity-guided mixed configuration of the HIP path (KeypointNet(compute_dtype=ops.F32MIX)): fp32 storage of every
     tensor of the skip stream, three-term products by default, and
       * single-term fp16 products (operands rounded for that product only) in the 3x3 convolutions INSIDE the residual blocks of
@@ -234,4 +239,5 @@ def mixed_policy(fp16_hourglass_levels=2, branch_single_term=True, fire_single_t
     p.act_rule = act_rule
     p.enter_rule = lambda name: torch.float16 if in_deep(name) else None
     p.branch_dtype = torch.float16 if branch_single_term else None
+    p.stem_fp16_shadow = bool(branch_single_term and stem_fp16)
     return p

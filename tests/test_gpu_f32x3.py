@@ -258,7 +258,7 @@ def test_cast_round_trip_and_rounding():
 @pytest.mark.parametrize("name", sorted(cases.NET_CASES))
 def test_mixed_network_meets_the_heat_bar_and_matches_its_cpu_model(name):
     """KeypointNet(compute_dtype=ops.F32MIX) against the reference's golden outputs - heat maps within the north_star 1e-3 (the CPU
-    model predicts 3.3e-4 to 3.6e-4 on these networks) - and against the CPU rounding-point model of the SAME precision plan
+    model predicts 4.1e-4 and 5.0e-4 on these two networks) - and against the CPU rounding-point model of the SAME precision plan
     (tests/precision/emulate.py: mixed_policy), whose error statistics it must reproduce: the plan that is emulated, priced by the
     attribution table and documented is the plan the device runs."""
     import os
@@ -274,10 +274,10 @@ def test_mixed_network_meets_the_heat_bar_and_matches_its_cpu_model(name):
     g = gu.golden_net(name)
     e_heat = np.abs(heat.numpy() - g["heat"])
     print(f"{name} f32mix: heat err max {e_heat.max():.2e} mean {e_heat.mean():.2e}; depth {np.abs(depth.numpy() - g['depth']).max():.2e}")
-    assert e_heat.max() <= 1e-3 and e_heat.max() <= 6e-4 and e_heat.mean() <= 1e-4
+    assert e_heat.max() <= 1e-3 and e_heat.max() <= 7.5e-4 and e_heat.mean() <= 1e-4
     assert np.abs(depth.numpy() - g["depth"]).max() <= 4e-3 and np.abs(centers.numpy() - g["centers"]).max() <= 4e-3
     _, emu = emulate.build(case["heatmaps_out"], case["weight_seed"])
-    model = emu.forward(torch.from_numpy(xh), emulate.mixed_policy(ops.MIX_FP16_LEVELS, ops.MIX_BRANCH_SINGLE))
+    model = emu.forward(torch.from_numpy(xh), emulate.mixed_policy(ops.MIX_FP16_LEVELS, ops.MIX_BRANCH_SINGLE, ops.MIX_STEM_FP16))
     # The model cannot reproduce the device value by value: a tensor that differs by accumulation-order noise (1e-6) upstream rounds
     # ~0.3 % of its elements to the other fp16 neighbour, which moves each output by a fraction of the rounding error itself.  What
     # it must reproduce is the SIZE of the error - same rounding points, same statistics: mean |error| within 15 %, maximum within 1.5x.
