@@ -368,3 +368,24 @@ def test_subsampled_fp32_output_keeps_the_even_grid(h, w):
         assert torch.equal(s16.t, f16.t)
     with pytest.raises(ops.OkpError):
         plan([xa], sub, h, w, out_subsample=2)                    # needs the full-grid fp16 copy
+
+
+def test_mixed_network_on_other_frame_sizes_and_uint8_frames():
+    """The mixed configuration's special forms (fp16 side outputs, even-pixel fp32 tensors, two-launch stem, chunked front) away from
+    511 x 511: (a) 255 x 383 frames - an odd frame size, stem output 128 x 192; (b) uint8 frames through the fused normalisation
+    (packed-frame path: the single-launch stem form) against the same network on the normalised fp32 frames.  The exact-product
+    configuration float32x3 is the checker (itself held to the reference by the golden tests)."""
+    from object_keypoints_amd import ops
+    case = cases.NET_CASES["valve_k3"]
+    mix, x3 = _net(case, ops.F32MIX), _net(case, ops.F32X3)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x = torch.randn((3, 3, 255, 383), generator=gen, device="cuda")
+    a, b = mix.deployed(x), x3.deployed(x)
+    assert tuple(a[0].shape) == (3, 3, 32, 48)
+    assert float((a[0] - b[0]).abs().max()) <= 1e-3 and float((a[1] - b[1]).abs().max()) <= 6e-3
+    u8 = torch.randint(0, 256, (2, 511, 511, 3), generator=gen, device="cuda", dtype=torch.uint8)
+    mean = torch.tensor(ops.RGB_MEAN, device="cuda").view(1, 3, 1, 1); std = torch.tensor(ops.RGB_STD, device="cuda").view(1, 3, 1, 1)
+    xf = ((u8.permute(0, 3, 1, 2).float() / 255.0) - mean) / std
+    mix.raw_frame_size = None
+    hu, hf = mix.deployed(u8)[0], x3.deployed(xf.contiguous())[0]
+    assert float((hu - hf).abs().max()) <= 1e-3
