@@ -381,3 +381,56 @@ def test_fused_heads_at_batch64_against_the_oracle(dtype):
         assert float((heat[i:i + 1].cpu() - rh).abs().max()) <= tol
         assert float((depth[i:i + 1].cpu() - rd).abs().max()) <= tol * (1.0 + float(rd.abs().max()))
         assert float((centers[i:i + 1].cpu().reshape(rc.shape) - rc).abs().max()) <= tol * (1.0 + float(rc.abs().max()))
+
+
+def test_stereo_stream_pipeline_tick_recovers_the_rendered_points():
+    """StereoStreamPipeline (BASELINE configs[4]: a tick = the frames of all stereo pairs -> one network batch -> peaks -> association ->
+    ONE triangulation launch): on heat maps rendered from known 3D points through the left and right camera of every pair the tick
+    returns those points per pair and key-point type; the hipGraph form of the network pass gives the same bits; an odd frame count
+    and an exceeded capacity are refused."""
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import geometry as og
+    p = og.load_calibration_params(CALIB)
+    offset = np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])
+    mk = lambda K, D: cu.FisheyeCamera(K, D, p["image_size"]).scale(511 / 720).cut(offset).scale(64 / 511)
+    left, right = mk(p["K"], p["D"]), mk(p["Kp"], p["Dp"])
+    stereo = cu.StereoCamera(left, right, p["T_RL"])
+    net = _net(torch.float16)
+    pipe = pp.StereoStreamPipeline(net, stereo, {"keypoint_config": [1, 3]}, capacity=8, max_distance=1.5)
+    n_pairs, K, size = 2, 3, 64
+    ys, xs = np.meshgrid(np.arange(size, dtype=np.float32), np.arange(size, dtype=np.float32), indexing="ij")
+    base = {0: [[0.00, 0.00, 0.55]], 1: [[0.12, -0.10, 0.60]], 2: [[-0.16, 0.12, 0.50], [0.14, 0.04, 0.65], [-0.12, -0.16, 0.70]]}
+    heat = np.zeros((2 * n_pairs, K, size, size), np.float32)
+    truth = []
+    for pr in range(n_pairs):
+        t = {}
+        for k, pts in base.items():
+            X = np.array(pts) + np.array([0.02 * pr, -0.015 * pr, 0.04 * pr])
+            t[k] = X
+            for side, (cam, T) in enumerate(((left, np.eye(4)), (right, p["T_RL"]))):
+                for px, py in cam.project(X, T):
+                    heat[2 * pr + side, k] += np.exp(-((xs - px) ** 2 + (ys - py) ** 2) / 4.0)
+        truth.append(t)
+    heat_dev = torch.from_numpy(np.clip(heat, 0, 1)).cuda()
+    frames = _frames(2 * n_pairs, seed=31)
+    out = pipe.tick(frames, heat_override=heat_dev)
+    assert len(out) == n_pairs
+    for pr in range(n_pairs):
+        for k in range(K):
+            got, want = out[pr][k], truth[pr][k]
+            assert got.shape == want.shape and got.dtype == np.float64
+            d = np.linalg.norm(got[:, None] - want[None], axis=2).min(axis=1)
+            assert d.max() < 0.06                      # 64 x 64 maps, 6.2 cm baseline: centimetres (bench.py: run_stream8)
+    pipe.capture(frames)
+    out_g = pipe.tick(frames, heat_override=heat_dev, use_graph=True)
+    with pytest.raises(pp.OkpError):
+        pipe.tick(frames)                              # the network's own maps (random weights: ~100 peaks each) exceed the capacity: loud
+    for pr in range(n_pairs):
+        for k in range(K):
+            assert np.array_equal(out[pr][k], out_g[pr][k])
+    with pytest.raises(pp.OkpError):
+        pipe.tick(frames[:3])
+    tiny = pp.StereoStreamPipeline(net, stereo, {"keypoint_config": [1, 3]}, capacity=2)
+    with pytest.raises(pp.OkpError):
+        tiny.tick(frames, heat_override=heat_dev)      # three bumps in one map, room for two
