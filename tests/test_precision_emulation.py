@@ -78,3 +78,18 @@ def test_attribution_table_says_no_layer_subset_reaches_the_bar():
     big = [p for p in t["points"] if p["heat_share"] >= top[62]]
     trunk = [p for p in big if not p["name"].startswith("backbone.hgs.") or p["name"].count(".") <= 3]
     assert len(trunk) >= 25
+
+
+def test_plan_tool_selects_the_shipped_mixed_plan_for_the_test_network():
+    """tests/precision/plan.py prices every float32mix plan on given weights with the rounding-point model and names the fastest one
+    inside a heat-error bound: for the synthetic network that is the plan object_keypoints_amd ships as default (fp16 hourglass levels
+    n <= 2, single-term residual branches); one more fp16 level is predicted - and measured - at ~9e-4."""
+    import plan
+    from object_keypoints_amd import ops, synth
+    _, emu = emulate.build(3, 0)
+    x = torch.from_numpy(synth.frames(2, seed=1))
+    rows, best = plan.choose(emu, x, bound=5.5e-4)
+    assert best is not None and (best["fp16_levels"], best["branch_single_term"]) == (ops.MIX_FP16_LEVELS, ops.MIX_BRANCH_SINGLE) == (2, True)
+    by = {(r["fp16_levels"], r["branch_single_term"]): r for r in rows}
+    assert by[(3, True)]["heat_max"] > 7e-4 and by[(4, True)]["heat_max"] > 1e-3          # where the margin goes
+    assert by[(2, False)]["heat_max"] < by[(2, True)]["heat_max"] < 5.5e-4
