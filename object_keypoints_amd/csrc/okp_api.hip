@@ -461,6 +461,14 @@ static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
     const int t2 = okp_select_tile(plan->dtype, plan->cout_pad, px * ncls0);
     if (t2 == 2 || tile == 2) tile = 2;
   }
+  if (plan->dtype == OKP_F32X3 && tile == 3) {
+    // split-product plans with a short reduction (1x1 convolutions: K <= 512) are bound by their fp32 tensors, not by the matrix pipe:
+    // the 128 x 256 tile runs two workgroups per CU, so one streams its rows in while the other writes its tile out (N=64, 64x64:
+    // heads layer 1 342 -> 230 us, pre[2] skip 252 -> 199 us, pre[1] skip 704 -> 562 us, two-source merge 373 -> 359 us)
+    int k = 0;
+    for (int t = 0; t < plan->n_taps; ++t) k += plan->cin[plan->taps[t].src];
+    if (k <= 512) tile = 4;
+  }
   static const bool patch_on = [] { const char* e = getenv("OKP_PATCH"); return !(e && e[0] == '0'); }();   // OKP_PATCH=0: A/B against the gather tile
   const int ncls = a->n_classes > 1 ? a->n_classes : 1;
   const bool dense1 = ncls == 1 && a->out_step == 1 && a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo;

@@ -1,6 +1,6 @@
 """Step time of the whole hot path (frames resident in HBM -> 3D keypoints) by batch size, eager launches and a captured
 hipGraph (BatchedKeypointPipeline.capture).  The reference processes ONE frame per call; small batches are its operating point.
-usage: latency_sweep.py [batches=1,2,4,8,16,32,64]"""
+usage: latency_sweep.py [batches=1,2,4,8,16,32,64] [dtype=bf16|f16|f32|f32x3|f32mix]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,11 +9,16 @@ from object_keypoints_amd.perception.pipeline import BatchedKeypointPipeline
 from object_keypoints_amd.perception.utils import camera_utils as cu
 
 batches = [1, 2, 4, 8, 16, 32, 64]
+precision = "bf16"
 for a in sys.argv[1:]:
     k, v = a.split("=")
     if k == "batches": batches = [int(x) for x in v.split(",")]
+    if k == "dtype": precision = v
 dev = torch.device("cuda", 0)
-net = bench.build_net(torch.bfloat16).to(dev)
+from object_keypoints_amd import ops
+compute = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": ops.F32X3, "f32mix": ops.F32MIX}[precision]
+net = bench.build_net(compute).to(dev)
+print(f"compute dtype {precision}")
 params = cu.load_calibration_params(os.path.join(bench.REPO, "config", "calibration.yaml"))
 camera = cu.FisheyeCamera(params["K"], params["D"], params["image_size"]).scale(511 / 720)
 camera = camera.cut(np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])).scale(64 / 511)

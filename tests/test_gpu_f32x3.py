@@ -232,7 +232,7 @@ def test_mixed_taps_of_a_residual_block_tail():
         plan = ops.ConvPlan(torch.float32, [c0, c1], [1, 2], cout, taps, b.numpy(), relu=True, tap_terms=[1] * 9 + [3])
     out = ops.Act.empty(n, h, w, cout, torch.float32, dev)
     f32 = torch.float32
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4):
         plan([ops.Act.from_nchw(t.to(dev), f32), ops.Act.from_nchw(x.to(dev), f32)], out, h, w, tile=tile)
         ref = F.relu(F.conv2d(t.half().double(), w2.half().double(), b.double(), padding=1) + F.conv2d(x.double(), ws.double(), stride=2)).float()
         assert float((out.to_nchw().cpu() - ref).abs().max()) <= _tol(ref), tile
@@ -315,7 +315,7 @@ def test_fp16_residual_and_fp16_shadow_output_of_a_split_plan():
         plan = ops.ConvPlan(torch.float32, [cin], [2], cout, [(0, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))], b.numpy(), relu=True)
     xa = ops.Act.from_nchw(x.to(dev), torch.float32)
     ra = ops.Act(br.permute(0, 2, 3, 1).contiguous().to(dev))
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4):
         out = ops.Act(torch.full((n, h, w, cout), -5.0, dtype=torch.float32, device=dev))
         o16 = ops.Act(torch.zeros((n, h, w, cout), dtype=torch.float16, device=dev))
         plan([xa], out, h, w, res=ra, out16=o16, tile=tile)
@@ -357,7 +357,7 @@ def test_subsampled_fp32_output_keeps_the_even_grid(h, w):
     with ops.f32_split():
         plan = ops.ConvPlan(torch.float32, [cin], [1], cout, conv_taps(wt.numpy()), b.numpy(), relu=True)
     xa = ops.Act.from_nchw(x.to(dev), torch.float32)
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4):
         full = ops.Act.empty(n, h, w, cout, torch.float32, dev)
         f16 = ops.Act.empty(n, h, w, cout, torch.float16, dev)
         plan([xa], full, h, w, res=r16, out16=f16, tile=tile)
