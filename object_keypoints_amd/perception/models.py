@@ -184,6 +184,27 @@ class KeypointNet(_HipModule):
         h1, d1, c1, h2, d2, c2 = [torch.cat(t) if len(outs) > 1 else t[0] for t in zip(*outs)]
         return (h1, h2), (d1, d2), (c1, c2)
 
+    def precision_audit(self, x, against=ops.F32X3):
+        """Run the deployed outputs of frames `x` in this network's compute precision AND in `against` (default: the split-product
+        configuration, fp32-grade: 2e-6 on the test networks) on the same weights, both on the HIP path, and return the absolute
+        differences {"heat" | "depth" | "centers": {"max", "mean", "p99"}}.  The error of a 16-bit or mixed configuration depends on
+        the weights: this is the on-device check that a plan chosen on one network still holds on another - a few
+        frames, two passes, no CPU reference involved."""
+        mine = (self.compute_dtype, self.mfma_split, self.mixed)
+        with torch.no_grad():
+            got = [t.float().clone() for t in self.deployed(x)]
+            try:
+                self.compute_dtype, self.mfma_split, self.mixed = ops.parse_compute_dtype(against)
+                ref = [t.float() for t in self.deployed(x)]
+            finally:
+                self.compute_dtype, self.mfma_split, self.mixed = mine
+        report = {}
+        for name, g, r in zip(("heat", "depth", "centers"), got, ref):
+            d = (g - r).abs().flatten()
+            k = max(1, int(round(0.99 * d.numel())))
+            report[name] = {"max": float(d.max()), "mean": float(d.mean()), "p99": float(d.kthvalue(k).values)}
+        return report
+
     def deployed(self, x):
         """What the packaged model returns (scripts/package_model.py:26-28):
         sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed."""

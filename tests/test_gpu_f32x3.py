@@ -389,3 +389,26 @@ def test_mixed_network_on_other_frame_sizes_and_uint8_frames():
     mix.raw_frame_size = None
     hu, hf = mix.deployed(u8)[0], x3.deployed(xf.contiguous())[0]
     assert float((hu - hf).abs().max()) <= 1e-3
+
+
+def test_precision_audit_prices_a_configuration_on_the_device():
+    """KeypointNet.precision_audit: the same weights run in the network's own precision and in the split-product configuration, both on
+    the HIP path; the differences it reports are those measured against the reference's golden outputs (float32x3 is within 3e-6 of them),
+    and the network is left in its own configuration."""
+    from object_keypoints_amd import ops, synth
+    case = cases.NET_CASES["valve_k3"]
+    g = gu.golden_net("valve_k3")
+    x = torch.from_numpy(synth.frames(1, seed=case["frame_seed"], start=case["frame_index"])).cuda()
+    for dtype, lo, hi in ((ops.F32MIX, 2e-4, 7.5e-4), (torch.float16, 1e-3, 3e-3), (torch.bfloat16, 5e-3, 3e-2)):
+        net = _net(case, dtype)
+        before = (net.compute_dtype, net.mfma_split, net.mixed)
+        rep = net.precision_audit(x)
+        assert (net.compute_dtype, net.mfma_split, net.mixed) == before
+        e_golden = float(np.abs(net.deployed(x)[0].cpu().numpy() - g["heat"]).max())
+        print(dtype, rep["heat"], e_golden)
+        assert lo <= rep["heat"]["max"] <= hi
+        assert abs(rep["heat"]["max"] - e_golden) <= 1e-5 + 0.02 * e_golden
+        assert rep["heat"]["mean"] <= rep["heat"]["p99"] <= rep["heat"]["max"]
+        assert set(rep) == {"heat", "depth", "centers"}
+    rep = _net(case, ops.F32X3).precision_audit(x, against=torch.float32)       # the two fp32-grade configurations against each other
+    assert rep["heat"]["max"] <= 1e-5
