@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 3     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3 */
+#define OKP_ABI_VERSION 4     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -187,6 +187,13 @@ int okp_cast(int src_dtype, const void* src_dev, int dst_dtype, void* dst_dev, i
 /* out = act(a + b) on contiguous tensors of `count` elements, a fp16, b and out fp32: the closing add of a residual block whose branch
  * ran on the fp16 kernels while the skip is the fp32 stream itself (residual without projection, py_utils/utils.py:184-185). */
 int okp_add_f16_f32(const void* a_f16_dev, const float* b_dev, float* out_dev, int64_t count, int act, void* stream);
+
+/* Stream `waiter` waits for everything enqueued on stream `signaller` so far (both on the current device): the fork / join of the hourglass'
+ * up1 branch that runs on a side stream next to the low path (hg_module.forward, py_utils/modules.py:50-66 - the reference runs the two
+ * one after the other).  Same semantics as an event record + stream wait, with an event that carries NO system-scope fence
+ * (hipEventDisableSystemFence): the dependency is device-to-device, kernel boundaries already release / acquire at device scope, and the
+ * cache writeback a default event adds to the signalling stream is what a fork costs the critical path.  Safe under stream capture. */
+int okp_stream_wait_stream(void* waiter, void* signaller);
 
 /* ------------------------------------------------------------------------------------
  * Frame packing for the 7x7/s2 stem: NCHW fp32 (n,3,h,w) -> NHWC4 `dtype` with a zero halo,

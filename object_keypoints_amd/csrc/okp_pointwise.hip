@@ -504,3 +504,28 @@ extern "C" int okp_head_out_forward(int dtype, const okp_head_out_args* a, void*
   else hipLaunchKernelGGL(okp_head_out_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_head_out launch");
 }
+
+// ---- cross-stream dependency without a system-scope fence (okp.h: okp_stream_wait_stream) ----------------------------------------
+namespace {
+constexpr int kEdgeEvents = 256;        // round-robin: a wait holds its own reference to the record it was given, re-recording an event later is safe
+struct EdgeEvents {
+  hipEvent_t ev[kEdgeEvents] = {};
+  int device = -1;
+  unsigned next = 0;
+};
+thread_local EdgeEvents t_edges;
+}  // namespace
+
+extern "C" int okp_stream_wait_stream(void* waiter, void* signaller) {
+  int dev = 0;
+  if (int e = okp_check_hip(hipGetDevice(&dev), "hipGetDevice")) return e;
+  EdgeEvents& E = t_edges;
+  if (E.device != dev) {                // (events belong to the device they were created on; a thread that changes device gets new ones)
+    for (hipEvent_t& e : E.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    E.device = dev; E.next = 0;
+  }
+  hipEvent_t& ev = E.ev[E.next++ % kEdgeEvents];
+  if (!ev) { if (int e = okp_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreateWithFlags")) return e; }
+  if (int e = okp_check_hip(hipEventRecord(ev, (hipStream_t)signaller), "hipEventRecord")) return e;
+  return okp_check_hip(hipStreamWaitEvent((hipStream_t)waiter, ev, 0), "hipStreamWaitEvent");
+}

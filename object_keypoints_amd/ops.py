@@ -363,6 +363,17 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
 
 
+LIGHT_EVENTS = os.environ.get("OKP_LIGHT_EVENTS", "1") == "1"     # forks / joins through okp_stream_wait_stream (no system-scope fence)
+
+
+def stream_wait(waiter, signaller):
+    """`waiter` (torch.cuda.Stream) waits for the work enqueued on `signaller` so far."""
+    if LIGHT_EVENTS:
+        _lib.check(_lib.lib().okp_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaller.cuda_stream)), "okp_stream_wait_stream")
+    else:
+        waiter.wait_stream(signaller)
+
+
 def cast(src, dtype):
     """Act -> Act of another element type (okp_cast: fp32 <-> fp16 / bf16): the boundary of an fp16 sub-network inside the fp32 stream."""
     if src.c0 != 0 or src.c != src.t.shape[3]:

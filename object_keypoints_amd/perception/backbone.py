@@ -445,12 +445,12 @@ class hg_module(nn.Module):
             return self.up2(low3, up1)
         main = torch.cuda.current_stream()
         side = self._side_stream(x.t.device)
-        side.wait_stream(main)                          # x is ready on the side stream
+        ops.stream_wait(side, main)                     # x is ready on the side stream
         with torch.cuda.stream(side):
             up1 = self.up1(x)
         x.t.record_stream(side)
         low3 = self._low_path(x)
-        main.wait_stream(side)                          # join before the merge
+        ops.stream_wait(main, side)                     # join before the merge
         up1.t.record_stream(main)
         return self.up2(low3, up1)
 

@@ -434,3 +434,35 @@ def test_stereo_stream_pipeline_tick_recovers_the_rendered_points():
     tiny = pp.StereoStreamPipeline(net, stereo, {"keypoint_config": [1, 3]}, capacity=2)
     with pytest.raises(pp.OkpError):
         tiny.tick(frames, heat_override=heat_dev)      # three bumps in one map, room for two
+
+
+def test_stream_wait_stream_orders_work_across_streams():
+    """okp_stream_wait_stream (the fork / join of the hourglass branches; events without a system-scope fence): a consumer stream sees
+    what the producer stream wrote before the edge, 600 edges in a row (the ring of 256 events is reused), in both directions; with
+    OKP_LIGHT_EVENTS=0 semantics (torch's wait_stream) as the reference behaviour."""
+    from object_keypoints_amd import ops
+    dev = torch.device("cuda", 0)
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    n = 32 << 20
+    src = torch.zeros(n, dtype=torch.float32, device=dev)
+    mid = torch.zeros(n, dtype=torch.float16, device=dev)
+    dst = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(600):
+        prod, cons = (a, b) if it % 2 == 0 else (b, a)
+        with torch.cuda.stream(prod):
+            src.fill_(float(it % 1000))                                   # a 128 MB fill: still running when the consumer is enqueued
+            ops.cast(ops.Act(src.view(1, 1, -1, 64)), torch.float16).t.view(-1)[:1]      # (another launch behind it on the producer)
+            mid.copy_(src)
+        ops.stream_wait(cons, prod)
+        with torch.cuda.stream(cons):
+            dst.copy_(mid)
+            probe = dst[::1 << 20].clone()
+        ops.stream_wait(prod, cons)                                        # the next iteration's producer must not overwrite early
+        if it % 50 == 49:
+            torch.cuda.synchronize()
+            bad += int((probe != float(it % 1000)).sum())
+    torch.cuda.synchronize()
+    assert bad == 0
+    assert ops.LIGHT_EVENTS
