@@ -187,7 +187,7 @@ class KeypointNet(_HipModule):
     def precision_audit(self, x, against=ops.F32X3):
         """Run the deployed outputs of frames `x` in this network's compute precision AND in `against` (default: the split-product
         configuration, fp32-grade: 2e-6 on the test networks) on the same weights, both on the HIP path, and return the absolute
-        differences {"heat" | "depth" | "centers": {"max", "mean", "p99"}}.  The error of a 16-bit or mixed configuration depends on
+        differences {"heat" | "depth" | "centers": {"max", "mean", "p99", "finite"}}.  The error of a 16-bit or mixed configuration depends on
         the weights: this is the on-device check that a plan chosen on one network still holds on another - a few
         frames, two passes, no CPU reference involved."""
         mine = (self.compute_dtype, self.mfma_split, self.mixed)
@@ -202,7 +202,8 @@ class KeypointNet(_HipModule):
         for name, g, r in zip(("heat", "depth", "centers"), got, ref):
             d = (g - r).abs().flatten()
             k = max(1, int(round(0.99 * d.numel())))
-            report[name] = {"max": float(d.max()), "mean": float(d.mean()), "p99": float(d.kthvalue(k).values)}
+            report[name] = {"max": float(d.max()), "mean": float(d.mean()), "p99": float(d.kthvalue(k).values),
+                            "finite": bool(torch.isfinite(g).all()) and bool(torch.isfinite(r).all())}      # (fp16 operands overflow above 65504)
         return report
 
     def deployed(self, x):
