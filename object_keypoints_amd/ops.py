@@ -318,6 +318,9 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
 
 
 FIRE_CHAIN_MAX = 8
+# shortest run of chainable modules that takes the resident launch: 1 - a single fire(384, 384) on an 8 x 8 map (low1[1] of the 16 x 16 level)
+# is one latency-bound tile per workgroup either way, and the resident kernel has the shorter chain of waits (step -0.6 %, ABBA)
+FIRE_CHAIN_MIN = int(os.environ.get("OKP_FIRE_CHAIN_MIN", "1"))
 FUSE_FIRE_CHAIN_FRAMED = os.environ.get("OKP_FIRE_CHAIN_FRAMED", "1") == "1"   # entry (stride 2) + chain + exit modules of the innermost level in one launch
 FUSE_FIRE_CHAIN = os.environ.get("OKP_FUSE_FIRE_CHAIN", "1") == "1"   # consecutive 512-channel fire modules on <= 4x4 maps: one resident launch
 

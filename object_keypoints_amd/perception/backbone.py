@@ -391,7 +391,7 @@ def run_fire_modules(mods, x):
         j = i
         while j < len(mods) and j - i < ops.FIRE_CHAIN_MAX and chainable(mods[j], x) and mods[j].inp_dim == mods[i].inp_dim:
             j += 1
-        if j - i >= 2:
+        if j - i >= ops.FIRE_CHAIN_MIN:
             plans = [m._plan(("p", x.dtype), lambda m=m: m._build(x.dtype, x.t.device)) for m in mods[i:j]]
             out = Act.empty(x.n, x.h, x.w, mods[i].out_dim, x.dtype, x.t.device)
             ops.fire_chain(plans, x, out)

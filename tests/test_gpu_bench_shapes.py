@@ -95,7 +95,7 @@ def test_streaming_fire_kernel_at_bench_shapes(c, co, h, stride, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("form", ["innermost_level", "pair_384"])
+@pytest.mark.parametrize("form", ["innermost_level", "pair_384", "single_384"])
 def test_resident_chains_at_bench_batch(form, dtype):
     """okp_fire_chain at N=64 as the bench launches it: the innermost hourglass level in one launch (stride-2 fire(384, 512) from 8x8,
     six fire(512, 512), fire(512, 384): entry / exit form) and a pair of fire(384, 384) at 8x8 - against the oracle's modules on frames
@@ -104,7 +104,7 @@ def test_resident_chains_at_bench_batch(form, dtype):
     from object_keypoints_amd.perception import backbone as bb
     from oracle import net as onet
     _need(dtype)
-    shapes = [(384, 512, 2)] + [(512, 512, 1)] * 6 + [(512, 384, 1)] if form == "innermost_level" else [(384, 384, 1)] * 2
+    shapes = [(384, 512, 2)] + [(512, 512, 1)] * 6 + [(512, 384, 1)] if form == "innermost_level" else [(384, 384, 1)] * (2 if form == "pair_384" else 1)
     omods = [onet.load_synthetic(onet.fire_module(a, b, stride=st), seed=80 + i) for i, (a, b, st) in enumerate(shapes)]
     mods = []
     for o, (a, b, st) in zip(omods, shapes):

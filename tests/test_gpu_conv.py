@@ -276,7 +276,7 @@ def test_stem_kernel_rejects_bad_views():
 
 
 @pytest.mark.parametrize("c,h,w,n,count", [(512, 4, 4, 5, 6), (512, 3, 4, 2, 2), (512, 2, 2, 3, 8), (512, 1, 3, 1, 3),
-                                             (384, 8, 8, 3, 2), (384, 7, 5, 2, 3), (384, 4, 4, 2, 2), (384, 8, 3, 1, 4)])
+                                             (384, 8, 8, 3, 2), (384, 7, 5, 2, 3), (384, 4, 4, 2, 2), (384, 8, 3, 1, 4), (384, 8, 8, 3, 1), (512, 4, 4, 2, 1)])
 @pytest.mark.parametrize("dtype", HALF)
 def test_fire_chain_matches_module_by_module(c, h, w, n, count, dtype):
     """okp_fire_chain_forward (activations resident in LDS across `count` fire(512, 512) modules) against the oracle's
