@@ -366,6 +366,7 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
 
 
+HOLD_BRANCH_OUTPUTS = os.environ.get("OKP_HOLD_BRANCH", "1") == "1"   # hourglass branches: lifetimes by program order instead of Tensor.record_stream
 LIGHT_EVENTS = os.environ.get("OKP_LIGHT_EVENTS", "1") == "1"     # forks / joins through okp_stream_wait_stream (no system-scope fence)
 
 

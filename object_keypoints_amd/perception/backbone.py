@@ -446,13 +446,30 @@ class hg_module(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_stream(x.t.device)
         ops.stream_wait(side, main)                     # x is ready on the side stream
+        if not ops.HOLD_BRANCH_OUTPUTS:
+            with torch.cuda.stream(side):
+                up1 = self.up1(x)
+            x.t.record_stream(side)
+            low3 = self._low_path(x)
+            ops.stream_wait(main, side)                 # join before the merge
+            up1.t.record_stream(main)
+            return self.up2(low3, up1)
+        # Tensor lifetimes across the two streams WITHOUT Tensor.record_stream (the caching allocator answers a recorded use with an
+        # event record on the using stream when the tensor dies - a marker packet in the MAIN queue right behind every merge, 6-8 us of
+        # delay for the kernel after it, eight times per step):
+        #  * x (main stream's pool) is read by the branch: it is this call's argument, alive until the call returns, and the join
+        #    below puts every branch kernel before anything the main stream does afterwards;
+        #  * up1 (side stream's pool) is read by the merge on the main stream: it is kept alive until this side stream next waits for
+        #    the main stream (the next fork that uses it), from where on every side-stream kernel comes after that merge.
+        held = _HELD_BRANCH_OUTPUTS.setdefault(side.cuda_stream, [])
+        held.clear()                                    # (the wait above orders the side stream behind the merges that read these)
         with torch.cuda.stream(side):
             up1 = self.up1(x)
-        x.t.record_stream(side)
         low3 = self._low_path(x)
         ops.stream_wait(main, side)                     # join before the merge
-        up1.t.record_stream(main)
-        return self.up2(low3, up1)
+        out = self.up2(low3, up1)
+        held.append(up1.t)
+        return out
 
     def _low_path(self, x):
         if isinstance(self.low2, _FireSeq):             # innermost level: low1, low2, low3 are one list of fire modules
@@ -474,6 +491,7 @@ class hg_module(nn.Module):
 
 
 _SIDE_STREAMS = {}
+_HELD_BRANCH_OUTPUTS = {}        # side stream handle -> branch outputs the main stream may still be reading (hg_module.forward)
 
 
 class _MergeMod(nn.Sequential):

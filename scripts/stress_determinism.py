@@ -29,5 +29,20 @@ with torch.no_grad():
                     print(f"{name}: repetition {r} differs in {int((a != b).sum())} elements, max {float((a - b).abs().max()):.3g}", flush=True)
         print(f"{name}: {reps} repetitions of 64 frames, {diff} mismatching outputs; finite: {all(bool(torch.isfinite(t).all()) for t in first)}", flush=True)
         bad += diff
+        # tensor lifetimes across the side streams (hg_module.forward keeps branch outputs alive by program order, not by
+        # Tensor.record_stream): passes of changing batch size make the caching allocator hand the same blocks to other tensors;
+        # every pass must equal the pass of the same frames with the branches on the main stream
+        diff = 0
+        for r in range(max(4, reps // 4)):
+            for b in (64, 24, 48, 8, 56):
+                xb = x[:b]
+                got = [t.clone() for t in net.deployed(xb)]
+                ops.SIDE_STREAMS = False
+                want = net.deployed(xb)
+                ops.SIDE_STREAMS = True
+                torch.cuda.synchronize()
+                diff += sum(0 if torch.equal(a, c) else 1 for a, c in zip(got, want))
+        print(f"{name}: changing batch sizes, side streams against one stream: {diff} mismatching outputs", flush=True)
+        bad += diff
         del net
 sys.exit(1 if bad else 0)
