@@ -366,6 +366,8 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
 
 
+SIDE_STREAM_OF_LEVEL = [int(v) for v in os.environ.get("OKP_SIDE_STREAM_OF_LEVEL", "0,1,2,2").split(",")]   # side stream of the 64x64, 32x32, 16x16, 8x8 level
+SKIP_COVERED_JOINS = os.environ.get("OKP_SKIP_COVERED_JOINS", "1") == "1"
 HOLD_BRANCH_OUTPUTS = os.environ.get("OKP_HOLD_BRANCH", "1") == "1"   # hourglass branches: lifetimes by program order instead of Tensor.record_stream
 LIGHT_EVENTS = os.environ.get("OKP_LIGHT_EVENTS", "1") == "1"     # forks / joins through okp_stream_wait_stream (no system-scope fence)
 

@@ -465,8 +465,15 @@ class hg_module(nn.Module):
         held.clear()                                    # (the wait above orders the side stream behind the merges that read these)
         with torch.cuda.stream(side):
             up1 = self.up1(x)
+        # A join covers every branch enqueued on that side stream before it: levels that share a side stream are nested, the inner
+        # level's branch is enqueued later and joined first, so the outer level finds its branch already joined and skips the barrier
+        # packet (6 us on the main queue).
+        seq = _SIDE_SEQ[side.cuda_stream] = _SIDE_SEQ.get(side.cuda_stream, 0) + 1
         low3 = self._low_path(x)
-        ops.stream_wait(main, side)                     # join before the merge
+        jkey = (main.cuda_stream, side.cuda_stream)
+        if not ops.SKIP_COVERED_JOINS or _JOINED_SEQ.get(jkey, 0) < seq:
+            ops.stream_wait(main, side)                 # join before the merge
+            _JOINED_SEQ[jkey] = _SIDE_SEQ[side.cuda_stream]
         out = self.up2(low3, up1)
         held.append(up1.t)
         return out
@@ -483,7 +490,8 @@ class hg_module(nn.Module):
         with the shared three; GPU_MAX_HW_QUEUES above its default of 4 costs 30 %, below it 1-5 %)."""
         # keyed by the MAIN stream as well: a pass that runs (or is being captured) on another stream - another host thread, a
         # second pipeline's hipGraph capture - gets its own side streams instead of recording into a foreign capture
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, min(4 - self.n, 2) if self.n <= 4 else 0)
+        group = ops.SIDE_STREAM_OF_LEVEL[4 - self.n] if 1 <= self.n <= 4 else 0
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, group)
         st = _SIDE_STREAMS.get(key)
         if st is None:
             st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -491,6 +499,7 @@ class hg_module(nn.Module):
 
 
 _SIDE_STREAMS = {}
+_SIDE_SEQ, _JOINED_SEQ = {}, {}  # branches enqueued per side stream; (main, side) -> newest branch a join has covered
 _HELD_BRANCH_OUTPUTS = {}        # side stream handle -> branch outputs the main stream may still be reading (hg_module.forward)
 
 
