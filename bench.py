@@ -19,10 +19,12 @@ frame); the network itself runs in full on the frames in every step.
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (the patch-resident 3x3 implicit-GEMM kernel), timed
 live with HIP events on the launch stream during the timed steps; `cpu_baseline` = the oracle (torch-CPU fp32
-restatement + NumPy post-processing) on the host cores, N=1 only, bounded sample.  At N=1 the line also carries `fp32`
-(BASELINE configs[1] precision: the path that meets the 1e-3 heat-map bar) and `fp16` (configs[4] precision) objects,
-each {value, ms_per_step, roofline, heat_err_vs_oracle}; `heat_err_vs_oracle` is the measured |heat - oracle heat| on
-the cpu_baseline's frames for that precision.
+restatement + NumPy post-processing) on the host cores, N=1 only, bounded sample.  At N=1 the line also carries `f32mix`,
+`f32x3`, `fp32` (BASELINE configs[1] precision) and `fp16` (configs[4] precision) objects, each {value, ms_per_step, roofline,
+collective, heat_err_vs_oracle, depth_err_vs_oracle, peak_jaccard, p_C_err_m, meets}: every north_star tolerance of that
+precision measured on the cpu_baseline's frames against the oracle (parity_fields).  `collective` describes the one
+data-path collective as this run saw it (backend, ranks, payload, median all-gather time).  `roofline.counter_commit` /
+`stale` say which tree the committed PMC counters were collected on.
 """
 import argparse
 import json
@@ -39,6 +41,7 @@ GFLOP_PER_FRAME = 74.565218304          # 37 282 609 152 MACs x 2 (SURVEY.md §8
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x3": 2500.0, "f32mix": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 # f32x3 (ops.F32X3): fp32 tensors, every product as three fp16 MFMA terms.  `achieved` counts the ALGORITHMIC FLOPs once, the peak is
 # the fp16 pipe's: a perfect kernel of this kind would read frac = 1/3 (roofline.mfma_terms says so in the line).
+PEAK_HBM_GBPS = 8000.0                  # HBM3E spec (6 290 GB/s measured with a float4 copy), same guide
 ERR_FRAMES = 4                          # frames of the cpu_baseline sample on which every precision is compared with the oracle
 
 
@@ -131,12 +134,13 @@ def self_launch(args, argv, device_count, popen=subprocess.Popen, out=sys.stdout
 # --------------------------------------------------------------------------------------------------
 
 class KernelTimer:
-    """ops.LAUNCH_HOOK: brackets launches of ONE implicit-GEMM instantiation with HIP events recorded on
-    the launch stream (torch's current stream is the stream the C ABI launches on)."""
+    """ops.LAUNCH_HOOK: brackets the launches of named implicit-GEMM populations with HIP events recorded on the launch
+    stream (torch's current stream is the stream the C ABI launches on).  A population = (plan dtype, tile codes, n_src or
+    None, split-product plans only?)."""
 
-    def __init__(self, dtype, tile, n_src):
-        self.key = (dtype, tile, n_src)
-        self.records = []
+    def __init__(self, populations):
+        self.pops = populations            # {label: (torch dtype, tiles, n_src | None, split | None)}
+        self.records = {k: [] for k in populations}
         self.enabled = False
         self.step = 0
         # a HIP event record costs the queue 6-7 us (a barrier packet): bracketing all 12 launches of every step took 1.3 % off the
@@ -145,22 +149,73 @@ class KernelTimer:
 
     def before(self, plan, tile, macs):
         import torch
-        if not self.enabled or self.step % self.every or plan.dtype != self.key[0] or tile not in self.key[1] or (self.key[2] is not None and plan.n_src != self.key[2]):
+        if not self.enabled or self.step % self.every:
             return None
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        return (e0, e1, macs)
+        for label, (dtype, tiles, n_src, split) in self.pops.items():
+            if plan.dtype == dtype and tile in tiles and (n_src is None or plan.n_src == n_src) and (split is None or plan.split == split):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                return (label, e0, e1, macs, getattr(plan, "last_bytes", 0))
+        return None
 
     def after(self, token):
         if token is not None:
-            token[1].record()
-            self.records.append(token)
+            token[2].record()
+            self.records[token[0]].append(token[1:])
 
-    def summary(self):
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        flops = 2.0 * sum(m for _, _, m in self.records)
-        return len(self.records), ms, flops
+    def summary(self, label):
+        rec = self.records[label]
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
+        return len(rec), ms, 2.0 * sum(m for _, _, m, _ in rec), float(sum(b for _, _, _, b in rec))
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def counter_provenance(path):
+    """Which tree a committed counter file was measured on: the `commit` its profile script stamped into `<file>.meta.json`
+    (scripts/profile_all.sh), compared with the kernels' sources as they are now.  stale = some file under csrc/ or include/ changed since."""
+    meta_path = path[:-5] + ".meta.json" if path.endswith(".json") else path + ".meta.json"
+    commit = None
+    if os.path.exists(meta_path):
+        try:
+            with open(meta_path) as f:
+                commit = json.load(f).get("commit")
+        except (OSError, ValueError):
+            commit = None
+    if commit is None:
+        return {"counter_commit": None, "stale": True, "stale_reason": "no commit stamp next to the counter file (a pre-round-4 set)"}
+    try:
+        r = subprocess.run(["git", "-C", REPO, "diff", "--quiet", commit, "--", "object_keypoints_amd/csrc", "include"], capture_output=True, timeout=20)
+        if r.returncode == 0:
+            return {"counter_commit": commit, "stale": False}
+        if r.returncode == 1:
+            return {"counter_commit": commit, "stale": True, "stale_reason": "kernel sources changed since the counters were collected"}
+    except Exception:
+        pass
+    # no git history on this box (a gpurun snapshot): compare with the source hash the profile script stamped
+    try:
+        with open(meta_path) as f:
+            want = json.load(f).get("csrc_sha16")
+        return {"counter_commit": commit, "stale": want != csrc_sha16(), **({} if want == csrc_sha16() else {"stale_reason": "kernel sources differ from the stamped hash"})}
+    except Exception:
+        return {"counter_commit": commit, "stale": None, "stale_reason": "cannot compare (no git history, no source hash)"}
+
+
+def csrc_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for d in ("object_keypoints_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(REPO, d))):
+            if f.endswith((".hip", ".h", ".cpp")):
+                with open(os.path.join(REPO, d, f), "rb") as fh:
+                    h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def committed_counters(kernel_sig, precision="bf16"):
@@ -171,7 +226,8 @@ def committed_counters(kernel_sig, precision="bf16"):
     profiles/r*_<precision>_pmc_hbm_traffic.json / ..._sq_counters.json for the others (scripts/profile_r03.sh).  Null when absent."""
     import glob
     import re
-    res = {"traffic": None, "traffic_source": None, "mfma_busy": None, "lds_wait": None, "hbm_GBps": None, "counter_source": None}
+    res = {"traffic": None, "traffic_source": None, "mfma_busy": None, "lds_wait": None, "hbm_GBps": None, "counter_source": None,
+           "counter_commit": None, "stale": None}
     tag = "" if precision == "bf16" else precision + "_"
     pat = re.compile(r"^r\d+[a-z]*_" + tag + r"(pmc_hbm_traffic|sq_counters)\.json$")
     def newest(kind):
@@ -184,6 +240,7 @@ def committed_counters(kernel_sig, precision="bf16"):
             if any(sig in name for sig in kernel_sig):
                 res["traffic"] = (row["fetch_MB_per_launch_corrected"] + row["write_MB_per_launch"]) * 1e6
                 res["traffic_source"] = os.path.basename(files[-1])
+                res.update(counter_provenance(files[-1]))
                 break
     files = newest("sq_counters")
     if files:
@@ -225,7 +282,7 @@ def usable_cores():
 
 def cpu_baseline(seconds):
     """The oracle (a port: torch-CPU fp32 restatement + NumPy post-processing) on the host cores.  Also returns the
-    oracle's heat maps of the sample frames: the checker for `heat_err_vs_oracle`."""
+    oracle's heat / depth maps of the sample frames: the checker for the `*_vs_oracle` fields of every precision."""
     import numpy as np
     import torch
     from oracle import net as onet
@@ -242,7 +299,7 @@ def cpu_baseline(seconds):
     def step():
         heat, depth, _ = onet.deployed_forward(net, x)
         heat, depth = heat.numpy(), depth.numpy()
-        keep["heat"] = heat
+        keep["heat"], keep["depth"] = heat, depth
         for n in range(heat.shape[0]):
             for k in range(heat.shape[1]):
                 idx = op.peak_indices(heat[n, k])[:64]
@@ -259,7 +316,7 @@ def cpu_baseline(seconds):
             break
     return ({"value": frames / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
              "sample": f"{frames} frames (batches of {ERR_FRAMES}, 3x511x511 fp32): oracle torch-CPU forward + NumPy peak-NMS/centroid/depth lifting, {el:.1f} s"},
-            keep["heat"])
+            keep)
 
 
 TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32", "f32mix": "float32"}
@@ -268,10 +325,12 @@ OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3", "f
 KERNEL_SIG = {"bf16": ("okp_igemm_patch_kernel",), "f16": ("okp_igemm_patch_kernel",),
               "f32": ("okp_igemm_kernel<float, 256, 256, 4, 2, 2, 128, 32, 1>", "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"),
               "f32x3": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"),
-              "f32mix": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E")}
+              "f32mix": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"),
+              "f32mix_hbm": ("okp_igemm_kernel<F32S, 128, 128,", "F32SELi128ELi128E")}
 KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
                "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>",
-               "f32mix": "okp_igemm_kernel<f32 split, 1 or 3 fp16 MFMA terms per tap,256x256,src1>"}
+               "f32mix": "okp_igemm_kernel<f32 split, 1 or 3 fp16 MFMA terms per tap,256x256,src1>",
+               "f32mix_hbm": "okp_igemm_kernel<f32 split,128x128> (1x1 convolutions / fire modules on fp32 tensors)"}
 
 
 def bump_maps(start, count, dev, keypoint_config=(1, 3)):
@@ -296,9 +355,14 @@ def run_precision(name, ctx, steps, warmup):
     pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, ctx["camera"], capacity=64)
     frames = ctx["frames"]
     b_heat, b_depth, b_centers, n_peaks = ctx["bumps"]
-    # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile
+    # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile;
+    # float32mix has two populations: the HBM-bound 128x128 split tiles (1x1 convolutions / fire modules on fp32 tensors: the largest
+    # share of its kernel time) and the MFMA-bound 256x256 split tile (`cnvs`, transposed convolutions)
     gather = name in ("f32", "f32x3", "f32mix")
-    timer = KernelTimer(dtype, (3,) if gather else (13,), 1 if gather else None)
+    pops = {"mfma": (dtype, (3,) if gather else (13,), 1 if gather else None, None)}
+    if name == "f32mix":
+        pops["hbm"] = (dtype, (2,), None, True)
+    timer = KernelTimer(pops)
     ops.LAUNCH_HOOK = timer
 
     def step():
@@ -324,27 +388,49 @@ def run_precision(name, ctx, steps, warmup):
         assert not bool(out["overflow"]), "peak / object capacity exceeded in the timed step"
         found = int(out["count"].sum())
         assert batch <= found <= n_peaks, (found, n_peaks)      # at least the centre of every frame; bumps closer than the 5x5 window merge
-        sample_heat = net.deployed(ctx["err_frames"])[0].cpu().numpy() if ctx["err_frames"] is not None else None
+        sample = None
+        if ctx["err_frames"] is not None:
+            # the error sample through the product path: maps, peak indices (okp_peak_nms) and per-peak 3D points (okp_lift_peaks)
+            h, d, _ = net.deployed(ctx["err_frames"])
+            cnt, yx, xyc = ops.peak_nms(h, cap=SAMPLE_CAP)
+            pts = ops.lift_peaks(pipe.cam, cnt, xyc, d, int(pipe.max_index[0]), int(pipe.max_index[1]))
+            sample = {k: v.cpu().numpy() for k, v in (("heat", h), ("depth", d), ("count", cnt), ("yx", yx), ("points", pts))}
+        coll = collective_probe(out["points"], batch, world, dev)
     value = batch * world * steps / elapsed
-    n_launch, k_ms, k_flops = timer.summary()
+    n_launch, k_ms, k_flops, _ = timer.summary("mfma")
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[name]
     ctr = committed_counters(KERNEL_SIG[name], name)
+    roof = {"bound": "mfma", "kernel": KERNEL_NAME[name], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": ctr["traffic"], "traffic_unit": "HBM bytes/launch",
+            "traffic_source": ctr["traffic_source"], "mfma_busy": ctr["mfma_busy"], "lds_wait": ctr["lds_wait"],
+            "hbm_GBps": ctr["hbm_GBps"], "counter_source": ctr["counter_source"], "counter_commit": ctr["counter_commit"], "stale": ctr["stale"],
+            "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
+            "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}
     res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-           "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3,
-           "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[name], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": ctr["traffic"], "traffic_unit": "HBM bytes/launch",
-                        "traffic_source": ctr["traffic_source"], "mfma_busy": ctr["mfma_busy"], "lds_wait": ctr["lds_wait"],
-                        "hbm_GBps": ctr["hbm_GBps"], "counter_source": ctr["counter_source"],
-                        "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
-                        "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}}
+           "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3, "roofline": roof}
+    if name == "f32mix":
+        # the population that takes the largest share of this configuration's kernel time is HBM-bound: it is the `roofline` object,
+        # the MFMA-bound split tile moves to `roofline_mfma`
+        n_h, ms_h, _, bytes_h = timer.summary("hbm")
+        ctr_h = committed_counters(KERNEL_SIG["f32mix_hbm"], name)
+        ach = bytes_h / (ms_h * 1e-3) / 1e9 if ms_h > 0 else 0.0
+        res["roofline_mfma"] = roof
+        res["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAME["f32mix_hbm"], "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                           "frac": ach / PEAK_HBM_GBPS, "traffic": ctr_h["traffic"], "traffic_unit": "HBM bytes/launch",
+                           "traffic_source": ctr_h["traffic_source"], "hbm_GBps": ctr_h["hbm_GBps"], "counter_source": ctr_h["counter_source"],
+                           "counter_commit": ctr_h["counter_commit"], "stale": ctr_h["stale"],
+                           "launches_timed": n_h, "avg_launch_us": (ms_h * 1e3 / n_h) if n_h else None,
+                           "avg_algorithmic_MB_per_launch": (bytes_h / n_h / 1e6) if n_h else None,
+                           "share_of_kernel_time": "largest single kernel of the float32mix step (29.9 % in profiles/r03y_f32mix_kernel_stats.csv)"}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
     if name == "f32mix":
-        res["roofline"]["mfma_terms"] = "1 (3x3 convolutions inside residual blocks) or 3 per tap"
+        res["roofline_mfma"]["mfma_terms"] = "1 (3x3 convolutions inside residual blocks) or 3 per tap"
+    res["collective"] = coll
     del pipe, net
     torch.cuda.empty_cache()
-    return res, sample_heat
+    return res, sample
 
 
 def run_stream8(ctx, ticks=200, warmup=10):
@@ -422,6 +508,72 @@ def run_stream8(ctx, ticks=200, warmup=10):
             "headroom_x": (1e3 / 30.0) / med_g, "points_per_tick": matched, "triangulation_err_m_max": worst}
 
 
+SAMPLE_CAP = 1024      # peak slots per map of the error sample (random-weight networks give flat maps: ~100 peaks each)
+
+
+def collective_probe(points, batch, world, dev, reps=8):
+    """The one data-path collective (all_gather_keypoints), bracketed by HIP events on a few calls AFTER the timed region: which
+    backend and how many ranks it saw, the payload per rank and its median duration.  Without a process group (plain
+    `python bench.py`) there is no collective and the object says so."""
+    import torch
+    import torch.distributed as dist
+    from object_keypoints_amd import distributed as dist_
+    payload = int(points.numel() * points.element_size())
+    if not dist.is_initialized():
+        return {"backend": None, "world": 1, "payload_bytes_per_rank": payload, "allgather_us_median": None,
+                "note": "no process group (not started by torchrun): all_gather_keypoints passes the tensor through"}
+    us = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist_.barrier()
+        e0.record()
+        g = dist_.all_gather_keypoints(points, total_frames=batch * world)
+        e1.record()
+        torch.cuda.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
+    assert g.shape[0] == batch * world
+    us.sort()
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "payload_bytes_per_rank": payload,
+            "gathered_bytes": int(g.numel() * g.element_size()), "allgather_us_median": us[len(us) // 2], "allgather_us_min": us[0], "calls": reps}
+
+
+def parity_fields(sample, oracle, camera_file):
+    """Every north_star tolerance of one precision on the error sample, against the oracle (= the reference, tests/golden):
+    heat maps (bar 1e-3), depth maps, peak-index sets (bar: identical, i.e. Jaccard 1.0) and the 3D points of the peaks both
+    sides found (bar 1e-4 m).  The oracle's peaks / points come from its own heat / depth maps through oracle.pipeline."""
+    import numpy as np
+    from oracle import pipeline as op
+    cam = op.eval_camera(camera_file)
+    d2p = op.DetectionToPoint(); d2p.reset(cam)
+    heat, depth = sample["heat"], sample["depth"]
+    inter = union = 0
+    worst = 0.0
+    n_pts = 0
+    for n in range(heat.shape[0]):
+        for k in range(heat.shape[1]):
+            idx = op.peak_indices(oracle["heat"][n, k])
+            c = int(sample["count"][n, k])
+            assert c <= SAMPLE_CAP, "error sample: more peaks than SAMPLE_CAP"
+            mine = {tuple(v): j for j, v in enumerate(sample["yx"][n, k, :c].tolist())}
+            theirs = [tuple(v) for v in idx.tolist()]
+            inter += len(set(theirs) & set(mine)); union += len(set(theirs) | set(mine))
+            pts, _ = op.refine_peaks(oracle["heat"][n, k], idx)
+            if not pts:
+                continue
+            want = d2p(np.stack(pts), oracle["depth"][n, k])
+            for j, key in enumerate(theirs):
+                if key in mine:
+                    worst = max(worst, float(np.linalg.norm(sample["points"][n, k, mine[key], :3] - want[j])))
+                    n_pts += 1
+    e_d = np.abs(depth.astype(np.float64) - oracle["depth"].astype(np.float64))
+    return {"heat_err_vs_oracle": heat_error(heat, oracle["heat"]),
+            "depth_err_vs_oracle": {"max": float(e_d.max()), "mean": float(e_d.mean())},
+            "peak_jaccard": inter / union if union else 1.0, "peaks_compared": union,
+            "p_C_err_m": worst, "p_C_points": n_pts,
+            "meets": {"heat_1e-3": bool(np.abs(heat - oracle["heat"]).max() <= 1e-3), "peaks_identical": inter == union,
+                      "p_C_1e-4_m": worst <= 1e-4}}
+
+
 def heat_error(got, want):
     import numpy as np
     e = np.abs(got.astype(np.float64) - want.astype(np.float64)).ravel()
@@ -476,6 +628,7 @@ def rank_main(args):
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
         "conv_stack_tflops_per_gpu": head["conv_stack_tflops_per_gpu"],
         "roofline": head["roofline"],
+        "collective": head["collective"],
     }
     extra_heat = {}
     if world == 1:
@@ -489,10 +642,11 @@ def rank_main(args):
     if world == 1 and not args.no_stream8:
         result["stream8"] = run_stream8(ctx)
     if with_cpu:
-        result["cpu_baseline"], oracle_heat = cpu_baseline(args.cpu_seconds)
-        result["heat_err_vs_oracle"] = heat_error(head_heat, oracle_heat)
-        for name, h in extra_heat.items():
-            result[OBJECT_KEY[name]]["heat_err_vs_oracle"] = heat_error(h, oracle_heat)
+        result["cpu_baseline"], oracle = cpu_baseline(args.cpu_seconds)
+        cal = os.path.join(REPO, "config", "calibration.yaml")
+        result.update(parity_fields(head_heat, oracle, cal))
+        for name, smp in extra_heat.items():
+            result[OBJECT_KEY[name]].update(parity_fields(smp, oracle, cal))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if torch.distributed.is_initialized():

@@ -106,6 +106,10 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
     const int s = taps[t].src, c = cin[s];
     if (c * esz == 64 && t + 1 < n_taps && taps[t + 1].src == s) {
       // two half-slice taps share one 128-byte slice (the bf16 stem: 8 px x 4 ch per kernel row)
+      if (tap_terms && (tap_terms[t] == 1 || tap_terms[t + 1] == 1)) {
+        okp_set_error("okp_conv_create_x3: taps %d / %d share one K-slice (64-byte sources): single-term products are not supported there", t, t + 1);
+        delete plan; return nullptr;
+      }
       OkpSlice sl{(uint8_t)t, (uint8_t)(t + 1), (uint8_t)s, 8, 0, 0, 0};
       slices.push_back(sl);
       t += 2;
@@ -431,6 +435,13 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
       okp_set_error("okp_conv_forward: n_classes must be 4 with out_step 2 and four equal tap groups"); return OKP_EINVAL;
     }
     if ((a->ho - 1) * 2 + a->out_oy + 1 >= a->out.h || (a->wo - 1) * 2 + a->out_ox + 1 >= a->out.w) { okp_set_error("okp_conv_forward: sub-pixel classes do not fit out"); return OKP_EINVAL; }
+  }
+  if (p.n_classes > 1 && plan->n_single_slices != 0 && plan->n_single_slices != plan->n_slices) {
+    // (single-term slices are sorted in front of the whole K range: with sub-pixel classes, each a K range of its own, that order
+    //  would move slices across class boundaries - a 4-tap plan passes the creation-time check of the 8+-tap case)
+    okp_set_error("okp_conv_forward: sub-pixel classes need one term count for all taps of the plan (%d of %d K-slices are single-term)",
+                  plan->n_single_slices, plan->n_slices);
+    return OKP_EINVAL;
   }
   p.slices_per_class = plan->n_slices / p.n_classes;
   p.n_single_slices = plan->n_single_slices / p.n_classes;

@@ -44,18 +44,18 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 MIX_FP16_LEVELS = int(os.environ.get("OKP_MIX_FP16_LEVELS", "2"))    # hg_module levels n <= this run in fp16 (n = 2: the 16 x 16 level)
-MIX_BRANCH_SINGLE = os.environ.get("OKP_MIX_BRANCH_SINGLE", "1") == "1"
+MIX_BRANCH_SINGLE = True        # (module attributes; the measured trade-off of each is in DESIGN.md 2.2)
 # ... and those single-term branches run on the fp16 kernels proper (the patch-resident 3x3 kernel: half the bytes, no in-loop conversion):
 # the producer of a stream tensor writes an fp16 copy next to it (okp_conv_args.out16), conv1 / conv2 are fp16 plans, and the block
 # closes with the three-term projected skip taking the fp16 branch as its residual (or okp_add_f16_f32).  0 = single-term taps of the
 # split-product kernel on the fp32 tensors (same products, slower).
-MIX_BRANCH_FP16 = os.environ.get("OKP_MIX_BRANCH_FP16", "1") == "1"
+MIX_BRANCH_FP16 = True
 # ... and a stream tensor whose only fp32 reader is the next block's stride-2 skip (stem output, pre[1] output) is kept in fp32 at even
 # rows / columns only (okp_conv_args.out_subsample): three quarters of its bytes were written and never read
-MIX_COMPACT = os.environ.get("OKP_MIX_COMPACT", "1") == "1"
+MIX_COMPACT = True
 # ... and the stem then runs as two launches: the fp16 stem kernel writes the full-grid fp16 tensor (read by pre[1].conv1 only: a branch
 # input), a stride-4 three-term launch the fp32 values at even pixels (read by pre[1]'s skip: the stream) - a quarter of the three-term work
-MIX_STEM_FP16 = os.environ.get("OKP_MIX_STEM_FP16", "1") == "1"
+MIX_STEM_FP16 = True
 
 
 class f32_split:
@@ -182,6 +182,8 @@ class ConvPlan:
         self.cout = cout
         self.n_src = len(cins)
         self.cins = list(cins)
+        self._strides = (list(strides) + [1])[:2]
+        self._tap_srcs = [t[0] for t in taps]
         n_taps = len(taps)
         arr_t = (_lib.okp_tap * n_taps)()
         keep = []
@@ -221,6 +223,27 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
+    def _algorithmic_bytes(self, srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample):
+        """Compulsory HBM bytes of one launch (bench.py's roofline of HBM-bound launches): every source pixel the taps sample once,
+        every output element once (+ the fp16 copy), the residual once; weights not counted (L2-resident, shared by all tiles)."""
+        esz = lambda a: a.t.element_size()
+        b = 0
+        for i, s_ in enumerate(srcs):
+            n_taps_src = sum(1 for t in self._tap_srcs if t == i)
+            stride = self._strides[i]
+            px = s_.h * s_.w if (n_taps_src > 1 or stride == 1) else ho * wo       # a strided 1x1 samples one pixel per output pixel
+            b += s_.n * px * self.cins[i] * esz(s_)
+        opx = out.n * ho * wo * (n_classes if n_classes > 1 else 1)
+        if write_out:
+            b += (opx // (out_subsample * out_subsample)) * self.cout * esz(out)
+        if out16 is not None:
+            b += opx * self.cout * 2
+        if res is not None:
+            b += opx * self.cout * esz(res)
+        if dw is not None:
+            b += opx * self.cout * esz(dw[2]) + (opx * self.cout * esz(dw[3]) if dw[3] is not None else 0)
+        return b
+
     def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True, out_subsample=1):
         """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch.
         Split-product plans: out16 = fp16 Act that receives the result as well (write_out=False: only that copy is written; `out` then
@@ -233,6 +256,10 @@ class ConvPlan:
         if out.dtype != self.dtype or out.c != self.cout:
             raise OkpError(f"out has {out.c} channels / {out.dtype}, plan has {self.cout} / {self.dtype}")
         res16 = res is not None and self.split and res.dtype == torch.float16
+        if res is not None and res.dtype != self.dtype and not res16:
+            raise OkpError(f"residual is {res.dtype}, plan is {self.dtype}" + (" (split-product plans also take a float16 residual)" if self.split else ""))
+        if dw is not None and (dw[2].dtype != self.dtype or (dw[3] is not None and dw[3].dtype != self.dtype)):
+            raise OkpError("depth-wise branch: dw_out / dw_res dtype differs from plan dtype")
         if (out16 is not None or res16 or not write_out) and not self.split:
             raise OkpError("out16 / fp16 residual / write_out=False belong to split-product (ops.F32X3) plans")
         if out16 is not None and (out16.dtype != torch.float16 or out16.c != self.cout):
@@ -251,6 +278,7 @@ class ConvPlan:
             s1 = srcs[1] if len(srcs) > 1 else None
             if hook is not None:
                 self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
+                self.last_bytes = self._algorithmic_bytes(srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample)
                 tile = _dispatch(T.conv_select_tile, self._h, srcs[0].t, srcs[0].c0, s1.t if s1 else None, s1.c0 if s1 else 0, out.t, out.c0, ho, wo,
                                  out_step, oy, ox, tile, n_classes, dw is not None)
                 token = hook.before(self, tile, macs)
@@ -286,6 +314,7 @@ class ConvPlan:
                 a.dw_res = dw_res.view() if dw_res is not None else _NULL_TENSOR
             if hook is not None:
                 self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
+                self.last_bytes = self._algorithmic_bytes(srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample)
                 a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
                 token = hook.before(self, a.tile, macs)
             _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
@@ -320,9 +349,10 @@ def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
 FIRE_CHAIN_MAX = 8
 # shortest run of chainable modules that takes the resident launch: 1 - a single fire(384, 384) on an 8 x 8 map (low1[1] of the 16 x 16 level)
 # is one latency-bound tile per workgroup either way, and the resident kernel has the shorter chain of waits (step -0.6 %, ABBA)
-FIRE_CHAIN_MIN = int(os.environ.get("OKP_FIRE_CHAIN_MIN", "1"))
-FUSE_FIRE_CHAIN_FRAMED = os.environ.get("OKP_FIRE_CHAIN_FRAMED", "1") == "1"   # entry (stride 2) + chain + exit modules of the innermost level in one launch
-FUSE_FIRE_CHAIN = os.environ.get("OKP_FUSE_FIRE_CHAIN", "1") == "1"   # consecutive 512-channel fire modules on <= 4x4 maps: one resident launch
+# (the FUSE_* / *_MIN values below are module attributes that tests flip to compare paths; they are not environment switches)
+FIRE_CHAIN_MIN = 1
+FUSE_FIRE_CHAIN_FRAMED = True   # entry (stride 2) + chain + exit modules of the innermost level in one launch
+FUSE_FIRE_CHAIN = True          # consecutive 512-channel fire modules on <= 4x4 maps: one resident launch
 
 
 def fire_chain(modules, x, out):
@@ -349,15 +379,14 @@ def fire_chain(modules, x, out):
 SIDE_STREAMS = True      # hourglass up1 branches run on side streams, concurrently with the low path
 SIDE_MIN_BATCH = int(os.environ.get("OKP_SIDE_MIN_BATCH", "8"))    # eager passes of fewer frames are host-bound and a fork / join costs the host ~40 us:
                                                                    # below this batch the branches run on the main stream (unless a hipGraph is being captured)
-SIDE_MIN_LEVEL = int(os.environ.get("OKP_SIDE_MIN_LEVEL", "1"))   # hourglass levels (4 = 64x64 ... 1 = 8x8) from which the fork is used
 FUSE_FIRE = True        # one-launch streaming fire module (okp_fire2.hip) where it exists: 256 -> 128 -> 256, stride 1
                         # (the two high-resolution hourglass levels): 98-104 us vs 140 us per module at 64x64, N=64
-FUSE_FIRE_MIN_HW = int(os.environ.get("OKP_FUSE_FIRE_MIN_HW", "8"))    # 4x4 maps: two launches are faster (25 vs 20 us)
+FUSE_FIRE_MIN_HW = 8    # 4x4 maps: two launches are faster (25 vs 20 us)
 
 
 _FIRE2_CONFIGS = {1: {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)},      # stride -> (cin, mid) instances of okp_fire2.hip
                   2: {(256, 128), (384, 192), (384, 256)}}
-FUSE_FIRE_S2 = os.environ.get("OKP_FUSE_FIRE_S2", "1") == "1"
+FUSE_FIRE_S2 = True
 
 
 def fire_fusable(inp_dim, mid, stride, h, w):
@@ -366,10 +395,7 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
 
 
-SIDE_STREAM_OF_LEVEL = [int(v) for v in os.environ.get("OKP_SIDE_STREAM_OF_LEVEL", "0,1,2,2").split(",")]   # side stream of the 64x64, 32x32, 16x16, 8x8 level
-SKIP_COVERED_JOINS = os.environ.get("OKP_SKIP_COVERED_JOINS", "1") == "1"
-HOLD_BRANCH_OUTPUTS = os.environ.get("OKP_HOLD_BRANCH", "1") == "1"   # hourglass branches: lifetimes by program order instead of Tensor.record_stream
-LIGHT_EVENTS = os.environ.get("OKP_LIGHT_EVENTS", "1") == "1"     # forks / joins through okp_stream_wait_stream (no system-scope fence)
+LIGHT_EVENTS = True     # forks / joins through okp_stream_wait_stream (events without a system-scope fence); False: torch's wait_stream
 
 
 def stream_wait(waiter, signaller):
@@ -563,7 +589,7 @@ def head_out(src, outputs, w_dev, bias_dev):
     COUNTERS["launches"] += 1
 
 
-FUSE_HEADS = os.environ.get("OKP_FUSE_HEADS", "1") == "1"    # bf16, 128 features: the three heads of a stack in one launch
+FUSE_HEADS = True    # 16-bit, 128 features: the three heads of a stack in one launch
 
 
 def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):

@@ -25,10 +25,11 @@ from ..ops import Act, ConvPlan, OkpError, StemPlan
 # ------------------------------------------------------------------------------------------
 
 import os
-STEM_DIRECT = os.environ.get("OKP_STEM_DIRECT", "1") != "0"     # bf16: the stem kernel reads fp32 NCHW frames itself (no pack launch)
-STEM_KERNEL = os.environ.get("OKP_STEM_KERNEL", "1") != "0"     # bf16: dedicated stem kernel (okp_stem.hip); 0 = generic tap-list kernel
-UNPOOL_TILE = int(os.environ.get("OKP_UNPOOL_TILE", "0"))   # experiments: tile code of the transposed-conv launches (0 = heuristic)
-STEM_TILE = int(os.environ.get("OKP_STEM_TILE", "4"))      # 7x7/s2 stem: 128 co x 256 px tile measured fastest (603 vs 728 us)
+# (module attributes, flipped by tests that compare the paths; not environment switches)
+STEM_DIRECT = True       # 16-bit: the stem kernel reads fp32 NCHW frames itself (no pack launch)
+STEM_KERNEL = True       # 16-bit: dedicated stem kernel (okp_stem.hip); False = generic tap-list kernel
+UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
+STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
 
 
 def _np(t):
@@ -439,44 +440,46 @@ class hg_module(nn.Module):
         if ops.F32_MIX and x.dtype == torch.float32 and self.n <= ops.MIX_FP16_LEVELS:
             # mixed configuration: this level and everything below it run in fp16 on the fused fp16 kernels (ops.F32MIX)
             return ops.cast(self.forward(ops.cast(x, torch.float16)), torch.float32)
-        if not ops.SIDE_STREAMS or self.n < ops.SIDE_MIN_LEVEL or (x.n < ops.SIDE_MIN_BATCH and not torch.cuda.is_current_stream_capturing()):
+        if not ops.SIDE_STREAMS or (x.n < ops.SIDE_MIN_BATCH and not torch.cuda.is_current_stream_capturing()):
+            for held in _HELD_BRANCH_OUTPUTS.values():      # (no fork in this pass: nothing of an earlier pass needs to stay pinned)
+                held.clear()
             up1 = self.up1(x)
             low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)
             return self.up2(low3, up1)
         main = torch.cuda.current_stream()
         side = self._side_stream(x.t.device)
         ops.stream_wait(side, main)                     # x is ready on the side stream
-        if not ops.HOLD_BRANCH_OUTPUTS:
-            with torch.cuda.stream(side):
-                up1 = self.up1(x)
-            x.t.record_stream(side)
-            low3 = self._low_path(x)
-            ops.stream_wait(main, side)                 # join before the merge
-            up1.t.record_stream(main)
-            return self.up2(low3, up1)
         # Tensor lifetimes across the two streams WITHOUT Tensor.record_stream (the caching allocator answers a recorded use with an
         # event record on the using stream when the tensor dies - a marker packet in the MAIN queue right behind every merge, 6-8 us of
         # delay for the kernel after it, eight times per step):
         #  * x (main stream's pool) is read by the branch: it is this call's argument, alive until the call returns, and the join
-        #    below puts every branch kernel before anything the main stream does afterwards;
+        #    below - in a finally clause: also when the low path raises - puts every branch kernel before anything the main stream
+        #    does afterwards;
         #  * up1 (side stream's pool) is read by the merge on the main stream: it is kept alive until this side stream next waits for
         #    the main stream (the next fork that uses it), from where on every side-stream kernel comes after that merge.
         held = _HELD_BRANCH_OUTPUTS.setdefault(side.cuda_stream, [])
         held.clear()                                    # (the wait above orders the side stream behind the merges that read these)
-        with torch.cuda.stream(side):
-            up1 = self.up1(x)
-        # A join covers every branch enqueued on that side stream before it: levels that share a side stream are nested, the inner
-        # level's branch is enqueued later and joined first, so the outer level finds its branch already joined and skips the barrier
-        # packet (6 us on the main queue).
-        seq = _SIDE_SEQ[side.cuda_stream] = _SIDE_SEQ.get(side.cuda_stream, 0) + 1
-        low3 = self._low_path(x)
         jkey = (main.cuda_stream, side.cuda_stream)
-        if not ops.SKIP_COVERED_JOINS or _JOINED_SEQ.get(jkey, 0) < seq:
-            ops.stream_wait(main, side)                 # join before the merge
-            _JOINED_SEQ[jkey] = _SIDE_SEQ[side.cuda_stream]
-        out = self.up2(low3, up1)
-        held.append(up1.t)
-        return out
+        joined = False
+        try:
+            with torch.cuda.stream(side):
+                up1 = self.up1(x)
+            # A join covers every branch enqueued on that side stream before it: levels that share a side stream are nested, the inner
+            # level's branch is enqueued later and joined first, so the outer level finds its branch already joined and skips the
+            # barrier packet (6 us on the main queue).
+            seq = _SIDE_SEQ[side.cuda_stream] = _SIDE_SEQ.get(side.cuda_stream, 0) + 1
+            low3 = self._low_path(x)
+            if _JOINED_SEQ.get(jkey, 0) < seq:
+                ops.stream_wait(main, side)             # join before the merge
+                _JOINED_SEQ[jkey] = _SIDE_SEQ[side.cuda_stream]
+            joined = True
+            out = self.up2(low3, up1)
+            held.append(up1.t)
+            return out
+        finally:
+            if not joined:                              # a launch failed between fork and join: x must outlive the branch kernels
+                ops.stream_wait(main, side)
+                _JOINED_SEQ[jkey] = _SIDE_SEQ.get(side.cuda_stream, 0)
 
     def _low_path(self, x):
         if isinstance(self.low2, _FireSeq):             # innermost level: low1, low2, low3 are one list of fire modules
@@ -490,15 +493,25 @@ class hg_module(nn.Module):
         with the shared three; GPU_MAX_HW_QUEUES above its default of 4 costs 30 %, below it 1-5 %)."""
         # keyed by the MAIN stream as well: a pass that runs (or is being captured) on another stream - another host thread, a
         # second pipeline's hipGraph capture - gets its own side streams instead of recording into a foreign capture
-        group = ops.SIDE_STREAM_OF_LEVEL[4 - self.n] if 1 <= self.n <= 4 else 0
+        group = _SIDE_STREAM_OF_LEVEL[4 - self.n] if 1 <= self.n <= 4 else 0
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, group)
         st = _SIDE_STREAMS.get(key)
         if st is None:
+            if len(_SIDE_STREAMS) >= _SIDE_STREAMS_MAX:          # main streams come and go (host threads, captures): oldest entries first
+                for old in list(_SIDE_STREAMS)[:len(_SIDE_STREAMS) - _SIDE_STREAMS_MAX + 1]:
+                    gone = _SIDE_STREAMS.pop(old)
+                    gone.synchronize()
+                    _HELD_BRANCH_OUTPUTS.pop(gone.cuda_stream, None)
+                    _SIDE_SEQ.pop(gone.cuda_stream, None)
+                    for jk in [k for k in _JOINED_SEQ if k[1] == gone.cuda_stream]:
+                        del _JOINED_SEQ[jk]
             st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
         return st
 
 
 _SIDE_STREAMS = {}
+_SIDE_STREAMS_MAX = 48           # (main stream, level group) entries kept: 16 main streams' worth
+_SIDE_STREAM_OF_LEVEL = (0, 1, 2, 2)   # side stream of the 64x64, 32x32, 16x16, 8x8 level (every other assignment swept: within noise, DESIGN App. A)
 _SIDE_SEQ, _JOINED_SEQ = {}, {}  # branches enqueued per side stream; (main, side) -> newest branch a join has covered
 _HELD_BRANCH_OUTPUTS = {}        # side stream handle -> branch outputs the main stream may still be reading (hg_module.forward)
 

@@ -184,6 +184,19 @@ class KeypointNet(_HipModule):
         h1, d1, c1, h2, d2, c2 = [torch.cat(t) if len(outs) > 1 else t[0] for t in zip(*outs)]
         return (h1, h2), (d1, d2), (c1, c2)
 
+    def configuration(self):
+        """Name of the compute configuration: 'float32mix', 'float32x3', 'float32', 'bfloat16' or 'float16'."""
+        if self.mixed:
+            return ops.F32MIX
+        if self.mfma_split:
+            return ops.F32X3
+        return str(self.compute_dtype).replace("torch.", "")
+
+    def set_compute_dtype(self, compute_dtype):
+        """Switch the configuration of the SAME weights (plans are cached per configuration; nothing is rebuilt that exists)."""
+        self.compute_dtype, self.mfma_split, self.mixed = ops.parse_compute_dtype(compute_dtype)
+        return self
+
     def precision_audit(self, x, against=ops.F32X3):
         """Run the deployed outputs of frames `x` in this network's compute precision AND in `against` (default: the split-product
         configuration, fp32-grade: 2e-6 on the test networks) on the same weights, both on the HIP path, and return the absolute

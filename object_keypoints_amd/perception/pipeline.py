@@ -114,14 +114,42 @@ def strip_module_prefixes(sd):
     return clean
 
 
-def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
+HEAT_BAR = 1e-3          # north_star: heat maps within 1e-3 of the fp32 reference
+
+
+def _audited(net, audit_frames, heat_bar):
+    """float32mix is a plan derived on ONE weight family: its single-term fp16 branches are cheap because BatchNorm
+    gains attenuate them there.  With `audit_frames` the loaded network is priced on the device against float32x3 (fp32-grade, 2e-6)
+    on the caller's frames (KeypointNet.precision_audit: two passes, no CPU reference) and, where the heat maps are further than
+    `heat_bar` apart - or not finite: fp16 operands overflow above 65504 - the network falls back to float32x3 with a warning."""
+    if audit_frames is None:
+        return net
+    if not (net.mixed or net.compute_dtype in ops.HALF_DTYPES):
+        net.audit = {"configuration": net.configuration(), "checked": False, "reason": "fp32-grade configuration: nothing to audit"}
+        return net
+    frames = audit_frames.to(next(net.parameters()).device, torch.float32)
+    report = net.precision_audit(frames)
+    ok = report["heat"]["finite"] and report["heat"]["max"] <= heat_bar
+    net.audit = {"configuration": net.configuration(), "checked": True, "frames": int(frames.shape[0]), "heat_bar": heat_bar, "report": report,
+                 "fell_back": not ok}
+    if not ok:
+        import warnings
+        warnings.warn(f"{net.configuration()}: heat maps differ from float32x3 by {report['heat']['max']:.2e} on the audit frames "
+                      f"(bar {heat_bar:.0e}, finite: {report['heat']['finite']}); falling back to float32x3", RuntimeWarning, stacklevel=3)
+        net.set_compute_dtype(ops.F32X3)
+    return net
+
+
+def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_frames=None, heat_bar=HEAT_BAR):
     """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
     TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet.
     Entries of the file that are not KeypointNet parameters (loss buffers, metrics of the Lightning module) are ignored;
-    a missing network tensor is an error."""
+    a missing network tensor is an error.
+    audit_frames (opt-in; [n,3,H,W] float32, a handful of representative frames): price a mixed / 16-bit `compute_dtype` on these
+    weights and fall back to float32x3 when it misses `heat_bar` (see _audited; the result is in `net.audit`)."""
     device = device or _device()
     if isinstance(model, models.KeypointNet):
-        return model.to(device).eval()
+        return _audited(model.to(device).eval(), audit_frames, heat_bar)
     if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
         clean = read_checkpoint_state_dict(model)
     elif isinstance(model, dict):
@@ -139,7 +167,7 @@ def load_keypoint_net(model, compute_dtype=torch.float32, device=None):
     if missing:
         raise OkpError(f"model file lacks {len(missing)} KeypointNet tensors, e.g. '{missing[0]}'")
     net.load_state_dict({k: clean[k] for k in own})
-    return net.to(device).eval()
+    return _audited(net.to(device).eval(), audit_frames, heat_bar)
 
 
 def load_cornernet_backbone(net, pretrained):

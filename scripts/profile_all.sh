@@ -1,6 +1,10 @@
 #!/bin/bash
-# usage: profile_r03.sh <tag> [dtype]   (on the GPU box)  ->  gpurun_out/<tag>/   (dtype: bf16 (default) | f16 | f32 | f32x3 | f32mix)
-# The rocprofv3 evidence behind one precision's `roofline` object of bench.py, from the SAME command with --dtype <dtype>:
+# usage: profile_all.sh <tag> <commit> [dtype ...]   (on the GPU box)  ->  gpurun_out/<tag>/
+#        dtypes: bf16 f16 f32 f32x3 f32mix (default: all five); <commit> = `git rev-parse --short HEAD` of the tree that was pushed
+#        (the box has no .git): it is stamped, with a hash of the kernel sources, into <file>.meta.json next to every counter file,
+#        and bench.py reports it as roofline.counter_commit / roofline.stale.
+# e.g.   gpurun --timeout 3000 -- "bash scripts/profile_all.sh r04a $(git rev-parse --short HEAD)"
+# The rocprofv3 evidence behind each precision's `roofline` object of bench.py, from the SAME command with --dtype <dtype>:
 #   <p>kernel_stats.csv, <p>last_forward.txt, <p>bench_profiled.json   rocprofv3 --kernel-trace --stats
 #   <p>pmc_hbm_traffic.json        two separate --pmc passes (FETCH_SIZE / WRITE_SIZE)
 #   <p>sq_counters.json            two separate --pmc passes of SQ counters, per kernel: mfma_busy_frac, lds_wait_frac,
@@ -8,7 +12,10 @@
 # with <p> = "" for bf16 and "<dtype>_" otherwise (bench.py's committed_counters() looks for profiles/r*_<p>....json).
 # Every rocprofv3 command has the program directly behind `--` and uses --pmc without any trace option.
 tag=$1
-dt=${2:-bf16}
+commit=$2
+shift 2
+dtypes="$@"; [ -z "$dtypes" ] && dtypes="bf16 f16 f32 f32x3 f32mix"
+for dt in $dtypes; do
 p=""; [ "$dt" != "bf16" ] && p="${dt}_"
 steps=10; [ "$dt" = "f32" ] && steps=4
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
@@ -33,5 +40,9 @@ cd $GRAFT_REPO_ROOT
 python3 scripts/pmc_traffic.py $out/fetch $out/write > $out/${p}pmc_hbm_traffic.json
 python3 scripts/pmc_sq_bench.py $out/sqa $out/sqb $out/${p}pmc_hbm_traffic.json $out/${p}kernel_stats.csv > $out/${p}sq_counters.json
 rm -rf $out/fetch $out/write $out/sqa $out/sqb
+for f in pmc_hbm_traffic sq_counters; do
+  python3 -c "import json,sys,time; sys.path.insert(0,'.'); import bench; json.dump({'commit': '$commit', 'csrc_sha16': bench.csrc_sha16(), 'dtype': '$dt', 'collected_unix': int(time.time()), 'command': 'bench.py --dtype $dt --no-cpu-baseline --no-stream8 --extra-dtypes='}, open('$out/${p}$f.meta.json','w'))"
+done
 tail -12 $out/${p}last_forward.txt
 head -24 $out/${p}sq_counters.json
+done

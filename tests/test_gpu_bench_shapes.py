@@ -439,7 +439,7 @@ def test_stereo_stream_pipeline_tick_recovers_the_rendered_points():
 def test_stream_wait_stream_orders_work_across_streams():
     """okp_stream_wait_stream (the fork / join of the hourglass branches; events without a system-scope fence): a consumer stream sees
     what the producer stream wrote before the edge, 600 edges in a row (the ring of 256 events is reused), in both directions; with
-    OKP_LIGHT_EVENTS=0 semantics (torch's wait_stream) as the reference behaviour."""
+    ops.LIGHT_EVENTS = False semantics (torch's wait_stream) as the reference behaviour."""
     from object_keypoints_amd import ops
     dev = torch.device("cuda", 0)
     a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)

@@ -98,10 +98,19 @@ def test_learned_pipeline_from_a_model_file(kind, oracle_case, tmp_path):
         assert len(o["p_centers"]) == len(w["p_centers"])
 
 
-@pytest.mark.parametrize("mode,kp_tol,pc_tol", [("float32x3", 1e-3, 1e-4), ("float32mix", 2e-2, 5e-3)])
+def _mix_bounds():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision"))
+    from bounds import BOUNDS
+    return BOUNDS["f32mix"]["keypoint_max_px"], BOUNDS["f32mix"]["p_C_max_m"]
+
+
+@pytest.mark.parametrize("mode,kp_tol,pc_tol", [("float32x3", 1e-3, 1e-4), ("float32mix",) + _mix_bounds()])
 def test_learned_pipeline_in_the_split_product_configurations(mode, kp_tol, pc_tol, oracle_case, tmp_path):
     """The reference's production sequence with compute_dtype="float32x3" (the fp32 configuration's bars: heat 1e-3, key points
-    1e-3 px, 3D points 1e-4 m) and "float32mix" (heat 1e-3; centroids and depth follow the 4e-4 heat / 2e-3 depth error)."""
+    1e-3 px, 3D points 1e-4 m) and "float32mix", which meets the HEAT bar only: centroids within 2e-2 px and 3D points within 5e-3 m
+    (tests/precision/bounds.py: 50x the 1e-4 m bar - they follow the 4e-4 heat / 4e-3 depth error)."""
     from object_keypoints_amd.perception import pipeline as pp
     from object_keypoints_amd.perception.utils import camera_utils as cu
     c = oracle_case
