@@ -435,3 +435,44 @@ def test_mixed_network_holds_the_heat_bar_on_many_frames():
         worst = (mix.deployed(x)[0] - x3.deployed(x)[0]).abs().flatten(1).max(dim=1).values.cpu().numpy()
     print("per-frame max heat error:", " ".join(f"{v:.1e}" for v in worst))
     assert worst.max() <= _bounds()["f32mix"]["heat_max_any_frame"] and np.median(worst) <= 6e-4 and worst.min() >= 1e-4
+
+
+def test_audit_frames_falls_back_to_float32x3_on_unit_gain_weights():
+    """load_keypoint_net(..., compute_dtype="float32mix", audit_frames=...): the mixed plan was derived on weights whose branches close
+    with BatchNorm gains of 0.3; on the `torch-default` family of tests/precision/families.py (gamma 1 / beta 0, calibrated running
+    statistics - the rounding-point model predicts 3.6e-3) the on-device audit finds the heat maps further than 1e-3 from float32x3,
+    warns, and the returned network runs float32x3 - and IS inside the bar against the CPU reference of the same weights.  On the
+    derived-on weights the same call audits, stays float32mix and says so."""
+    import os
+    import sys
+    import warnings
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import pipeline as pp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision"))
+    import families
+    onet, _ = families.build_family("torch-default")
+    sd = {k: v.clone() for k, v in onet.state_dict().items()}
+    frames = torch.from_numpy(synth.frames(2, seed=1))
+    with pytest.warns(RuntimeWarning, match="falling back to float32x3"):
+        net = pp.load_keypoint_net(sd, compute_dtype=ops.F32MIX, audit_frames=frames)
+    assert net.configuration() == ops.F32X3 and net.mfma_split and not net.mixed
+    a = net.audit
+    assert a["checked"] and a["fell_back"] and a["configuration"] == ops.F32MIX and a["report"]["heat"]["finite"]
+    assert 1.5e-3 <= a["report"]["heat"]["max"] <= 8e-3                    # the model says 3.6e-3 on these frames
+    with torch.no_grad():
+        heat = net.deployed(frames.cuda())[0].cpu()
+        from oracle import net as oracle_net
+        want = oracle_net.deployed_forward(onet, frames)[0]
+    assert float((heat - want).abs().max()) <= 1e-4                        # float32x3 against the fp32 CPU reference: fp32-grade
+    # the same call on the weights the plan was derived on: audited, kept
+    case = cases.NET_CASES["valve_k3"]
+    vals = synth.fill_state_dict({k: tuple(v.shape) for k, v in onet.state_dict().items()}, seed=case["weight_seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        kept = pp.load_keypoint_net({k: torch.from_numpy(np.array(v)) for k, v in vals.items()}, compute_dtype=ops.F32MIX, audit_frames=frames)
+    assert kept.configuration() == ops.F32MIX and kept.audit["checked"] and not kept.audit["fell_back"]
+    assert kept.audit["report"]["heat"]["max"] <= _bounds()["f32mix"]["heat_max_any_frame"]
+    # a 16-bit configuration trips it as well; an fp32-grade one is not audited at all
+    with pytest.warns(RuntimeWarning):
+        assert pp.load_keypoint_net(sd, compute_dtype=torch.bfloat16, audit_frames=frames).configuration() == ops.F32X3
+    assert pp.load_keypoint_net(sd, compute_dtype=ops.F32X3, audit_frames=frames).audit["checked"] is False

@@ -93,3 +93,32 @@ def test_plan_tool_selects_the_shipped_mixed_plan_for_the_test_network():
     by = {(r["fp16_levels"], r["branch_single_term"]): r for r in rows}
     assert by[(3, True)]["heat_max"] > 7e-4 and by[(4, True)]["heat_max"] > 1e-3          # where the margin goes
     assert by[(2, False)]["heat_max"] < by[(2, True)]["heat_max"] < 5.5e-4
+
+
+def test_float32mix_on_weight_families_it_was_not_derived_on():
+    """tests/precision/families.py -> tests/golden/precision_families.json: the shipped float32mix plan priced with the rounding-point
+    model on five weight families.  What the table establishes, asserted here (and one family recomputed, so the file cannot go stale):
+      * on the family the plan was derived on (BatchNorm gains of 0.3 closing every branch; two seeds, and with logits twice as large)
+        it stays inside the 1e-3 heat bar, worst 8.1e-4: the bound for this family is 9e-4 (tests/precision/bounds.py);
+      * on families whose branches enter the stream with gain 1 (torch's default BatchNorm initialisation, or the synthetic gamma range
+        without the 0.3, running statistics calibrated so that activations stay O(10)) it MISSES the bar by 3-3.6x: the single-term
+        fp16 branches are only cheap where a small BatchNorm gain attenuates them.  float32x3 holds everywhere (<= 1e-5).
+    Hence load_keypoint_net(..., compute_dtype="float32mix", audit_frames=...) - an on-device audit with a fall-back to float32x3
+    (tests/test_gpu_f32x3.py::test_audit_frames_falls_back_to_float32x3_on_unit_gain_weights)."""
+    import json
+    import families
+    with open(os.path.join(gu.GOLDEN, "precision_families.json")) as f:
+        table = json.load(f)["families"]
+    assert set(table) == set(families.FAMILIES)
+    for name in ("derived-on", "other-seed", "head-gain-x2"):
+        r = table[name]
+        assert r["float32mix"]["heat_max"] <= BOUNDS["f32mix"]["heat_max_any_frame"] and r["float32mix"]["meets_heat_1e-3"], name
+        assert r["float16"]["heat_max"] > 1e-3
+    for name in ("torch-default", "branch-gain-1"):
+        r = table[name]
+        assert 2e-3 <= r["float32mix"]["heat_max"] <= 6e-3 and not r["float32mix"]["meets_heat_1e-3"], name
+        assert r["activation_abs_max"] < 100.0                       # a sane network: nothing near the fp16 range limit
+    for name, r in table.items():
+        assert r["float32x3"]["heat_max"] <= 2e-5 and r["float32x3"]["finite"] and r["float32mix"]["finite"], name
+    again = families.price("torch-default", n_frames=table["torch-default"]["frames"])
+    assert abs(again["float32mix"]["heat_max"] / table["torch-default"]["float32mix"]["heat_max"] - 1.0) <= 0.02
