@@ -395,7 +395,8 @@ def run_precision(name, ctx, steps, warmup):
             cnt, yx, xyc = ops.peak_nms(h, cap=SAMPLE_CAP)
             pts = ops.lift_peaks(pipe.cam, cnt, xyc, d, int(pipe.max_index[0]), int(pipe.max_index[1]))
             sample = {k: v.cpu().numpy() for k, v in (("heat", h), ("depth", d), ("count", cnt), ("yx", yx), ("points", pts))}
-        coll = collective_probe(out["points"], batch, world, dev)
+        coll = collective_probe(out["points"], batch, world, dev, own_group=ctx.get("probe_collective", False) and world == 1)
+        ctx["probe_collective"] = False        # (once per run: the headline precision)
     value = batch * world * steps / elapsed
     n_launch, k_ms, k_flops, _ = timer.summary("mfma")
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -511,30 +512,50 @@ def run_stream8(ctx, ticks=200, warmup=10):
 SAMPLE_CAP = 1024      # peak slots per map of the error sample (random-weight networks give flat maps: ~100 peaks each)
 
 
-def collective_probe(points, batch, world, dev, reps=8):
+def collective_probe(points, batch, world, dev, reps=8, own_group=False):
     """The one data-path collective (all_gather_keypoints), bracketed by HIP events on a few calls AFTER the timed region: which
-    backend and how many ranks it saw, the payload per rank and its median duration.  Without a process group (plain
-    `python bench.py`) there is no collective and the object says so."""
+    backend and how many ranks it saw, the payload per rank and its median duration.  A plain `python bench.py --gpus 1` has no
+    process group - all_gather_keypoints passes the tensor through in the timed steps - so with own_group the probe creates a
+    one-rank RCCL group for itself (tcp://127.0.0.1, no torchrun), measures the real collective on it and destroys it again: the
+    N = 1 record then shows the communicator set-up and the all-gather working on this box."""
     import torch
     import torch.distributed as dist
     from object_keypoints_amd import distributed as dist_
     payload = int(points.numel() * points.element_size())
+    made = False
+    note = None
     if not dist.is_initialized():
-        return {"backend": None, "world": 1, "payload_bytes_per_rank": payload, "allgather_us_median": None,
-                "note": "no process group (not started by torchrun): all_gather_keypoints passes the tensor through"}
-    us = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist_.barrier()
-        e0.record()
-        g = dist_.all_gather_keypoints(points, total_frames=batch * world)
-        e1.record()
-        torch.cuda.synchronize()
-        us.append(e0.elapsed_time(e1) * 1e3)
-    assert g.shape[0] == batch * world
-    us.sort()
-    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "payload_bytes_per_rank": payload,
-            "gathered_bytes": int(g.numel() * g.element_size()), "allgather_us_median": us[len(us) // 2], "allgather_us_min": us[0], "calls": reps}
+        if not own_group:
+            return {"backend": None, "world": 1, "payload_bytes_per_rank": payload, "allgather_us_median": None,
+                    "note": "no process group (not started by torchrun): all_gather_keypoints passes the tensor through"}
+        try:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+            made = True
+            note = "one-rank RCCL group created by the probe (the timed steps ran without a process group)"
+        except Exception as e:       # no RCCL on this box: say so, the benchmark itself is unaffected
+            return {"backend": None, "world": 1, "payload_bytes_per_rank": payload, "allgather_us_median": None,
+                    "note": f"no process group, and a one-rank RCCL group could not be created: {type(e).__name__}: {str(e)[:120]}"}
+    try:
+        us = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist_.barrier()
+            e0.record()
+            g = dist_.all_gather_keypoints(points, total_frames=batch * world)
+            e1.record()
+            torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3)
+        assert g.shape[0] == batch * world and (made is False or torch.equal(torch.nan_to_num(g), torch.nan_to_num(points)))
+        us.sort()
+        res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "payload_bytes_per_rank": payload,
+               "gathered_bytes": int(g.numel() * g.element_size()), "allgather_us_median": us[len(us) // 2], "allgather_us_min": us[0], "calls": reps}
+        if note:
+            res["note"] = note
+        return res
+    finally:
+        if made:
+            dist.destroy_process_group()
 
 
 def parity_fields(sample, oracle, camera_file):
@@ -609,7 +630,7 @@ def rank_main(args):
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + start)
     frames = torch.randn((args.batch, 3, 511, 511), generator=gen, device=dev, dtype=torch.float32)
     with_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    ctx = {"dev": dev, "world": world, "batch": args.batch, "camera": camera, "frames": frames,
+    ctx = {"dev": dev, "world": world, "batch": args.batch, "camera": camera, "frames": frames, "probe_collective": True,
            "bumps": bump_maps(start, args.batch, dev),
            "err_frames": torch.from_numpy(synth.frames(ERR_FRAMES, seed=1)).to(dev) if with_cpu else None}
 
