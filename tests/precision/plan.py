@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE (CPU): which float32mix plan do given weights allow?
 
 The mixed configuration trades precision for speed in two places whose cost depends on the weights: single-term products inside the trunk's
-residual branches (OKP_MIX_BRANCH_SINGLE) and fp16 inner hourglass levels (OKP_MIX_FP16_LEVELS).  This tool runs the rounding-point model
+residual branches (ops.MIX_BRANCH_SINGLE) and fp16 inner hourglass levels (OKP_MIX_FP16_LEVELS).  This tool runs the rounding-point model
 (emulate.py) of every combination on a few frames and prints the predicted heat / depth error next to the speed each plan measured on
 MI355X, then names the fastest plan inside the bound.
 
@@ -56,7 +56,7 @@ def main():
     x = torch.from_numpy(synth.frames(a.frames, seed=1))
     rows, best = choose(emu, x, a.bound)
     for r in rows:
-        print(f"OKP_MIX_FP16_LEVELS={r['fp16_levels']} OKP_MIX_BRANCH_SINGLE={int(r['branch_single_term'])}: {r['frames_per_s']:5d} frames/s, "
+        print(f"fp16 levels {r['fp16_levels']} (OKP_MIX_FP16_LEVELS), single-term branches {int(r['branch_single_term'])} (ops.MIX_BRANCH_SINGLE): {r['frames_per_s']:5d} frames/s, "
               f"heat max {r['heat_max']:.2e}, depth max {r['depth_max']:.2e} {'<= bound' if r['ok'] else ''}")
     print("fastest plan inside the bound:", best and {k: best[k] for k in ("fp16_levels", "branch_single_term")})
 
