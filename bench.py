@@ -530,10 +530,13 @@ def collective_probe(points, batch, world, dev, reps=8, own_group=False):
                     "note": "no process group (not started by torchrun): all_gather_keypoints passes the tensor through"}
         try:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            fd_guard = _StdoutToStderr()          # RCCL prints its version banner to C stdout: the line this process prints must stay alone there
+            fd_guard.__enter__()
             dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
             made = True
             note = "one-rank RCCL group created by the probe (the timed steps ran without a process group)"
         except Exception as e:       # no RCCL on this box: say so, the benchmark itself is unaffected
+            fd_guard.__exit__(None, None, None)
             return {"backend": None, "world": 1, "payload_bytes_per_rank": payload, "allgather_us_median": None,
                     "note": f"no process group, and a one-rank RCCL group could not be created: {type(e).__name__}: {str(e)[:120]}"}
     try:
@@ -556,6 +559,26 @@ def collective_probe(points, batch, world, dev, reps=8, own_group=False):
     finally:
         if made:
             dist.destroy_process_group()
+            fd_guard.__exit__(None, None, None)
+
+
+class _StdoutToStderr:
+    """File descriptor 1 -> 2 for the duration (C-level prints of a library included: the C stdio buffers are flushed before fd 1 comes back)."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self.libc = ctypes.CDLL(None)
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def parity_fields(sample, oracle, camera_file):
