@@ -52,39 +52,34 @@ class _OpaqueGlobal:
         pass
 
 
-def _tolerant_pickle_module():
-    """A pickle module for torch.load whose Unpickler resolves the globals torch's own weights-only unpickler allows (tensor
-    and storage rebuilders, OrderedDict, torch.Size, dtypes ...) and replaces EVERY other global by an inert stub class.
-    Needed for the reference's training checkpoints: pytorch-lightning 1.2.1 (requirements.txt) keys the `callbacks` dict of
-    a checkpoint by the callback CLASS (ModelCheckpoint, scripts/train.py:170) and stores hyper-parameter objects - globals
-    that `weights_only=True` rejects outright and that an unrestricted load would import and execute."""
-    import pickle
-    import types
-    from torch import _weights_only_unpickler as wo
-    allowed = dict(wo._get_allowed_globals())
-    stubs = {}
+MAX_OPAQUE_GLOBALS = 256        # a training checkpoint names a handful of foreign classes; a file that names more is not one
 
-    class Unpickler(pickle.Unpickler):
-        def find_class(self, module, name):
-            key = f"{module}.{name}"
-            if key in allowed:
-                return allowed[key]
-            if key not in stubs:
-                stubs[key] = type(name, (_OpaqueGlobal,), {"__module__": "okp_opaque." + module})
-            return stubs[key]
 
-    mod = types.ModuleType("okp_tolerant_pickle")
-    mod.Unpickler = Unpickler
-    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
-    mod.__dict__.update({k: getattr(pickle, k) for k in ("UnpicklingError", "PickleError", "HIGHEST_PROTOCOL", "dumps", "loads", "dump", "Pickler")})
-    return mod
+def _load_with_opaque_globals(path):
+    """torch.load(weights_only=True) - torch's own restricted unpickling VM, with its limits on what REDUCE / BUILD / NEWOBJ may touch -
+    for a checkpoint that names globals the VM does not allow: each such global (torch.serialization.get_unsafe_globals_in_checkpoint
+    lists them without unpickling anything) is registered as a SAFE global under its pickled name, bound to an inert stub class
+    (_OpaqueGlobal: constructible, callable, stateless), for the duration of this one load.  Nothing the pickle names is imported or
+    run; what a stub 'constructs' is another stub.  Needed for the reference's training checkpoints: pytorch-lightning 1.2.1
+    (requirements.txt) keys the `callbacks` dict of a checkpoint by the callback CLASS (ModelCheckpoint, scripts/train.py:170) and
+    stores hyper-parameter objects.  Residual trust: torch's VM itself and the tensor / storage rebuilders on its default allow-list
+    (tests/test_host_logic.py pins that the allow-list names nothing outside torch, collections and builtins' containers)."""
+    names = list(torch.serialization.get_unsafe_globals_in_checkpoint(path))
+    if len(names) > MAX_OPAQUE_GLOBALS:
+        raise OkpError(f"{path}: names {len(names)} globals outside torch's weights-only allow-list; not a training checkpoint")
+    stubs = []
+    for full in names:
+        module, _, name = full.rpartition(".")
+        stubs.append((type(name or "opaque", (_OpaqueGlobal,), {"__module__": "okp_opaque." + module}), full))
+    with torch.serialization.safe_globals(stubs):
+        return torch.load(path, map_location="cpu", weights_only=True)
 
 
 def read_checkpoint_state_dict(path):
     """Tensors of a model file: TorchScript archive (scripts/package_model.py:40-42), torch.save'd state_dict, or a
-    (pytorch-lightning) training checkpoint {"state_dict": ..., "callbacks": ..., ...}.  Never executes pickled code: the
-    weights-only loader first; a checkpoint that carries other globals is re-read with those replaced by inert stubs
-    (_tolerant_pickle_module) and only its tensors are kept.  Returns {name: tensor} with the module prefixes stripped."""
+    (pytorch-lightning) training checkpoint {"state_dict": ..., "callbacks": ..., ...}.  Never executes pickled code and never leaves
+    torch's weights-only unpickler: a checkpoint that carries other globals is re-read with those bound to inert stubs
+    (_load_with_opaque_globals) and only its tensors are kept.  Returns {name: tensor} with the module prefixes stripped."""
     import pickle
     if _is_torchscript_archive(path):
         sd = torch.jit.load(path, map_location="cpu").state_dict()
@@ -93,7 +88,7 @@ def read_checkpoint_state_dict(path):
             sd = torch.load(path, map_location="cpu", weights_only=True)
         except pickle.UnpicklingError:
             try:
-                sd = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle_module())
+                sd = _load_with_opaque_globals(path)
             except Exception as e:
                 raise OkpError(f"{path}: not a state_dict, Lightning checkpoint or TorchScript archive this loader can read ({e})") from e
         if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):

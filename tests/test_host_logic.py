@@ -406,6 +406,13 @@ def test_reads_a_pytorch_lightning_1_2_1_shaped_checkpoint_without_running_its_p
         torch.load(path, map_location="cpu", weights_only=True)          # what the plain safe loader does with this file
     sd = pp.read_checkpoint_state_dict(path)
     assert set(sd) == {"heatmap_head.output_head2.2.weight", "backbone.pre.0.conv.weight", "loss.weights"}
+    # the load stays inside torch's weights-only VM: the foreign globals were safe globals (inert stubs) for that one call only ...
+    assert torch.serialization.get_safe_globals() == []
+    assert sorted(torch.serialization.get_unsafe_globals_in_checkpoint(path)) == sorted(f"{mod.__name__}.{n}" for n in ("ModelCheckpoint", "HParams", "boom"))
+    # ... and what the VM trusts by default is torch's own rebuilders plus a few containers (the residual trust of this loader, pinned)
+    from torch import _weights_only_unpickler as wo
+    foreign = sorted(k for k in wo._get_allowed_globals() if not k.startswith("torch."))
+    assert all(k.split(".")[0] in ("collections", "builtins", "_codecs") for k in foreign), foreign
     assert torch.equal(sd["heatmap_head.output_head2.2.weight"], tensors["model.heatmap_head.output_head2.2.weight"])
     # a plain state_dict and a {"state_dict": ...} dict go through the weights-only loader as before
     torch.save({"a.weight": torch.ones(2)}, str(tmp_path / "sd.pt"))
