@@ -407,7 +407,7 @@ def test_reads_a_pytorch_lightning_1_2_1_shaped_checkpoint_without_running_its_p
     sd = pp.read_checkpoint_state_dict(path)
     assert set(sd) == {"heatmap_head.output_head2.2.weight", "backbone.pre.0.conv.weight", "loss.weights"}
     # the load stays inside torch's weights-only VM: the foreign globals were safe globals (inert stubs) for that one call only ...
-    assert torch.serialization.get_safe_globals() == []
+    assert not any("okp_opaque" in getattr(g[0] if isinstance(g, tuple) else g, "__module__", "") for g in torch.serialization.get_safe_globals())
     assert sorted(torch.serialization.get_unsafe_globals_in_checkpoint(path)) == sorted(f"{mod.__name__}.{n}" for n in ("ModelCheckpoint", "HParams", "boom"))
     # ... and what the VM trusts by default is torch's own rebuilders plus a few containers (the residual trust of this loader, pinned)
     from torch import _weights_only_unpickler as wo
