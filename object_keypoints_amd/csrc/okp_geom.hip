@@ -210,6 +210,41 @@ __global__ __launch_bounds__(64) void okp_group_objects_kernel(const GroupParams
   }
 }
 
+constexpr int OKP_TRI_OCTET_MAX = 256;
+
+struct TriParams {
+  okp_camera left, right;
+  double T[12];
+  double F[9];
+  int correct;
+};
+
+// ---- Hartley-Sturm correction (cv2.correctMatches) -------------------------------------------
+__device__ void mat3_mul(const double (&A)[3][3], const double (&B)[3][3], double (&C)[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i][k] * B[k][j]; C[i][j] = s; }
+}
+
+// Right null vector of a 3x3 matrix (rank 2): the largest cross product of two rows.
+__device__ void null3(const double (&M)[3][3], double (&e)[3]) {
+  double best = -1;
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    const double c0 = M[a][1] * M[b][2] - M[a][2] * M[b][1];
+    const double c1 = M[a][2] * M[b][0] - M[a][0] * M[b][2];
+    const double c2 = M[a][0] * M[b][1] - M[a][1] * M[b][0];
+    const double n = c0 * c0 + c1 * c1 + c2 * c2;
+    if (n > best) { best = n; e[0] = c0; e[1] = c1; e[2] = c2; }
+  }
+}
+
+__device__ double hs_cost(double t, double a, double b, double c, double d, double f1, double f2) {
+  const double u = a * t + b, v = c * t + d;
+  return t * t / (1.0 + f1 * f1 * t * t) + v * v / (u * u + f2 * f2 * v * v);
+}
+
+// ---- one thread per pair: the form for MANY pairs (every lane busy; rounds 1-3).  okp_triangulate_dlt launches it above
+// OKP_TRI_OCTET_MAX pairs, the octet-cooperative wavefront kernel below for fewer (a camera rig's tens of points per tick: latency) ----
 // One-sided (Hestenes) Jacobi on the columns of a 4x4 matrix; returns the column of V that
 // belongs to the smallest singular value, i.e. argmin |A v| over unit v.
 __device__ void null_vector4(double (&A)[4][4], double (&v)[4]) {
@@ -244,37 +279,6 @@ __device__ void null_vector4(double (&A)[4][4], double (&v)[4]) {
     if (n < bestn) { bestn = n; best = j; }
   }
   for (int i = 0; i < 4; ++i) v[i] = V[i][best];
-}
-
-struct TriParams {
-  okp_camera left, right;
-  double T[12];
-  double F[9];
-  int correct;
-};
-
-// ---- Hartley-Sturm correction (cv2.correctMatches) -------------------------------------------
-__device__ void mat3_mul(const double (&A)[3][3], const double (&B)[3][3], double (&C)[3][3]) {
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i][k] * B[k][j]; C[i][j] = s; }
-}
-
-// Right null vector of a 3x3 matrix (rank 2): the largest cross product of two rows.
-__device__ void null3(const double (&M)[3][3], double (&e)[3]) {
-  double best = -1;
-  for (int a = 0; a < 3; ++a) {
-    const int b = (a + 1) % 3;
-    const double c0 = M[a][1] * M[b][2] - M[a][2] * M[b][1];
-    const double c1 = M[a][2] * M[b][0] - M[a][0] * M[b][2];
-    const double c2 = M[a][0] * M[b][1] - M[a][1] * M[b][0];
-    const double n = c0 * c0 + c1 * c1 + c2 * c2;
-    if (n > best) { best = n; e[0] = c0; e[1] = c1; e[2] = c2; }
-  }
-}
-
-__device__ double hs_cost(double t, double a, double b, double c, double d, double f1, double f2) {
-  const double u = a * t + b, v = c * t + d;
-  return t * t / (1.0 + f1 * f1 * t * t) + v * v / (u * u + f2 * f2 * v * v);
 }
 
 // Real roots of a degree-6 polynomial g[0] + g[1] t + ... + g[6] t^6 by Durand-Kerner in complex fp64.
@@ -393,7 +397,7 @@ __device__ void hartley_sturm(const double (&F)[9], double& x1, double& y1, doub
   x2 = q2v[0] / q2v[2] + x2; y2 = q2v[1] / q2v[2] + y2;
 }
 
-__global__ void okp_triangulate_kernel(TriParams tp, const float* __restrict__ lxy, const float* __restrict__ rxy, int m,
+__global__ void okp_triangulate_thread_kernel(TriParams tp, const float* __restrict__ lxy, const float* __restrict__ rxy, int m,
                                        double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -428,6 +432,248 @@ __global__ void okp_triangulate_kernel(TriParams tp, const float* __restrict__ l
   out[3 * i + 0] = v[0] / v[3];
   out[3 * i + 1] = v[1] / v[3];
   out[3 * i + 2] = v[2] / v[3];
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Triangulation as a WAVEFRONT kernel: eight lanes (an octet) cooperate on one keypoint pair, eight pairs per wave.  The three
+// serial pieces of the per-pair work are spread over the octet and reduced with width-8 shuffles:
+//   * undistortion: lane 0 the left point, lane 1 the right point;
+//   * the degree-6 polynomial of Hartley-Sturm: lane k owns root k of a Durand-Kerner iteration (all roots stepped together from
+//     the previous iterate; the other roots arrive by shuffle), the cost of the seven candidates (six roots + t = infinity) is
+//     evaluated one per lane and the minimum taken by an octet reduction with OpenCV's order of preference (infinity, then root order);
+//   * the 4x4 null vector of the DLT system: one-sided Jacobi with the two disjoint column rotations of a round in parallel -
+//     lanes (rotation r, row i) - dot products by group reductions, rotated columns exchanged between the groups.
+// What is uniform per pair (3x3 algebra, polynomial coefficients, back-transformation) is computed redundantly by the eight lanes.
+// One thread per pair (rounds 1-3) walked six roots x up to 500 iterations and six rotations x up to 30 sweeps in sequence.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double oct_bcast(double v, int src) { return __shfl(v, src, 8); }
+__device__ __forceinline__ double oct_max(double v) {
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 8));
+  return v;
+}
+__device__ __forceinline__ double quad_sum(double v) {       // over the four lanes of a rotation group (lane bits 0-1)
+  v += __shfl_xor(v, 1, 8);
+  v += __shfl_xor(v, 2, 8);
+  return v;
+}
+
+// Real parts of the roots of g[0] + ... + g[6] t^6: lane g (< degree) of the octet returns its root in `re`; returns the degree.
+__device__ int poly6_roots_oct(const double (&gc)[7], int g, double& re) {
+  int deg = 6;
+  double scale = 0;
+  for (int i = 0; i <= 6; ++i) scale = fmax(scale, fabs(gc[i]));
+  while (deg > 0 && fabs(gc[deg]) <= 1e-14 * scale) --deg;            // (uniform over the octet)
+  re = 0.0;
+  if (__all(deg == 0)) return deg;
+  double a[7];
+  const double lead = deg > 0 ? gc[deg] : 1.0;
+  for (int i = 0; i <= 6; ++i) a[i] = i <= deg ? gc[i] / lead : 0.0;
+  double radius = 0;
+  for (int i = 0; i < deg; ++i) radius = fmax(radius, fabs(a[i]));
+  radius = fmin(1.0 + radius, 1e6);
+  const bool mine = g < deg;
+  double im = 0.0;
+  if (mine) {
+    const double ang = 2.0 * 3.141592653589793 * g / deg + 0.4;
+    const double r = radius * (0.5 + 0.07 * g);
+    re = r * cos(ang); im = r * sin(ang);
+  }
+  bool done = deg == 0;
+  for (int it = 0; it < 500; ++it) {
+    double pr = 1.0, pi = 0.0;                                         // p(z) by Horner, monic, at this lane's root
+    for (int i = 5; i >= 0; --i)
+      if (i < deg) { const double nr = pr * re - pi * im + a[i]; pi = pr * im + pi * re; pr = nr; }
+    double qr = 1.0, qi = 0.0;                                         // prod over the other roots (z - z_j)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double rj = oct_bcast(re, j), ij = oct_bcast(im, j);
+      if (j < deg && j != g) {
+        const double dr = re - rj, di = im - ij;
+        const double nr = qr * dr - qi * di; qi = qr * di + qi * dr; qr = nr;
+      }
+    }
+    const double den = qr * qr + qi * qi + 1e-300;
+    const double sr = (pr * qr + pi * qi) / den, si = (pi * qr - pr * qi) / den;
+    if (mine && !done) { re -= sr; im -= si; }
+    const double change = oct_max(mine ? fabs(sr) + fabs(si) : 0.0);
+    done = done || change < 1e-14 * radius;
+    if (__all(done)) break;                                            // every octet of the wave has converged
+  }
+  return deg;
+}
+
+// cv2.correctMatches for one pair, by the octet (g = lane within it)
+__device__ void hartley_sturm_oct(const double (&F)[9], int g, double& x1, double& y1, double& x2, double& y2) {
+  // translate both points to the origin: F' = T2^-T F T1^-1 with T^-1 = [[1,0,x],[0,1,y],[0,0,1]]
+  double Fm[3][3], T1i[3][3] = {{1, 0, x1}, {0, 1, y1}, {0, 0, 1}}, T2it[3][3] = {{1, 0, 0}, {0, 1, 0}, {x2, y2, 1}};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fm[i][j] = F[3 * i + j];
+  double tmp[3][3], Fp[3][3];
+  mat3_mul(T2it, Fm, tmp);
+  mat3_mul(tmp, T1i, Fp);
+  double e1[3], e2[3], Ft[3][3];
+  null3(Fp, e1);                                  // F' e1 = 0
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ft[i][j] = Fp[j][i];
+  null3(Ft, e2);                                  // e2^T F' = 0
+  const double n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1]), n2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1]);
+  const bool degenerate = n1 < 1e-300 || n2 < 1e-300;           // (the shuffles below need every lane: no early return)
+  const double s1 = degenerate ? 1.0 : n1, s2 = degenerate ? 1.0 : n2;
+  for (int i = 0; i < 3; ++i) { e1[i] /= s1; e2[i] /= s2; }
+  double R1[3][3] = {{e1[0], e1[1], 0}, {-e1[1], e1[0], 0}, {0, 0, 1}};
+  double R2[3][3] = {{e2[0], e2[1], 0}, {-e2[1], e2[0], 0}, {0, 0, 1}};
+  double R1t[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R1t[i][j] = R1[j][i];
+  double Fpp[3][3];
+  mat3_mul(R2, Fp, tmp);
+  mat3_mul(tmp, R1t, Fpp);
+  const double f1 = e1[2], f2 = e2[2];
+  const double a = Fpp[1][1], b = Fpp[1][2], c = Fpp[2][1], d = Fpp[2][2];
+  // g(t) = t((at+b)^2 + f2^2 (ct+d)^2)^2 - (ad-bc)(1+f1^2 t^2)^2 (at+b)(ct+d)
+  double gp[7] = {0, 0, 0, 0, 0, 0, 0};
+  {
+    const double q2 = a * a + f2 * f2 * c * c, q1 = 2 * (a * b + f2 * f2 * c * d), q0 = b * b + f2 * f2 * d * d;
+    const double s4 = q2 * q2, s3 = 2 * q2 * q1, sq2 = 2 * q2 * q0 + q1 * q1, sq1 = 2 * q1 * q0, s0 = q0 * q0;
+    gp[5] += s4; gp[4] += s3; gp[3] += sq2; gp[2] += sq1; gp[1] += s0;       // t * q^2
+    const double k = a * d - b * c;
+    const double r0 = 1, r2 = 2 * f1 * f1, r4 = f1 * f1 * f1 * f1;
+    const double w2 = a * c, w1 = a * d + b * c, w0 = b * d;
+    gp[0] -= k * (r0 * w0);
+    gp[1] -= k * (r0 * w1);
+    gp[2] -= k * (r0 * w2 + r2 * w0);
+    gp[3] -= k * (r2 * w1);
+    gp[4] -= k * (r2 * w2 + r4 * w0);
+    gp[5] -= k * (r4 * w1);
+    gp[6] -= k * (r4 * w2);
+  }
+  double root;
+  const int nroots = poly6_roots_oct(gp, g, root);
+  // one candidate per lane: lanes 0..5 the real parts of the roots (OpenCV evaluates the cost there), lane 6 t = infinity:
+  // s = 1/f1^2 + c^2/(a^2 + f2^2 c^2).  Preference among equal costs as in the sequential scan: infinity first, then root order.
+  double cs = 1e300, ct = 0.0;
+  int key = 99;
+  if (g < nroots) { cs = hs_cost(root, a, b, c, d, f1, f2); ct = root; key = g + 1; }
+  else if (g == 6) {
+    const double den = a * a + f2 * f2 * c * c;
+    if (f1 != 0.0 && den != 0.0) { cs = 1.0 / (f1 * f1) + c * c / den; key = 0; }
+  }
+  if (!(cs < 1e300)) { cs = 1e300; ct = 0.0; key = 99; }         // (NaN / overflow: never preferred; all of them: t = 0 as the sequential default)
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) {
+    const double s2o = __shfl_xor(cs, off, 8), t2o = __shfl_xor(ct, off, 8);
+    const int k2o = __shfl_xor(key, off, 8);
+    if (s2o < cs || (s2o == cs && k2o < key)) { cs = s2o; ct = t2o; key = k2o; }
+  }
+  const bool inf_best = key == 0;
+  const double best_t = key == 99 ? 0.0 : ct;
+  // closest points on l1 = (t f1, 1, -t), l2 = (-f2 (ct+d), at+b, ct+d) to the origin
+  double p1[3], p2[3];
+  if (inf_best) {
+    p1[0] = f1; p1[1] = 0; p1[2] = f1 * f1;       // limit t -> inf of (t^2 f1, t, t^2 f1^2 + 1) / t^2
+    p2[0] = f2 * c * c; p2[1] = -a * c; p2[2] = f2 * f2 * c * c + a * a;
+  } else {
+    const double t = best_t, u = a * t + b, v = c * t + d;
+    p1[0] = t * t * f1; p1[1] = t; p1[2] = t * t * f1 * f1 + 1.0;
+    p2[0] = f2 * v * v; p2[1] = -u * v; p2[2] = f2 * f2 * v * v + u * u;
+  }
+  // back: x = T^-1 R^T p
+  double q1v[3], q2v[3];
+  for (int i = 0; i < 3; ++i) {
+    q1v[i] = R1[0][i] * p1[0] + R1[1][i] * p1[1] + R1[2][i] * p1[2];
+    q2v[i] = R2[0][i] * p2[0] + R2[1][i] * p2[1] + R2[2][i] * p2[2];
+  }
+  if (degenerate || fabs(q1v[2]) < 1e-300 || fabs(q2v[2]) < 1e-300) return;
+  x1 = q1v[0] / q1v[2] + x1; y1 = q1v[1] / q1v[2] + y1;
+  x2 = q2v[0] / q2v[2] + x2; y2 = q2v[1] / q2v[2] + y2;
+}
+
+// Null vector of a 4x4 matrix (argmin |A v| over unit v) by one-sided (Hestenes) Jacobi, by the octet: lane (r = g >> 2, i = g & 3)
+// holds row i of A and of V (a0..a3, v0..v3; both groups hold every row) and rotates the r-th column pair of the round.
+__device__ void null_vector4_oct(int g, double a0, double a1, double a2, double a3, double (&nv)[4]) {
+  const int r = g >> 2, i = g & 3;
+  double v0 = i == 0, v1 = i == 1, v2 = i == 2, v3 = i == 3;
+  auto get = [&](int col, double c0, double c1, double c2, double c3) { return col == 0 ? c0 : col == 1 ? c1 : col == 2 ? c2 : c3; };
+  bool done = false;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+      // round 0: (0,1) | (2,3);  round 1: (0,2) | (1,3);  round 2: (0,3) | (1,2)
+      const int p = r == 0 ? 0 : (round == 0 ? 2 : 1);
+      const int q = r == 0 ? round + 1 : (round == 2 ? 2 : 3);
+      const double ap = get(p, a0, a1, a2, a3), aq = get(q, a0, a1, a2, a3);
+      const double vp = get(p, v0, v1, v2, v3), vq = get(q, v0, v1, v2, v3);
+      const double alpha = quad_sum(ap * ap), beta = quad_sum(aq * aq), gamma = quad_sum(ap * aq);
+      double nap = ap, naq = aq, nvp = vp, nvq = vq;
+      if (gamma != 0.0 && !done) {
+        off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        nap = c * ap - s * aq; naq = s * ap + c * aq;
+        nvp = c * vp - s * vq; nvq = s * vp + c * vq;
+      }
+      // every lane takes its own group's two columns from itself and the other two from its partner in the other group (lane ^ 4)
+      const double oap = __shfl_xor(nap, 4, 8), oaq = __shfl_xor(naq, 4, 8), ovp = __shfl_xor(nvp, 4, 8), ovq = __shfl_xor(nvq, 4, 8);
+      const int op = r == 0 ? (round == 0 ? 2 : 1) : 0;                  // the partner's pair
+      const int oq = r == 0 ? (round == 2 ? 2 : 3) : round + 1;
+      auto put = [&](int col, double x, double& c0, double& c1, double& c2, double& c3) {
+        if (col == 0) c0 = x; else if (col == 1) c1 = x; else if (col == 2) c2 = x; else c3 = x;
+      };
+      put(p, nap, a0, a1, a2, a3); put(q, naq, a0, a1, a2, a3); put(op, oap, a0, a1, a2, a3); put(oq, oaq, a0, a1, a2, a3);
+      put(p, nvp, v0, v1, v2, v3); put(q, nvq, v0, v1, v2, v3); put(op, ovp, v0, v1, v2, v3); put(oq, ovq, v0, v1, v2, v3);
+    }
+    done = done || oct_max(off) < 1e-15;
+    if (__all(done)) break;
+  }
+  // the column of the smallest norm (the first one among equals)
+  const double n0 = quad_sum(a0 * a0), n1 = quad_sum(a1 * a1), n2 = quad_sum(a2 * a2), n3 = quad_sum(a3 * a3);
+  int best = 0;
+  double bestn = n0;
+  if (n1 < bestn) { bestn = n1; best = 1; }
+  if (n2 < bestn) { bestn = n2; best = 2; }
+  if (n3 < bestn) { bestn = n3; best = 3; }
+  const double mine = get(best, v0, v1, v2, v3);        // V[i][best] of this lane's row
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nv[k] = oct_bcast(mine, k);
+}
+
+__global__ __launch_bounds__(64) void okp_triangulate_kernel(TriParams tp, const float* __restrict__ lxy, const float* __restrict__ rxy, int m,
+                                                           double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane & 7;
+  const int pair = blockIdx.x * 8 + (lane >> 3);
+  const bool live = pair < m;
+  const int i = live ? pair : 0;                  // idle octets of the last wave work on pair 0 (the wave-wide votes need every lane) and store nothing
+  double ux = 0.0, uy = 0.0;
+  if (g == 0) camera_undistort(tp.left, (double)lxy[2 * i], (double)lxy[2 * i + 1], ux, uy);
+  else if (g == 1) camera_undistort(tp.right, (double)rxy[2 * i], (double)rxy[2 * i + 1], ux, uy);
+  // cv2 hands float32 back for float32 input (camera_utils.py:93-97)
+  double xl = (double)(float)oct_bcast(ux, 0), yl = (double)(float)oct_bcast(uy, 0);
+  double xr = (double)(float)oct_bcast(ux, 1), yr = (double)(float)oct_bcast(uy, 1);
+  if (tp.correct) {
+    double F[9];
+    for (int k = 0; k < 9; ++k) F[k] = tp.F[k];
+    hartley_sturm_oct(F, g, xl, yl, xr, yr);
+    xl = (double)(float)xl; yl = (double)(float)yl; xr = (double)(float)xr; yr = (double)(float)yr;
+  }
+  // P1 = K_l [I 0]; P2 = K_r T_RL[:3]; row i of the DLT system for this lane
+  const int row = g & 3;
+  double a[4];
+  for (int j = 0; j < 4; ++j) {
+    const double P1_0 = j == 0 ? tp.left.fx : j == 2 ? tp.left.cx : 0.0, P1_1 = j == 1 ? tp.left.fy : j == 2 ? tp.left.cy : 0.0, P1_2 = j == 2 ? 1.0 : 0.0;
+    const double P2_0 = tp.right.fx * tp.T[j] + tp.right.cx * tp.T[8 + j];
+    const double P2_1 = tp.right.fy * tp.T[4 + j] + tp.right.cy * tp.T[8 + j];
+    const double P2_2 = tp.T[8 + j];
+    a[j] = row == 0 ? xl * P1_2 - P1_0 : row == 1 ? yl * P1_2 - P1_1 : row == 2 ? xr * P2_2 - P2_0 : yr * P2_2 - P2_1;
+  }
+  double v[4];
+  null_vector4_oct(g, a[0], a[1], a[2], a[3], v);
+  if (live && g == 0) {
+    out[3 * pair + 0] = v[0] / v[3];
+    out[3 * pair + 1] = v[1] / v[3];
+    out[3 * pair + 2] = v[2] / v[3];
+  }
 }
 
 }  // namespace
@@ -517,6 +763,9 @@ extern "C" int okp_triangulate_dlt(const okp_camera* left, const okp_camera* rig
   for (int i = 0; i < 12; ++i) tp.T[i] = T_RL[i];
   for (int i = 0; i < 9; ++i) tp.F[i] = F ? F[i] : 0.0;
   tp.correct = correct_matches;
-  hipLaunchKernelGGL(okp_triangulate_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, tp, lxy, rxy, m, out);
+  // measured (scripts/probe_triangulate.py, launch + host): 4 / 20 pairs 23-24 us (octets) against 50 us (threads); 256 pairs 50 / 48 us;
+  // 4096 pairs 64 / 48 us - an octet keeps six of eight lanes busy in the root iteration, a thread all of one
+  if (m <= OKP_TRI_OCTET_MAX) hipLaunchKernelGGL(okp_triangulate_kernel, dim3((m + 7) / 8), dim3(64), 0, (hipStream_t)stream, tp, lxy, rxy, m, out);     // eight pairs per wave
+  else hipLaunchKernelGGL(okp_triangulate_thread_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, tp, lxy, rxy, m, out);
   return okp_check_hip(hipGetLastError(), "okp_triangulate_dlt launch");
 }

@@ -179,6 +179,28 @@ def test_triangulation_known_answer_and_oracle(known):
     assert np.abs(got2 - want2).max() < 1e-6
 
 
+@pytest.mark.parametrize("m", [1, 7, 8, 9, 61, 256, 257, 700])
+def test_triangulation_wavefront_and_thread_kernels_agree_with_the_oracle(m):
+    """okp_triangulate_dlt has two kernels: up to 256 pairs the wavefront form (eight lanes per pair: Durand-Kerner with one root per lane,
+    the seven Hartley-Sturm candidates reduced over the octet, the 4x4 Jacobi with both column rotations of a round in parallel), above
+    that one thread per pair.  Both against the oracle (cv2.correctMatches + cv2.triangulatePoints restated, camera_utils.py:92-110) on
+    noisy correspondences, on pair counts around the octet / wave / switch-over boundaries; with and without the correction."""
+    import os
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import geometry as og
+    calib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "calibration.yaml")
+    stereo, ostereo = cu.StereoCamera.from_file(calib), og.StereoCamera.from_file(calib)
+    rng = np.random.default_rng(100 + m)
+    X = np.stack([rng.uniform(-0.4, 0.4, m), rng.uniform(-0.25, 0.25, m), rng.uniform(0.5, 2.0, m)], axis=1)
+    pl = ostereo.left_camera.project(X) + rng.normal(0, 0.5, (m, 2))
+    pr = ostereo.right_camera.project(X, ostereo.T_RL) + rng.normal(0, 0.5, (m, 2))
+    got, want = stereo.triangulate(pl, pr), ostereo.triangulate(pl, pr)
+    assert got.shape == (m, 3) and np.isfinite(got).all()
+    assert np.abs(got - want).max() < 1e-6                                  # (measured 3e-14: both kernels find the same roots / null vector)
+    assert np.abs(stereo.triangulate(pl, pr, correct_matches=False) - ostereo.triangulate(pl, pr, correct=False)).max() < 1e-6
+    assert np.array_equal(stereo.triangulate(pl, pr), got)                  # run to run
+
+
 def test_stereo_triangulate_undistorts_with_the_fisheye_model_whatever_the_camera_class():
     """The reference's StereoCamera.triangulate calls cv2.fisheye.undistortPoints with the cameras' K / D unconditionally
     (camera_utils.py:92-97): a stereo pair of RadTanPinholeCamera objects therefore gives the same 3D points as FisheyeCamera
