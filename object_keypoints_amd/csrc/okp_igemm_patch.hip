@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "okp_igemm_kernel.h"
 
@@ -43,24 +44,53 @@ namespace {
 constexpr uint32_t kPatchKeys = 0x7ac788u;
 __device__ __forceinline__ uint32_t patch_key(int col) { return (kPatchKeys >> (3 * (col >> 1))) & 7u; }
 
-constexpr int kWStage = 256 * 128;                 // one K-step of weights: 256 rows x 128 B
 constexpr int kPitch = 18;                         // patch row pitch in pixels (16-wide patches leave two columns unused)
 constexpr int kPatchBuf = 41 * 1024;               // 18 x 18 px x 128 B, rounded up to whole 1 KiB LDS-DMA blocks
-constexpr int kLdsPatch = 2 * kWStage;
-constexpr int kLdsSteps = kLdsPatch + 2 * kPatchBuf;
-constexpr int kLdsBias = kLdsSteps + 256 * (int)sizeof(OkpPatchStep);
-constexpr int kLdsTotal = kLdsBias + 1024;
-static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
-static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
 
-template <typename T>
-__global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
+#ifdef OKP_PATCH_STAMPS
+// Debug build: shader-clock stamps of every K-step of a workgroup's first tile (before / after the DMA wait, after the barrier, after the
+// first MFMA group was issued), kept in LDS and dumped for the first 16 workgroups.  Perturbs the loop by ~3 scalar-memory round trips per step.
+constexpr int kStampBytes = 1984;                // 32 steps x 4 waves, or 16 steps x 8 waves (two 4-wave workgroups still fit one CU)
+__device__ __forceinline__ uint64_t stamp() { uint64_t t; asm volatile("s_memtime %0" : "=s"(t)); return t; }
+#else
+constexpr int kStampBytes = 0;
+#endif
+
+// Two workgroup shapes share the loop below:
+//   CO = 256 (tile 13): ONE 8-wave workgroup per CU owns 256 channels x 256 pixels; two patch buffers, the next chunk's patch lands while
+//                       the current one is multiplied;
+//   CO = 128 (tile 15): TWO 4-wave workgroups per CU, each 128 channels x 256 pixels with ONE patch buffer (77 KiB of LDS each).  A workgroup
+//                       stalls for its next patch (it can only be requested once every wave has read the old one), for its barriers and
+//                       for its serial epilogue - the CU's other workgroup multiplies meanwhile.  Same wave tile (64 channels x 128 pixels),
+//                       same K order: bit-identical results.
+template <int CO>
+struct PatchCfg {
+  static constexpr int kThreads = CO * 2, kWaves = CO / 32;
+  static constexpr int kWStage = CO * 128;         // one K-step of weights: CO rows x 128 B
+  static constexpr int kPatchBufs = CO == 256 ? 2 : 1;
+  static constexpr int kLdsPatch = 2 * kWStage;
+  static constexpr int kLdsSteps = kLdsPatch + kPatchBufs * kPatchBuf;
+  static constexpr int kLdsBias = kLdsSteps + 256 * (int)sizeof(OkpPatchStep);
+  static constexpr int kLdsStamps = kLdsBias + 1024;
+  static constexpr int kLdsSched = kLdsStamps + kStampBytes;     // next tile of the workgroup (dynamic tile order)
+  static constexpr int kLdsTotal = kLdsSched + 16;
+  static_assert(256 * CO * 2 <= kLdsSteps, "epilogue staging (256 px x CO ch, 16 bits) must not reach the step table");
+};
+static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
+
+static_assert(2 * PatchCfg<128>::kLdsTotal <= 160 * 1024, "two 4-wave workgroups must fit one CU's LDS");
+
+template <typename T, int CO>
+__global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_kernel(const OkpPatchParams p) {
   using x4_t = typename H16<T>::x4;
   using x8_t = typename H16<T>::x8;
+  using C = PatchCfg<CO>;
+  constexpr int kWStage = C::kWStage, kLdsPatch = C::kLdsPatch, NT = C::kThreads, NW = C::kWaves;
+  constexpr bool kOneBuf = C::kPatchBufs == 1;
   constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
-  __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
-  char* const steps_lds = smem + kLdsSteps;
-  char* const bias_lds = smem + kLdsBias;
+  __shared__ __attribute__((aligned(16))) char smem[C::kLdsTotal];
+  char* const steps_lds = smem + C::kLdsSteps;
+  char* const bias_lds = smem + C::kLdsBias;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,17 +99,22 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
   const int fr = lane & 15, fh = lane >> 4;
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.cout_pad * 4, 0x00020000);
 
-  if (tid < p.n_steps) reinterpret_cast<u32x4*>(steps_lds)[tid] = reinterpret_cast<const u32x4*>(p.steps)[tid];
+  for (int i = tid; i < p.n_steps; i += NT) reinterpret_cast<u32x4*>(steps_lds)[i] = reinterpret_cast<const u32x4*>(p.steps)[i];
   __syncthreads();
 
   // weights loader: lane (row r0 = tid >> 3, position tid & 7) fetches the chunk the read-side swizzle expects there
   const int r0 = tid >> 3;
   const int wc = (tid & 7) ^ ((r0 >> 1) & 7);
 
-  for (int slot = blockIdx.x; slot < p.n_tiles; slot += gridDim.x) {
-    // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos)
+  // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos); workgroup b
+  // runs on XCD b & 7.  Static order: slot b, b + grid, ... .  Dynamic order (p.sched, tile 15): a workgroup's first tile is its
+  // static one, every further one is drawn from its XCD's counter - of the two workgroups that share a CU the older one wins the
+  // arbitration for the matrix pipe and finishes a tile in 2/3 of the time the younger one needs, so equal shares would leave the
+  // CU half empty for the last third of the launch.
+  constexpr bool kDyn = CO == 128;
+  for (int slot = blockIdx.x; slot < p.n_tiles;) {
     const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
     // class-minor order: the four sub-pixel classes of a pixel block are consecutive tiles, i.e. workgroups of ONE XCD in the
@@ -94,7 +129,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     const int trem = px_tile - n * p.tiles_y * p.tiles_x;
     const int tyi = fastdiv(trem, p.div_tiles_x);
     const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
-    const int co0 = co_tile * 256;
+    const int co0 = co_tile * CO;
 
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16, (int)((uint32_t)(co0 + lane * 4) * 4u), 0, 0, 0);
@@ -102,7 +137,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     uint32_t wbase[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int co = co0 + r0 + i * 64;
+      const int co = co0 + r0 + i * (NT / 8);
       wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)wc * 16u : kInvalidOff;
     }
 
@@ -111,9 +146,9 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       char* const wt = smem + stage * kWStage + wave * 1024;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * 8192), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * (NT * 16)), 16, (int)(wbase[i] + wslice), 0, 0, 0);
     };
-    // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
+    // passes [k0, k1) of a patch: pass k = 1 KiB blocks NW k .. NW k + NW - 1 (one per wave) = patch pixels 8 NW k .. 8 NW (k + 1) - 1
     auto issue_patch = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
       const OkpPatchGeom& G = p.g[geom];                         // uniform index into the kernel arguments: scalar loads
       const int PW = G.PW, npx = G.npx;                          // valid columns; rows x kPitch
@@ -121,7 +156,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const int yb = G.conv_stride * y0 + G.oy, xb = G.conv_stride * x0 + G.ox;
       const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.data), 0, (int)G.bytes, 0x00020000);
       for (int k = k0; k < k1; ++k) {
-        const int blk = k * 8 + wave;
+        const int blk = k * NW + wave;
         if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
         const int idx = blk * 8 + (lane >> 3);
         const int i = idx / kPitch, j = idx - i * kPitch;
@@ -144,25 +179,45 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const u32x4 s0 = *reinterpret_cast<const u32x4*>(steps_lds + t0 * 16);
       const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0[3]);
       const int g0 = w3 & 0xff;
-      issue_patch(g0, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g0].npx + 63) >> 6, __builtin_amdgcn_readfirstlane((int)s0[2]) & 0xff);
+      issue_patch(g0, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g0].npx + 8 * NW - 1) / (8 * NW), kOneBuf ? 0 : (__builtin_amdgcn_readfirstlane((int)s0[2]) & 0xff));
     }
     issue_w(t0, t0 & 1);
 
+    int grp_last = 0x7fffffff;                     // (one patch buffer) last K-step of the group whose patch is resident
     for (int t = t0; t < t1; ++t) {
       const u32x4 sv = *reinterpret_cast<const u32x4*>(steps_lds + t * 16);
       const uint32_t tap_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[0]);
       const uint32_t nx_c0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[1]);
       const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[2]);
-      const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
+      const int pbuf = kOneBuf ? 0 : (int)(pk & 0xff), nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
       const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[3]);
       const int dxo = (w3 >> 8) & 0xff;                            // column offset of this step's tap inside the patch
       const bool more = t + 1 < t1;
-      const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
+      const bool next_patch = !kOneBuf && nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
 
+      if (kOneBuf) {
+        // one patch buffer: the patch of a new (chunk, geometry) group can only be requested once every wave has read the old one
+        if (t > grp_last) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          const int g = w3 & 0xff;
+          issue_patch(g, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g].npx + 8 * NW - 1) / (8 * NW), 0);
+        }
+        grp_last = (int)(w3 >> 24);
+      }
       // my part of step t's weights (and of its patch) has landed, and my fragment reads of step t-1 have returned (the
       // barrier frees their stage / patch buffer for the next LDS-DMA)
+#ifdef OKP_PATCH_STAMPS
+      uint64_t T0 = stamp();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      uint64_t T1 = stamp();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      uint64_t T2 = stamp();
+#else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
+#endif
 
       const char* const wt = smem + (t & 1) * kWStage;
       const char* const pbase = smem + kLdsPatch + pbuf * kPatchBuf;
@@ -199,6 +254,15 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       __builtin_amdgcn_sched_barrier(0);
       mma8(a0, bq0, S0{});
       __builtin_amdgcn_sched_barrier(0);
+#ifdef OKP_PATCH_STAMPS
+      {
+        uint64_t T3 = stamp();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(T0), "+s"(T1), "+s"(T2), "+s"(T3) :: "memory");
+        if (slot == (int)blockIdx.x && lane == 0 && t - t0 < kStampBytes / (16 * NW))
+          *reinterpret_cast<u32x4*>(smem + C::kLdsStamps + ((t - t0) * NW + wave) * 16) = u32x4{(uint32_t)T0, (uint32_t)T1, (uint32_t)T2, (uint32_t)T3};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       bq0[0] = ldb(0, 4); bq0[1] = ldb(0, 5); a1[0] = lda(1, 0); a1[1] = lda(1, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma8(a0, bq1, S1{});
@@ -225,8 +289,26 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       mma8(a1, bq0, S2{});
       mma8(a1, bq1, S3{});
     }
+#ifdef OKP_PATCH_STAMPS
+    {
+      uint64_t TE = stamp();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(TE) :: "memory");
+      if (slot == (int)blockIdx.x && lane == 0 && t1 - t0 < kStampBytes / (16 * NW))
+        *reinterpret_cast<u32x4*>(smem + C::kLdsStamps + ((t1 - t0) * NW + wave) * 16) = u32x4{(uint32_t)TE, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    if (slot == (int)blockIdx.x && (blockIdx.x < 8 || (blockIdx.x >= 256 && blockIdx.x < 264)) && p.dbg) {
+      const int row = blockIdx.x < 8 ? blockIdx.x : blockIdx.x - 248;       // workgroups 0..7 and 256..263 (the second ones of their CUs)
+      for (int i = tid; i < kStampBytes / 4; i += NT) p.dbg[row * (kStampBytes / 4) + i] = reinterpret_cast<const uint32_t*>(smem + C::kLdsStamps)[i];
+    }
+#endif
     __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
 
+    if (kDyn && tid == 0) {                        // the next tile (read by everyone behind the epilogue's last barrier)
+      int nx = slot + (int)gridDim.x;
+      if (p.sched) nx = (((int)gridDim.x - xcd + 7) / 8 + atomicAdd(&p.sched[xcd], 1)) * 8 + xcd;
+      *reinterpret_cast<volatile int*>(smem + C::kLdsSched) = nx;
+    }
     // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
@@ -235,7 +317,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 #pragma unroll
       for (int j = 0; j < TPX; ++j) {
         const int prow = (wpx * TPX + j) * 16 + fr;
-        char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
+        char* dst = smem + prow * (CO * 2) + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
         x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][e] + bv[e]);
@@ -243,7 +325,8 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       }
     }
     __syncthreads();
-    constexpr int U = 256 * 32 / 512;              // 16-byte items (8 channels of one pixel) per thread
+    constexpr int Q = CO / 8;                      // 16-byte items (8 channels) per pixel
+    constexpr int U = 256 * Q / NT;                // ... per thread (16)
     constexpr int UH = 8;                          // residual vectors in flight together (4: -1 %, 16: spills, +12 %)
     const bool relu = p.act == OKP_ACT_RELU;
 #pragma unroll 1
@@ -252,8 +335,8 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       uint32_t ooff[UH];
 #pragma unroll
       for (int u = 0; u < UH; ++u) {
-        const int it = tid + (ub + u) * 512;
-        const int q = it & 31, prow = it >> 5;
+        const int it = tid + (ub + u) * NT;
+        const int q = it & (Q - 1), prow = it / Q;
         const int co = co0 + q * 8;
         const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
         ooff[u] = co < p.cout ? opix : kInvalidOff;
@@ -261,7 +344,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
-          const int q = (tid + (ub + u) * 512) & 31;
+          const int q = (tid + (ub + u) * NT) & (Q - 1);
           const int co = co0 + q * 8;
           const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
           rres[u] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 2);
@@ -269,9 +352,9 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       }
 #pragma unroll
       for (int u = 0; u < UH; ++u) {
-        const int it = tid + (ub + u) * 512;
-        const int q = it & 31, prow = it >> 5;
-        u32x4 w = *reinterpret_cast<const u32x4*>(smem + prow * 512 + ((q ^ (prow & 7)) << 4));
+        const int it = tid + (ub + u) * NT;
+        const int q = it & (Q - 1), prow = it / Q;
+        u32x4 w = *reinterpret_cast<const u32x4*>(smem + prow * (CO * 2) + ((q ^ (prow & 7)) << 4));
         if (ooff[u] == kInvalidOff) continue;
         char* op = static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q * 8) * 2;
         if (!p.res) {
@@ -295,6 +378,12 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       }
     }
     __syncthreads();                               // staging is free again: the next tile's LDS-DMA may overwrite it
+    if (kDyn) slot = *reinterpret_cast<volatile int*>(smem + C::kLdsSched);
+    else slot += gridDim.x;
+  }
+  if (kDyn && p.sched && tid == 0) {                       // the last workgroup to leave puts the counters back to zero for the next launch
+    if (atomicAdd(&p.sched[8], 1) == (int)gridDim.x - 1)
+      for (int i = 0; i < 9; ++i) atomicExch(&p.sched[i], 0);
   }
 }
 
@@ -312,8 +401,9 @@ bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
   return true;
 }
 
-int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStream_t stream) {
-  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, int tile, hipStream_t stream) {
+  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile %d (patch-resident kernel) does not apply to this plan / problem", tile); return OKP_EINVAL; }
+  const int CO = tile == 15 ? 128 : 256;           // 15: two 4-wave workgroups per CU, 128 channels each
   OkpPatchParams p;
   std::memset(&p, 0, sizeof(p));
   for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
@@ -331,11 +421,65 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
   p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
-  p.n_co_tiles = q.cout_pad / 256;
+  p.n_co_tiles = q.cout_pad / CO;
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;
-  const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
-  if (plan->dtype == OKP_BF16) hipLaunchKernelGGL(okp_igemm_patch_kernel<__bf16>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(okp_igemm_patch_kernel<_Float16>, grid, block, 0, stream, p);
+#ifdef OKP_PATCH_STAMPS
+  static uint32_t* dbg = nullptr;
+  if (!dbg) (void)hipMalloc((void**)&dbg, 16 * kStampBytes);
+  (void)hipMemsetAsync(dbg, 0, 16 * kStampBytes, stream);
+  p.dbg = dbg;
+#endif
+  if (CO == 128) {
+    // EXPERIMENT: one global counter set (launches of this kernel must not overlap)
+    static int* sched = nullptr;
+    static const bool dyn = [] { const char* e = getenv("OKP_PATCH_DYN"); return !(e && e[0] == '0'); }();
+    if (!sched && dyn) { (void)hipMalloc((void**)&sched, 64); (void)hipMemset(sched, 0, 64); }
+    p.sched = dyn ? sched : nullptr;
+  }
+  const int resident = CO == 256 ? 256 : 512;      // persistent grid: the workgroups the 256 CUs hold at once
+  const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block(CO * 2);
+  if (CO == 256) {
+    if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 256>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 256>), grid, block, 0, stream, p);
+  } else {
+    if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 128>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 128>), grid, block, 0, stream, p);
+  }
+#ifdef OKP_PATCH_STAMPS
+  if (getenv("OKP_PATCH_STAMPS_PRINT")) {
+    (void)hipStreamSynchronize(stream);
+    std::vector<uint32_t> h(16 * kStampBytes / 4);
+    (void)hipMemcpy(h.data(), dbg, 16 * kStampBytes, hipMemcpyDeviceToHost);
+    const int NW = CO / 32, ns = p.steps_per_class;
+    printf("patch stamps: tile %d, %d K-steps per tile; clocks per step: wait(DMA) | barrier | to first MFMAs issued | rest of the body\n", tile, ns);
+    double sum[4] = {0, 0, 0, 0};
+    for (int wg = 0; wg < 16; ++wg) {
+      const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4)];
+      const int last = std::min(ns, kStampBytes / (16 * NW) - 1);
+      printf("workgroup %3d: first step starts at clock %u (relative to workgroup 0), step %d at +%u\n", wg < 8 ? wg : wg + 248, a[0] - h[0], last, a[last * NW * 4] - a[0]);
+    }
+    for (int wg = 0; wg < 16; wg += 8) {
+      for (int t = 0; t < ns && t < kStampBytes / (16 * NW) - 1; ++t) {
+        printf("wg %3d step %2d:", wg < 8 ? wg : wg + 248, t);
+        for (int w = 0; w < NW; w += NW - 1) {
+          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * NW + w) * 4];
+          const uint32_t nx = a[NW * 4];
+          printf("   wave %d: %5u | %5u | %5u | %5u", w, a[1] - a[0], a[2] - a[1], a[3] - a[2], nx - a[3]);
+        }
+        printf("\n");
+      }
+    }
+    int cnt = 0;
+    for (int wg = 0; wg < 16; ++wg)
+      for (int t = 1; t < ns && t < kStampBytes / (16 * NW) - 1; ++t)
+        for (int w = 0; w < NW; ++w) {
+          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * NW + w) * 4];
+          sum[0] += a[1] - a[0]; sum[1] += a[2] - a[1]; sum[2] += a[3] - a[2]; sum[3] += a[NW * 4] - a[3]; ++cnt;
+        }
+    printf("mean over 16 workgroups, all waves, steps 1..: wait %.0f | barrier %.0f | first MFMAs %.0f | rest %.0f  = %.0f clocks per step\n",
+           sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, (sum[0] + sum[1] + sum[2] + sum[3]) / cnt);
+  }
+#endif
   return okp_check_hip(hipGetLastError(), "okp_igemm_patch launch");
 }

@@ -162,6 +162,10 @@ struct OkpPatchParams {
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
   int32_t act, n_co_tiles, n_tiles;
+  int32_t* sched;              // dynamic tile order: eight per-XCD tile counters + a count of finished workgroups, all zero between launches (or NULL: static order)
+#ifdef OKP_PATCH_STAMPS
+  uint32_t* dbg;
+#endif
 };
 
 struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 128 -> 256, stride 1
@@ -221,4 +225,4 @@ int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_ch
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
-int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // tile 13 / 15
