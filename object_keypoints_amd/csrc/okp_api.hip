@@ -408,8 +408,8 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   }
   if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
   if (a->res.data && (a->res.h != (sub2 ? a->out16.h : a->out.h) || a->res.w != (sub2 ? a->out16.w : a->out.w))) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
-  if (a->tile < 0 || a->tile > 15 || !((1u << a->tile) & 0xA15Fu)) {       // 0 (heuristic), 1, 2, 3, 4, 6, 8, 13, 15
-    okp_set_error("okp_conv_forward: tile %d is not one of 0 (heuristic), 1, 2, 3, 4, 6, 8, 13, 15", a->tile); return OKP_EINVAL;
+  if (a->tile < 0 || a->tile > 13 || !((1u << a->tile) & 0x215Fu)) {       // 0 (heuristic), 1, 2, 3, 4, 6, 8, 13
+    okp_set_error("okp_conv_forward: tile %d is not one of 0 (heuristic), 1, 2, 3, 4, 6, 8, 13", a->tile); return OKP_EINVAL;
   }
 
   OkpIgemmParams p;
@@ -488,8 +488,7 @@ static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
       ((tile == 6 && dense1) || (ncls == 4 && patch_tiles >= 256))) {
     bool ok = true;
     for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s];
-    static const int patch2 = [] { const char* e = getenv("OKP_PATCH2"); return e ? atoi(e) : 0; }();   // experiment switch: 1 = tile 15 everywhere
-    if (ok) return (patch2 == 1 || (patch2 == 2 && ncls == 1 && plan->patch_n_geom == plan->n_src)) ? 15 : 13;   // 2: stride-1 / single-tap sources only
+    if (ok) return 13;
   }
   return tile;
 }

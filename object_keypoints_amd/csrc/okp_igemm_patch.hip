@@ -44,53 +44,40 @@ namespace {
 constexpr uint32_t kPatchKeys = 0x7ac788u;
 __device__ __forceinline__ uint32_t patch_key(int col) { return (kPatchKeys >> (3 * (col >> 1))) & 7u; }
 
+constexpr int kWStage = 256 * 128;                 // one K-step of weights: 256 rows x 128 B
 constexpr int kPitch = 18;                         // patch row pitch in pixels (16-wide patches leave two columns unused)
 constexpr int kPatchBuf = 41 * 1024;               // 18 x 18 px x 128 B, rounded up to whole 1 KiB LDS-DMA blocks
-
+constexpr int kLdsPatch = 2 * kWStage;
+constexpr int kLdsSteps = kLdsPatch + 2 * kPatchBuf;
+constexpr int kLdsBias = kLdsSteps + 256 * (int)sizeof(OkpPatchStep);
 #ifdef OKP_PATCH_STAMPS
-// Debug build: shader-clock stamps of every K-step of a workgroup's first tile (before / after the DMA wait, after the barrier, after the
-// first MFMA group was issued), kept in LDS and dumped for the first 16 workgroups.  Perturbs the loop by ~3 scalar-memory round trips per step.
-constexpr int kStampBytes = 1984;                // 32 steps x 4 waves, or 16 steps x 8 waves (two 4-wave workgroups still fit one CU)
+// Debug build (OKP_EXTRA_CFLAGS=-DOKP_PATCH_STAMPS, scripts/run_patch_stamps.sh): shader-clock stamps of every K-step of a workgroup's first
+// tile - before / after the LDS-DMA wait, after the barrier, after the first MFMA group was issued - kept in LDS and dumped for workgroups
+// 0..15.  Perturbs the loop by three scalar-memory round trips per step.
+constexpr int kStampBytes = 1024;                  // 8 steps x 8 waves x 16 B (what is left of the LDS)
 __device__ __forceinline__ uint64_t stamp() { uint64_t t; asm volatile("s_memtime %0" : "=s"(t)); return t; }
 #else
 constexpr int kStampBytes = 0;
 #endif
-
-// Two workgroup shapes share the loop below:
-//   CO = 256 (tile 13): ONE 8-wave workgroup per CU owns 256 channels x 256 pixels; two patch buffers, the next chunk's patch lands while
-//                       the current one is multiplied;
-//   CO = 128 (tile 15): TWO 4-wave workgroups per CU, each 128 channels x 256 pixels with ONE patch buffer (77 KiB of LDS each).  A workgroup
-//                       stalls for its next patch (it can only be requested once every wave has read the old one), for its barriers and
-//                       for its serial epilogue - the CU's other workgroup multiplies meanwhile.  Same wave tile (64 channels x 128 pixels),
-//                       same K order: bit-identical results.
-template <int CO>
-struct PatchCfg {
-  static constexpr int kThreads = CO * 2, kWaves = CO / 32;
-  static constexpr int kWStage = CO * 128;         // one K-step of weights: CO rows x 128 B
-  static constexpr int kPatchBufs = CO == 256 ? 2 : 1;
-  static constexpr int kLdsPatch = 2 * kWStage;
-  static constexpr int kLdsSteps = kLdsPatch + kPatchBufs * kPatchBuf;
-  static constexpr int kLdsBias = kLdsSteps + 256 * (int)sizeof(OkpPatchStep);
-  static constexpr int kLdsStamps = kLdsBias + 1024;
-  static constexpr int kLdsSched = kLdsStamps + kStampBytes;     // next tile of the workgroup (dynamic tile order)
-  static constexpr int kLdsTotal = kLdsSched + 16;
-  static_assert(256 * CO * 2 <= kLdsSteps, "epilogue staging (256 px x CO ch, 16 bits) must not reach the step table");
-};
+// Source offsets of the patch pixels, per geometry, rebuilt for every tile: [geometry][328] u32 = byte offset of the pixel's first channel
+// | swizzle key of its column (bits 0-2), or bit 31 for a pixel outside the image / the patch.  The in-loop patch requests read their
+// addresses here instead of working them out (scalar loads of the geometry from the kernel arguments + ~30 vector instructions per
+// LDS-DMA: measured 4-6 % of a 3x3 launch and ~10 % of a stride-2 one, profiles/r04l_ablation_patch_issue_parts.txt).
+constexpr int kGeoEntries = 328;                   // 18 x 18 pixels, rounded up to whole 8-pixel LDS-DMA blocks
+constexpr int kLdsGeo = kLdsBias + 1024;
+constexpr int kLdsStamps = kLdsGeo + OKP_PATCH_MAX_GEOM * kGeoEntries * 4;
+constexpr int kLdsTotal = kLdsStamps + kStampBytes;
 static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
+static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
 
-static_assert(2 * PatchCfg<128>::kLdsTotal <= 160 * 1024, "two 4-wave workgroups must fit one CU's LDS");
-
-template <typename T, int CO>
-__global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_kernel(const OkpPatchParams p) {
+template <typename T>
+__global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
   using x4_t = typename H16<T>::x4;
   using x8_t = typename H16<T>::x8;
-  using C = PatchCfg<CO>;
-  constexpr int kWStage = C::kWStage, kLdsPatch = C::kLdsPatch, NT = C::kThreads, NW = C::kWaves;
-  constexpr bool kOneBuf = C::kPatchBufs == 1;
   constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
-  __shared__ __attribute__((aligned(16))) char smem[C::kLdsTotal];
-  char* const steps_lds = smem + C::kLdsSteps;
-  char* const bias_lds = smem + C::kLdsBias;
+  __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
+  char* const steps_lds = smem + kLdsSteps;
+  char* const bias_lds = smem + kLdsBias;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,22 +86,19 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
   const int fr = lane & 15, fh = lane >> 4;
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.cout_pad * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src_data[0]), 0, (int)p.src_bytes[0], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src_data[1]), 0, (int)p.src_bytes[1], 0x00020000);
 
-  for (int i = tid; i < p.n_steps; i += NT) reinterpret_cast<u32x4*>(steps_lds)[i] = reinterpret_cast<const u32x4*>(p.steps)[i];
+  if (tid < p.n_steps) reinterpret_cast<u32x4*>(steps_lds)[tid] = reinterpret_cast<const u32x4*>(p.steps)[tid];
   __syncthreads();
 
   // weights loader: lane (row r0 = tid >> 3, position tid & 7) fetches the chunk the read-side swizzle expects there
   const int r0 = tid >> 3;
   const int wc = (tid & 7) ^ ((r0 >> 1) & 7);
 
-  // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos); workgroup b
-  // runs on XCD b & 7.  Static order: slot b, b + grid, ... .  Dynamic order (p.sched, tile 15): a workgroup's first tile is its
-  // static one, every further one is drawn from its XCD's counter - of the two workgroups that share a CU the older one wins the
-  // arbitration for the matrix pipe and finishes a tile in 2/3 of the time the younger one needs, so equal shares would leave the
-  // CU half empty for the last third of the launch.
-  constexpr bool kDyn = CO == 128;
-  for (int slot = blockIdx.x; slot < p.n_tiles;) {
+  for (int slot = blockIdx.x; slot < p.n_tiles; slot += gridDim.x) {
+    // XCD-aware order as in okp_igemm_kernel: each XCD walks a contiguous range of tiles (neighbouring blocks share halos)
     const int xq = p.n_tiles >> 3, xr = p.n_tiles & 7, xcd = slot & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (slot >> 3);
     // class-minor order: the four sub-pixel classes of a pixel block are consecutive tiles, i.e. workgroups of ONE XCD in the
@@ -129,7 +113,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
     const int trem = px_tile - n * p.tiles_y * p.tiles_x;
     const int tyi = fastdiv(trem, p.div_tiles_x);
     const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
-    const int co0 = co_tile * CO;
+    const int co0 = co_tile * 256;
 
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16, (int)((uint32_t)(co0 + lane * 4) * 4u), 0, 0, 0);
@@ -137,7 +121,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
     uint32_t wbase[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int co = co0 + r0 + i * (NT / 8);
+      const int co = co0 + r0 + i * 64;
       wbase[i] = (co < p.cout_pad) ? (uint32_t)co * 128u + (uint32_t)wc * 16u : kInvalidOff;
     }
 
@@ -146,9 +130,30 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       char* const wt = smem + stage * kWStage + wave * 1024;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * (NT * 16)), 16, (int)(wbase[i] + wslice), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * 8192), 16, (int)(wbase[i] + wslice), 0, 0, 0);
     };
-    // passes [k0, k1) of a patch: pass k = 1 KiB blocks NW k .. NW k + NW - 1 (one per wave) = patch pixels 8 NW k .. 8 NW (k + 1) - 1
+    // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
+    bool abl_in_loop = false; (void)abl_in_loop;
+    // source offset (first channel) | column key of patch pixel idx of geometry G, or bit 31
+    auto patch_pixel = [&](const OkpPatchGeom& G, int idx) -> uint32_t {
+      const int i = idx / kPitch, j = idx - i * kPitch;
+      const int ys = G.conv_stride * y0 + G.oy + i * G.step, xs = G.conv_stride * x0 + G.ox + j * G.step;
+      const bool ok = idx < G.npx && j < G.PW && ys >= 0 && ys < G.H && xs >= 0 && xs < G.W;
+      return ok ? ((uint32_t)((n * G.H + ys) * G.W + xs) * (uint32_t)(G.pix_stride * 2)) | patch_key(j) : kInvalidOff;
+    };
+    // the in-loop form: addresses from the tile's offset table, everything else from registers (no scalar loads)
+    auto issue_patch_tab = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
+      const int npx = 18 * (int)((p.geom_ph >> (5 * geom)) & 31u);
+      const __amdgpu_buffer_rsrc_t rs_x = ((p.geom_src >> geom) & 1) ? rs_s1 : rs_s0;
+      const uint32_t* const tab = reinterpret_cast<const uint32_t*>(smem + kLdsGeo) + geom * kGeoEntries + (lane >> 3);
+      for (int k = k0; k < k1; ++k) {
+        const int blk = k * 8 + wave;
+        if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
+        const uint32_t e = tab[blk * 8];
+        const uint32_t off = (e & kInvalidOff) ? kInvalidOff : (e & ~7u) + c0b + ((((uint32_t)lane & 7u) ^ (e & 7u)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + kLdsPatch + buf * kPatchBuf + blk * 1024), 16, (int)off, 0, 0, 0);
+      }
+    };
     auto issue_patch = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
       const OkpPatchGeom& G = p.g[geom];                         // uniform index into the kernel arguments: scalar loads
       const int PW = G.PW, npx = G.npx;                          // valid columns; rows x kPitch
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       const int yb = G.conv_stride * y0 + G.oy, xb = G.conv_stride * x0 + G.ox;
       const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.data), 0, (int)G.bytes, 0x00020000);
       for (int k = k0; k < k1; ++k) {
-        const int blk = k * NW + wave;
+        const int blk = k * 8 + wave;
         if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
         const int idx = blk * 8 + (lane >> 3);
         const int i = idx / kPitch, j = idx - i * kPitch;
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
         const bool ok = idx < npx && j < PW && ys >= 0 && ys < H && xs >= 0 && xs < W;
         const uint32_t off = ok ? (uint32_t)((n * H + ys) * W + xs) * (uint32_t)ps2 + c0b + (uint32_t)ch * 16u : kInvalidOff;
         char* const dst = smem + kLdsPatch + buf * kPatchBuf + blk * 1024;
+#if defined(OKP_PATCH_ABL_NODMA)               // timing ablation: all the address arithmetic, no LDS-DMA (the in-loop calls only)
+        if (abl_in_loop) { asm volatile("" :: "v"(off), "v"(dst)); continue; }
+#elif defined(OKP_PATCH_ABL_CHEAPADDR)         // timing ablation: the LDS-DMA with an address that costs nothing (in-loop calls only)
+        if (abl_in_loop) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)(blk * 1024 + lane * 16), 0, 0, 0); continue; }
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
       }
     };
@@ -175,36 +185,32 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
 #pragma unroll
       for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // this tile's offset tables (read by the in-loop requests, all of them behind the first K-step's barrier)
+    for (int g = 0; g < p.n_geom; ++g)
+      if (tid < kGeoEntries) reinterpret_cast<uint32_t*>(smem + kLdsGeo)[g * kGeoEntries + tid] = patch_pixel(p.g[g], tid);
     {                                              // the first patch of the class: geometry / chunk / buffer of step t0
       const u32x4 s0 = *reinterpret_cast<const u32x4*>(steps_lds + t0 * 16);
       const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0[3]);
       const int g0 = w3 & 0xff;
-      issue_patch(g0, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g0].npx + 8 * NW - 1) / (8 * NW), kOneBuf ? 0 : (__builtin_amdgcn_readfirstlane((int)s0[2]) & 0xff));
+      issue_patch(g0, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g0].npx + 63) >> 6, __builtin_amdgcn_readfirstlane((int)s0[2]) & 0xff);
     }
     issue_w(t0, t0 & 1);
 
-    int grp_last = 0x7fffffff;                     // (one patch buffer) last K-step of the group whose patch is resident
     for (int t = t0; t < t1; ++t) {
       const u32x4 sv = *reinterpret_cast<const u32x4*>(steps_lds + t * 16);
       const uint32_t tap_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[0]);
       const uint32_t nx_c0b = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[1]);
       const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[2]);
-      const int pbuf = kOneBuf ? 0 : (int)(pk & 0xff), nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
+      const int pbuf = pk & 0xff, nx_k0 = (pk >> 8) & 0xff, nx_k1 = (pk >> 16) & 0xff, nx_geom = pk >> 24;
       const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[3]);
       const int dxo = (w3 >> 8) & 0xff;                            // column offset of this step's tap inside the patch
       const bool more = t + 1 < t1;
-      const bool next_patch = !kOneBuf && nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
+      const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
+#ifdef OKP_PATCH_ABL_NOPATCH                    // timing ablation (wrong results): no patch but the first of a tile is ever requested
+      const bool next_patch_abl = false;
+#define next_patch next_patch_abl
+#endif
 
-      if (kOneBuf) {
-        // one patch buffer: the patch of a new (chunk, geometry) group can only be requested once every wave has read the old one
-        if (t > grp_last) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          const int g = w3 & 0xff;
-          issue_patch(g, ((w3 >> 16) & 0xffu) * 128u, 0, (p.g[g].npx + 8 * NW - 1) / (8 * NW), 0);
-        }
-        grp_last = (int)(w3 >> 24);
-      }
       // my part of step t's weights (and of its patch) has landed, and my fragment reads of step t-1 have returned (the
       // barrier frees their stage / patch buffer for the next LDS-DMA)
 #ifdef OKP_PATCH_STAMPS
@@ -258,8 +264,8 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       {
         uint64_t T3 = stamp();
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(T0), "+s"(T1), "+s"(T2), "+s"(T3) :: "memory");
-        if (slot == (int)blockIdx.x && lane == 0 && t - t0 < kStampBytes / (16 * NW))
-          *reinterpret_cast<u32x4*>(smem + C::kLdsStamps + ((t - t0) * NW + wave) * 16) = u32x4{(uint32_t)T0, (uint32_t)T1, (uint32_t)T2, (uint32_t)T3};
+        if (slot == (int)blockIdx.x && lane == 0 && t - t0 < kStampBytes / 128)
+          *reinterpret_cast<u32x4*>(smem + kLdsStamps + ((t - t0) * 8 + wave) * 16) = u32x4{(uint32_t)T0, (uint32_t)T1, (uint32_t)T2, (uint32_t)T3};
       }
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       mma8(a0, bq0, S2{});
       __builtin_amdgcn_sched_barrier(0);
       bq0[0] = ldb(1, 0); bq0[1] = ldb(1, 1);
-      if (next_patch) issue_patch(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+      if (next_patch) issue_patch_tab(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma8(a0, bq1, S3{});
       __builtin_amdgcn_sched_barrier(0);
@@ -293,22 +299,15 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
     {
       uint64_t TE = stamp();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(TE) :: "memory");
-      if (slot == (int)blockIdx.x && lane == 0 && t1 - t0 < kStampBytes / (16 * NW))
-        *reinterpret_cast<u32x4*>(smem + C::kLdsStamps + ((t1 - t0) * NW + wave) * 16) = u32x4{(uint32_t)TE, 0u, 0u, 0u};
+      if (slot == (int)blockIdx.x && lane == 0 && t1 - t0 < kStampBytes / 128)
+        *reinterpret_cast<u32x4*>(smem + kLdsStamps + ((t1 - t0) * 8 + wave) * 16) = u32x4{(uint32_t)TE, 0u, 0u, 0u};
     }
     __syncthreads();
-    if (slot == (int)blockIdx.x && (blockIdx.x < 8 || (blockIdx.x >= 256 && blockIdx.x < 264)) && p.dbg) {
-      const int row = blockIdx.x < 8 ? blockIdx.x : blockIdx.x - 248;       // workgroups 0..7 and 256..263 (the second ones of their CUs)
-      for (int i = tid; i < kStampBytes / 4; i += NT) p.dbg[row * (kStampBytes / 4) + i] = reinterpret_cast<const uint32_t*>(smem + C::kLdsStamps)[i];
-    }
+    if (slot == (int)blockIdx.x && blockIdx.x < 16 && p.dbg)
+      for (int i = tid; i < kStampBytes / 4; i += 512) p.dbg[blockIdx.x * (kStampBytes / 4) + i] = reinterpret_cast<const uint32_t*>(smem + kLdsStamps)[i];
 #endif
     __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
 
-    if (kDyn && tid == 0) {                        // the next tile (read by everyone behind the epilogue's last barrier)
-      int nx = slot + (int)gridDim.x;
-      if (p.sched) nx = (((int)gridDim.x - xcd + 7) / 8 + atomicAdd(&p.sched[xcd], 1)) * 8 + xcd;
-      *reinterpret_cast<volatile int*>(smem + C::kLdsSched) = nx;
-    }
     // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
 #pragma unroll
       for (int j = 0; j < TPX; ++j) {
         const int prow = (wpx * TPX + j) * 16 + fr;
-        char* dst = smem + prow * (CO * 2) + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
+        char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
         x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][e] + bv[e]);
@@ -325,8 +324,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       }
     }
     __syncthreads();
-    constexpr int Q = CO / 8;                      // 16-byte items (8 channels) per pixel
-    constexpr int U = 256 * Q / NT;                // ... per thread (16)
+    constexpr int U = 256 * 32 / 512;              // 16-byte items (8 channels of one pixel) per thread
     constexpr int UH = 8;                          // residual vectors in flight together (4: -1 %, 16: spills, +12 %)
     const bool relu = p.act == OKP_ACT_RELU;
 #pragma unroll 1
@@ -335,8 +333,8 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       uint32_t ooff[UH];
 #pragma unroll
       for (int u = 0; u < UH; ++u) {
-        const int it = tid + (ub + u) * NT;
-        const int q = it & (Q - 1), prow = it / Q;
+        const int it = tid + (ub + u) * 512;
+        const int q = it & 31, prow = it >> 5;
         const int co = co0 + q * 8;
         const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
         ooff[u] = co < p.cout ? opix : kInvalidOff;
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
-          const int q = (tid + (ub + u) * NT) & (Q - 1);
+          const int q = (tid + (ub + u) * 512) & 31;
           const int co = co0 + q * 8;
           const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
           rres[u] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 2);
@@ -352,9 +350,9 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       }
 #pragma unroll
       for (int u = 0; u < UH; ++u) {
-        const int it = tid + (ub + u) * NT;
-        const int q = it & (Q - 1), prow = it / Q;
-        u32x4 w = *reinterpret_cast<const u32x4*>(smem + prow * (CO * 2) + ((q ^ (prow & 7)) << 4));
+        const int it = tid + (ub + u) * 512;
+        const int q = it & 31, prow = it >> 5;
+        u32x4 w = *reinterpret_cast<const u32x4*>(smem + prow * 512 + ((q ^ (prow & 7)) << 4));
         if (ooff[u] == kInvalidOff) continue;
         char* op = static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q * 8) * 2;
         if (!p.res) {
@@ -378,12 +376,6 @@ __global__ __launch_bounds__(CO * 2, CO == 256 ? 1 : 2) void okp_igemm_patch_ker
       }
     }
     __syncthreads();                               // staging is free again: the next tile's LDS-DMA may overwrite it
-    if (kDyn) slot = *reinterpret_cast<volatile int*>(smem + C::kLdsSched);
-    else slot += gridDim.x;
-  }
-  if (kDyn && p.sched && tid == 0) {                       // the last workgroup to leave puts the counters back to zero for the next launch
-    if (atomicAdd(&p.sched[8], 1) == (int)gridDim.x - 1)
-      for (int i = 0; i < 9; ++i) atomicExch(&p.sched[i], 0);
   }
 }
 
@@ -401,9 +393,8 @@ bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
   return true;
 }
 
-int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, int tile, hipStream_t stream) {
-  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile %d (patch-resident kernel) does not apply to this plan / problem", tile); return OKP_EINVAL; }
-  const int CO = tile == 15 ? 128 : 256;           // 15: two 4-wave workgroups per CU, 128 channels each
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStream_t stream) {
+  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
   OkpPatchParams p;
   std::memset(&p, 0, sizeof(p));
   for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
@@ -413,6 +404,14 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, int ti
     g.PW = plan->patch_PW[gi]; g.npx = 18 * plan->patch_PH[gi];
     g.oy = plan->patch_oy[gi]; g.ox = plan->patch_ox[gi]; g.step = plan->patch_step[gi]; g.conv_stride = plan->conv_stride[ss];
   }
+  p.n_geom = plan->patch_n_geom;
+  for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
+    const int ss = plan->patch_src[gi];
+    p.geom_ph |= (uint32_t)plan->patch_PH[gi] << (5 * gi);
+    p.geom_src |= (uint32_t)ss << gi;
+    p.src_data[ss] = q.src[ss]; p.src_bytes[ss] = q.src_bytes[ss];
+  }
+  if (!p.src_data[1]) { p.src_data[1] = p.src_data[0]; p.src_bytes[1] = p.src_bytes[0]; }
   p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias;
   p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
   p.n_classes = q.n_classes; p.steps_per_class = plan->n_slices / q.n_classes;
@@ -421,7 +420,7 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, int ti
   p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
   p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
-  p.n_co_tiles = q.cout_pad / CO;
+  p.n_co_tiles = q.cout_pad / 256;
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;
 #ifdef OKP_PATCH_STAMPS
@@ -430,52 +429,32 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, int ti
   (void)hipMemsetAsync(dbg, 0, 16 * kStampBytes, stream);
   p.dbg = dbg;
 #endif
-  if (CO == 128) {
-    // EXPERIMENT: one global counter set (launches of this kernel must not overlap)
-    static int* sched = nullptr;
-    static const bool dyn = [] { const char* e = getenv("OKP_PATCH_DYN"); return !(e && e[0] == '0'); }();
-    if (!sched && dyn) { (void)hipMalloc((void**)&sched, 64); (void)hipMemset(sched, 0, 64); }
-    p.sched = dyn ? sched : nullptr;
-  }
-  const int resident = CO == 256 ? 256 : 512;      // persistent grid: the workgroups the 256 CUs hold at once
-  const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block(CO * 2);
-  if (CO == 256) {
-    if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 256>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 256>), grid, block, 0, stream, p);
-  } else {
-    if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 128>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 128>), grid, block, 0, stream, p);
-  }
+  const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
+  if (plan->dtype == OKP_BF16) hipLaunchKernelGGL(okp_igemm_patch_kernel<__bf16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(okp_igemm_patch_kernel<_Float16>, grid, block, 0, stream, p);
 #ifdef OKP_PATCH_STAMPS
   if (getenv("OKP_PATCH_STAMPS_PRINT")) {
     (void)hipStreamSynchronize(stream);
     std::vector<uint32_t> h(16 * kStampBytes / 4);
     (void)hipMemcpy(h.data(), dbg, 16 * kStampBytes, hipMemcpyDeviceToHost);
-    const int NW = CO / 32, ns = p.steps_per_class;
-    printf("patch stamps: tile %d, %d K-steps per tile; clocks per step: wait(DMA) | barrier | to first MFMAs issued | rest of the body\n", tile, ns);
-    double sum[4] = {0, 0, 0, 0};
-    for (int wg = 0; wg < 16; ++wg) {
-      const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4)];
-      const int last = std::min(ns, kStampBytes / (16 * NW) - 1);
-      printf("workgroup %3d: first step starts at clock %u (relative to workgroup 0), step %d at +%u\n", wg < 8 ? wg : wg + 248, a[0] - h[0], last, a[last * NW * 4] - a[0]);
-    }
-    for (int wg = 0; wg < 16; wg += 8) {
-      for (int t = 0; t < ns && t < kStampBytes / (16 * NW) - 1; ++t) {
-        printf("wg %3d step %2d:", wg < 8 ? wg : wg + 248, t);
-        for (int w = 0; w < NW; w += NW - 1) {
-          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * NW + w) * 4];
-          const uint32_t nx = a[NW * 4];
-          printf("   wave %d: %5u | %5u | %5u | %5u", w, a[1] - a[0], a[2] - a[1], a[3] - a[2], nx - a[3]);
+    const int ns = std::min(p.steps_per_class, kStampBytes / 128 - 1);
+    printf("patch stamps: %d K-steps per tile; clocks per step: wait for the LDS-DMA | barrier | until the first MFMA group was issued | rest of the body\n", p.steps_per_class);
+    for (int wg = 0; wg < 16; wg += 5)
+      for (int t = 0; t < ns; ++t) {
+        printf("wg %2d step %2d:", wg, t);
+        for (int w = 0; w < 8; w += 7) {
+          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * 8 + w) * 4];
+          printf("   wave %d: %5u | %5u | %5u | %5u", w, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[32] - a[3]);
         }
         printf("\n");
       }
-    }
+    double sum[4] = {0, 0, 0, 0};
     int cnt = 0;
     for (int wg = 0; wg < 16; ++wg)
-      for (int t = 1; t < ns && t < kStampBytes / (16 * NW) - 1; ++t)
-        for (int w = 0; w < NW; ++w) {
-          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * NW + w) * 4];
-          sum[0] += a[1] - a[0]; sum[1] += a[2] - a[1]; sum[2] += a[3] - a[2]; sum[3] += a[NW * 4] - a[3]; ++cnt;
+      for (int t = 1; t < ns; ++t)
+        for (int w = 0; w < 8; ++w) {
+          const uint32_t* a = &h[(size_t)wg * (kStampBytes / 4) + (t * 8 + w) * 4];
+          sum[0] += a[1] - a[0]; sum[1] += a[2] - a[1]; sum[2] += a[3] - a[2]; sum[3] += a[32] - a[3]; ++cnt;
         }
     printf("mean over 16 workgroups, all waves, steps 1..: wait %.0f | barrier %.0f | first MFMAs %.0f | rest %.0f  = %.0f clocks per step\n",
            sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, (sum[0] + sum[1] + sum[2] + sum[3]) / cnt);

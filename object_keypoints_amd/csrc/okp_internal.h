@@ -152,6 +152,9 @@ struct OkpPatchGeom {          // one patch geometry: a source + the sub-lattice
 };
 struct OkpPatchParams {
   OkpPatchGeom g[OKP_PATCH_MAX_GEOM];
+  int32_t n_geom;
+  uint32_t geom_ph, geom_src;  // per geometry g: patch rows in bits 5 g .. 5 g + 4; source index in bit g (what the in-loop requests need, in two registers)
+  const void* src_data[2]; uint32_t src_bytes[2];
   const void* weights; uint32_t w_bytes; int32_t cout_pad, cout;
   const float* bias;
   const OkpPatchStep* steps; int32_t n_steps;
@@ -162,7 +165,6 @@ struct OkpPatchParams {
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
   int32_t act, n_co_tiles, n_tiles;
-  int32_t* sched;              // dynamic tile order: eight per-XCD tile counters + a count of finished workgroups, all zero between launches (or NULL: static order)
 #ifdef OKP_PATCH_STAMPS
   uint32_t* dbg;
 #endif
@@ -225,4 +227,4 @@ int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_ch
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
-int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream);   // tile 13 / 15
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);

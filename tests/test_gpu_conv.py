@@ -411,7 +411,7 @@ def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
         plan = ops.ConvPlan(dtype, [256, 256], [1, 1], 256, taps, b.numpy(), relu=True)
         srcs = [ops.Act.from_nchw(a.to(dev), dtype), ops.Act.from_nchw(c.to(dev), dtype)]
     outs = {}
-    tiles = (6, 13, 15)
+    tiles = (6, 13)
     for tile in tiles:
         big = ops.Act(torch.full((n, h, w, 288), -7.0, dtype=dtype, device=dev))
         plan(srcs, big.slice(16, 256), h, w, res=res, tile=tile)
@@ -421,7 +421,6 @@ def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
         got = outs[tile][..., 16:272].permute(0, 3, 1, 2)
         assert float((got - ref).abs().max()) <= _tol(dtype, ref), tile
     assert torch.equal(outs[13], outs[6])
-    assert torch.equal(outs[15], outs[6])          # two 4-wave workgroups per CU, one patch buffer each: same K order
 
 @pytest.mark.gpu
 def test_patch_resident_kernel_refuses_other_shapes():
@@ -456,16 +455,15 @@ def test_patch_resident_kernel_transposed_conv_classes(h, w, dtype):
     outs = {}
     keep = bb.UNPOOL_TILE
     try:
-        for tile in (6, 13, 15):
+        for tile in (6, 13):
             bb.UNPOOL_TILE = tile
             outs[tile] = m(la, ua).t.float().cpu()
     finally:
         bb.UNPOOL_TILE = keep
-    for tile in (13, 15):
+    for tile in (13,):
         got = outs[tile].permute(0, 3, 1, 2)
         assert float((got - ref).abs().max()) <= _tol(dtype, ref), tile
     assert torch.equal(outs[13], outs[6])
-    assert torch.equal(outs[15], outs[6])
 
 
 @pytest.mark.parametrize("dtype", HALF)
@@ -500,11 +498,8 @@ def test_patch_resident_kernel_full_size_matches_gather_kernel(case, dtype):
     out13 = ops.Act.empty(n, h, w, 256, dtype, dev)
     plan(srcs, out6, h, w, res=res, tile=6)
     plan(srcs, out13, h, w, res=res, tile=13)
-    out15 = ops.Act.empty(n, h, w, 256, dtype, dev)
-    plan(srcs, out15, h, w, res=res, tile=15)
     torch.cuda.synchronize()
     assert torch.equal(out13.t, out6.t)
-    assert torch.equal(out15.t, out6.t)
     assert bool(torch.isfinite(out13.t.float()).all()) and float(out13.t.float().abs().max()) > 0.5
 
 
