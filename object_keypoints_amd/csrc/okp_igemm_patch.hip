@@ -133,7 +133,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wt + i * 8192), 16, (int)(wbase[i] + wslice), 0, 0, 0);
     };
     // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63
-    bool abl_in_loop = false; (void)abl_in_loop;
     // source offset (first channel) | column key of patch pixel idx of geometry G, or bit 31
     auto patch_pixel = [&](const OkpPatchGeom& G, int idx) -> uint32_t {
       const int i = idx / kPitch, j = idx - i * kPitch;
@@ -170,11 +169,6 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         const bool ok = idx < npx && j < PW && ys >= 0 && ys < H && xs >= 0 && xs < W;
         const uint32_t off = ok ? (uint32_t)((n * H + ys) * W + xs) * (uint32_t)ps2 + c0b + (uint32_t)ch * 16u : kInvalidOff;
         char* const dst = smem + kLdsPatch + buf * kPatchBuf + blk * 1024;
-#if defined(OKP_PATCH_ABL_NODMA)               // timing ablation: all the address arithmetic, no LDS-DMA (the in-loop calls only)
-        if (abl_in_loop) { asm volatile("" :: "v"(off), "v"(dst)); continue; }
-#elif defined(OKP_PATCH_ABL_CHEAPADDR)         // timing ablation: the LDS-DMA with an address that costs nothing (in-loop calls only)
-        if (abl_in_loop) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)dst, 16, (int)(blk * 1024 + lane * 16), 0, 0, 0); continue; }
-#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
       }
     };
@@ -205,10 +199,10 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const uint32_t w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv[3]);
       const int dxo = (w3 >> 8) & 0xff;                            // column offset of this step's tap inside the patch
       const bool more = t + 1 < t1;
-      const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
 #ifdef OKP_PATCH_ABL_NOPATCH                    // timing ablation (wrong results): no patch but the first of a tile is ever requested
-      const bool next_patch_abl = false;
-#define next_patch next_patch_abl
+      const bool next_patch = false; (void)nx_k0; (void)nx_k1; (void)nx_geom; (void)nx_c0b;
+#else
+      const bool next_patch = nx_k1 > nx_k0 && (int)(w3 >> 24) + 1 < t1;   // the next group still belongs to this class
 #endif
 
       // my part of step t's weights (and of its patch) has landed, and my fragment reads of step t-1 have returned (the
