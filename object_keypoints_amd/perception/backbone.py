@@ -29,6 +29,7 @@ import os
 STEM_DIRECT = True       # 16-bit: the stem kernel reads fp32 NCHW frames itself (no pack launch)
 STEM_KERNEL = True       # 16-bit: dedicated stem kernel (okp_stem.hip); False = generic tap-list kernel
 UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
+SQUEEZE_TILE = 0         # tile code of the squeeze launch of a fire module that has no one-launch kernel (0 = heuristic)
 STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
 
 
@@ -297,7 +298,7 @@ class fire_module(_HipModule):
             ops.fire_fused(squeeze, expand, wd, bd, x, out, self.stride, self.skip)
             return out
         s = Act.empty(x.n, x.h, x.w, self.mid, x.dtype, x.t.device)
-        squeeze([x], s, x.h, x.w)
+        squeeze([x], s, x.h, x.w, tile=SQUEEZE_TILE)
         ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
         out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
         # concat is free: both branches write their channel window of the same NHWC tensor, and both run in ONE
