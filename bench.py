@@ -24,7 +24,9 @@ restatement + NumPy post-processing) on the host cores, N=1 only, bounded sample
 collective, heat_err_vs_oracle, depth_err_vs_oracle, peak_jaccard, p_C_err_m, meets}: every north_star tolerance of that
 precision measured on the cpu_baseline's frames against the oracle (parity_fields).  `collective` describes the one
 data-path collective as this run saw it (backend, ranks, payload, median all-gather time).  `roofline.counter_commit` /
-`stale` say which tree the committed PMC counters were collected on.
+`stale` say which tree the committed PMC counters were collected on.  `power` (N=1): board power and shader clock sampled with rocm-smi
+while the step runs back to back AFTER the timed region, and the dominant kernel alone on normally distributed and on all-zero operands
+(the same instructions at different power: the kernel runs at the board's power limit).
 """
 import argparse
 import json
@@ -397,6 +399,8 @@ def run_precision(name, ctx, steps, warmup):
             sample = {k: v.cpu().numpy() for k, v in (("heat", h), ("depth", d), ("count", cnt), ("yx", yx), ("points", pts))}
         coll = collective_probe(out["points"], batch, world, dev, own_group=ctx.get("probe_collective", False) and world == 1)
         power = power_probe(step) if ctx.get("probe_collective", False) and world == 1 else None
+        if power is not None and name in ("bf16", "f16"):
+            power["dominant_kernel_alone"] = operand_probe(dtype, dev)
         ctx["probe_collective"] = False        # (once per run: the headline precision)
     value = batch * world * steps / elapsed
     n_launch, k_ms, k_flops, _ = timer.summary("mfma")
@@ -436,16 +440,18 @@ def run_precision(name, ctx, steps, warmup):
     return res, sample
 
 
-def power_probe(step, seconds=3.0, smi="rocm-smi"):
+def power_probe(step, seconds=3.0, smi="rocm-smi", sync=None):
     """Board power and shader clock while the step runs back to back, sampled with rocm-smi AFTER the timed region (never inside it).
     The dominant 16-bit kernel sits at the board's power limit: the clock it sustains, not the 2.4 GHz the 2.5 PFLOP/s
     peak is quoted at, sets its rate.  Returns None where rocm-smi is missing or prints something else."""
     import re
     import shutil
     import threading
-    import torch
     if shutil.which(smi) is None:
         return None
+    if sync is None:
+        import torch
+        sync = torch.cuda.synchronize
     samples, stop = [], threading.Event()
 
     def sampler():
@@ -462,13 +468,13 @@ def power_probe(step, seconds=3.0, smi="rocm-smi"):
     t0 = time.perf_counter()
     for _ in range(20):
         step()                                   # the clock settles before the first sample
-    torch.cuda.synchronize()
+    sync()
     th.start()
     n = 0
     while time.perf_counter() - t0 < seconds:
         for _ in range(10):
             step()
-        torch.cuda.synchronize()
+        sync()
         n += 10
     stop.set()
     th.join(timeout=15)
@@ -485,6 +491,35 @@ def power_probe(step, seconds=3.0, smi="rocm-smi"):
     watts, mhz = [a for a, _ in samples], [b for _, b in samples]
     return {"board_W_mean": sum(watts) / len(watts), "board_W_max": max(watts), "cap_W": cap, "sclk_MHz_mean": sum(mhz) / len(mhz),
             "sclk_MHz_min": min(mhz), "sclk_MHz_peak_is_quoted_at": 2400, "samples": len(samples), "steps": n, "source": "rocm-smi --showpower --showclocks"}
+
+
+def operand_probe(dtype, dev, n=64, hw=64):
+    """The dominant kernel alone (3x3 256 -> 256 at 64 x 64, the batch of the step) on normally distributed operands and on all-zero ones:
+    the same instructions, the same memory traffic - what differs is the power the matrix pipe draws, and with it the clock the board
+    sustains.  After the timed region; 60 warm-up launches each."""
+    import numpy as np
+    import torch
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    rng = np.random.default_rng(0)
+    wt = (rng.standard_normal((256, 256, 3, 3)) / 48.0).astype(np.float32)
+    out = ops.Act.empty(n, hw, hw, 256, dtype, dev)
+    res = {"kernel": "okp_igemm_patch_kernel, 3x3 256 -> 256 at %d x %d, %d frames" % (hw, hw, n), "gflop": 2.0 * n * hw * hw * 256 * 2304 / 1e9}
+    for key, scale in (("random_operands", 1.0), ("zero_operands", 0.0)):
+        plan = ops.ConvPlan(dtype, [256], [1], 256, conv_taps(wt * scale), np.zeros(256, np.float32), relu=True)
+        x = ops.Act((torch.randn(n, hw, hw, 256, device=dev) * scale).to(dtype))
+        for _ in range(60):
+            plan([x], out, hw, hw, tile=13)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            plan([x], out, hw, hw, tile=13)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        res[key] = {"us_per_launch": us, "TFLOPs": res["gflop"] / us / 1e3}
+        del plan, x
+    return res
 
 
 def run_stream8(ctx, ticks=200, warmup=10):

@@ -445,3 +445,25 @@ def test_compute_mode_is_per_thread_and_parses():
         t.start(); t.join()
     assert seen == [(False, False)] and (ops.F32_SPLIT, ops.F32_MIX) == (False, False)
     assert not ops.f32_split(False, True).mixed                   # mixed implies split
+
+
+def test_bench_power_probe_parses_rocm_smi_and_tolerates_its_absence(tmp_path):
+    """bench.power_probe samples `rocm-smi --showpower --showclocks` next to the running step (after the timed region): it returns the
+    mean board power / shader clock of what the tool printed, and None where the tool is missing or prints something else."""
+    import bench
+    fake = tmp_path / "fake-smi"
+    fake.write_text("#!/bin/sh\n"
+                    "case \"$*\" in\n"
+                    "  *showmaxpower*) echo 'GPU[0]\t\t: Max Graphics Package Power (W): 1400.0';;\n"
+                    "  *) echo 'GPU[0]\t\t: sclk clock level: 3: (2100Mhz)'; echo 'GPU[0]\t\t: Current Socket Graphics Package Power (W): 1210.0';;\n"
+                    "esac\n")
+    fake.chmod(0o755)
+    calls = []
+    got = bench.power_probe(lambda: calls.append(1), seconds=0.5, smi=str(fake), sync=lambda: None)
+    assert got is not None and got["samples"] >= 1 and got["steps"] == len(calls) - 20
+    assert got["board_W_mean"] == 1210.0 and got["sclk_MHz_mean"] == 2100.0 and got["cap_W"] == 1400.0
+    assert bench.power_probe(lambda: None, seconds=0.1, smi=str(tmp_path / "no-such-tool"), sync=lambda: None) is None
+    silent = tmp_path / "silent-smi"
+    silent.write_text("#!/bin/sh\necho nothing useful\n")
+    silent.chmod(0o755)
+    assert bench.power_probe(lambda: None, seconds=0.2, smi=str(silent), sync=lambda: None) is None
