@@ -517,7 +517,7 @@ def operand_probe(dtype, dev, n=64, hw=64):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        res[key] = {"us_per_launch": us, "TFLOPs": res["gflop"] / us / 1e3}
+        res[key] = {"us_per_launch": us, "TFLOPs": res["gflop"] / us * 1e3}
         del plan, x
     return res
 
