@@ -361,7 +361,7 @@ def test_framed_fire_chain_matches_module_by_module(h, w, n, count, dtype):
     assert float((got - single).abs().max()) <= eps * (0.02 * scale * depth + 0.02)
 
 
-@pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile", "conv3x3_s2", "conv3x3_s2_odd_input"])
+@pytest.mark.parametrize("case", ["conv3x3", "conv3x3_res_window", "conv3x3_src_window", "residual_s2_skip", "two_chunks", "merge_1x1", "one_tile", "conv3x3_s2", "conv3x3_s2_odd_input"])
 @pytest.mark.parametrize("dtype", HALF)
 def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
     """Tile 13 (okp_igemm_patch: input patch + halo resident in LDS) against torch AND bit-for-bit against tile 6 (same
@@ -372,13 +372,18 @@ def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
     dev = _dev()
     rb = lambda v: _q(v, dtype)
     res = None
-    if case in ("conv3x3", "conv3x3_res_window", "two_chunks", "one_tile"):
+    if case in ("conv3x3", "conv3x3_res_window", "conv3x3_src_window", "two_chunks", "one_tile"):
         n, h, w = (1, 16, 16) if case == "one_tile" else (3, 32, 48)
         cin = 128 if case == "two_chunks" else 256
         x = rb(_rand((n, cin, h, w), 21)); wt = rb(_rand((256, cin, 3, 3), 22) / np.sqrt(cin * 9)); b = _rand((256,), 23) * 0.1
         ref = F.conv2d(x, wt, b, padding=1)
         plan = ops.ConvPlan(dtype, [cin], [1], 256, conv_taps(wt.numpy()), b.numpy(), relu=True)
         srcs = [ops.Act.from_nchw(x.to(dev), dtype)]
+        if case == "conv3x3_src_window":
+            # the source is a 256-channel window of a 320-channel tensor (pixel stride 640 bytes, base 64 bytes in): the per-tile offset
+            # table of the patch pixels (okp_igemm_patch.hip) is built from the view's stride and base
+            wide = torch.cat([rb(_rand((n, 32, h, w), 44)), x, rb(_rand((n, 32, h, w), 45))], dim=1)
+            srcs = [ops.Act.from_nchw(wide.to(dev), dtype).slice(32, 256)]
         if case == "conv3x3_res_window":
             r = rb(_rand((n, 320, h, w), 24))
             ref = ref + r[:, 32:288]
