@@ -5,7 +5,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "object_keypoints
 form = [] if src.endswith("_w4.hip") else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950"] + form + [
        "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "object_keypoints_amd/csrc"), "-c", src, "-o", "/tmp/_kres.o",
-       "-Rpass-analysis=kernel-resource-usage"]
+       "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("OKP_EXTRA_CFLAGS", "").split()      # (the build's experiment switches)
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
