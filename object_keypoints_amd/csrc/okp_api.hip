@@ -127,11 +127,13 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
   // a single tap: 16x16 with the conv stride as pixel step); a strided multi-tap source is split into the residue classes
   // of (dy, dx) modulo the stride - a stride-2 3x3 reads four interleaved sub-lattices of 17x17, 17x16, 16x17 and 16x16.
   int tap_geom[OKP_MAX_TAPS] = {0}, tap_ty[OKP_MAX_TAPS] = {0}, tap_tx[OKP_MAX_TAPS] = {0};
-  bool patch_ok = okp_is16(dtype) && plan->cout_pad % 256 == 0;
+  // (16-bit plans: chunks of 64 channels; split-product plans, okp_igemm_patch_x3.hip: 32 fp32 channels - KE either way - and no
+  //  single-term taps, which would split the K order in two ranges)
+  bool patch_ok = (okp_is16(dtype) || (dtype == OKP_F32X3 && !tap_terms)) && plan->cout_pad % 256 == 0;
   plan->patch_n_geom = 0;
   for (int sidx = 0; sidx < n_src && patch_ok; ++sidx) {
     const int cs = conv_stride[sidx];
-    if (cin[sidx] % 64) { patch_ok = false; break; }
+    if (cin[sidx] % KE) { patch_ok = false; break; }
     bool single = true; int first = -1;
     for (int t = 0; t < n_taps; ++t) if (taps[t].src == sidx) {
       if (first < 0) first = t;
@@ -213,17 +215,18 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
       }
     }
   }
-  // ---- step table of the patch-resident kernel (bf16, 256-channel tiles; okp_igemm_patch.hip) -----------------
-  // Eligible when every slice is 64 channels of ONE tap: the 16x16-pixel tile's input patch of a 64-channel chunk and
-  // geometry is loaded once and serves all its taps (consecutive K-steps).
+  // ---- step table of the patch-resident kernels (256-channel tiles; okp_igemm_patch.hip, okp_igemm_patch_x3.hip) -----------------
+  // Eligible when every slice is one whole chunk (64 16-bit / 32 fp32 channels) of ONE tap: the 16x16-pixel tile's input patch of a
+  // chunk and geometry is loaded once and serves all its taps (consecutive K-steps).
   std::vector<OkpPatchStep> psteps;
   {
-    bool ok = patch_ok && plan->n_slices <= 256 && cin[0] <= 255 * 64 && (n_src < 2 || cin[1] <= 255 * 64);
+    const bool x3 = dtype == OKP_F32X3;
+    bool ok = patch_ok && plan->n_slices <= 256 && cin[0] <= 255 * KE && (n_src < 2 || cin[1] <= 255 * KE);
     struct Group { int geom, c0, first, n; };
     std::vector<Group> groups;
     for (int si = 0; si < plan->n_slices && ok; ++si) {
       const OkpSlice& sl = slices[si];
-      if (sl.tap_lo != sl.tap_hi || sl.nvalid != 8 || sl.c0_hi != sl.c0_lo + 32 || sl.c0_lo % 64) { ok = false; break; }
+      if (sl.tap_lo != sl.tap_hi || sl.nvalid != 8 || sl.c0_hi != sl.c0_lo + KE / 2 || sl.c0_lo % KE || sl.pad) { ok = false; break; }
       const int g = tap_geom[sl.tap_lo];
       if (groups.empty() || groups.back().geom != g || groups.back().c0 != sl.c0_lo) groups.push_back({g, sl.c0_lo, si, 0});
       ++groups.back().n;
@@ -235,19 +238,27 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
         const Group& G = groups[gi];
         const bool has_next = gi + 1 < groups.size();
         const int np = has_next ? passes(groups[gi + 1].geom) : 0;
-        const int per = (np + G.n - 1) / G.n;
+        // split-product plans: the next patch lands as fp32 and is split in place during this group's LAST step, so its requests go
+        // into steps 0 .. n-2; behind a one-step group (and at the first step of a tile) the patch is split at the start of its own
+        // first step instead (OKP_PSTEP_CVT_*, okp_igemm_patch_x3.hip)
+        const int req_steps = (x3 && G.n >= 2) ? G.n - 1 : G.n;
+        const int per = (np + req_steps - 1) / req_steps;
+        const bool self = x3 && (gi == 0 || groups[gi - 1].n < 2);
         for (int i = 0; i < G.n; ++i) {
           const OkpSlice& sl = slices[G.first + i];
           OkpPatchStep st{};
           st.tap_bytes = (uint32_t)((tap_ty[sl.tap_lo] * 18 + tap_tx[sl.tap_lo]) * 128);
           st.tx = (uint8_t)tap_tx[sl.tap_lo];
-          st.c0q = (uint8_t)(G.c0 / 64);
+          st.c0q = (uint8_t)(G.c0 / KE);
           st.grp_last = (uint8_t)(G.first + G.n - 1);
           st.pbuf = (uint8_t)(gi & 1);
+          if (self && i == 0) st.pbuf |= OKP_PSTEP_CVT_SELF;
+          if (x3 && has_next && G.n >= 2 && i == G.n - 1) st.pbuf |= OKP_PSTEP_CVT_NEXT;
           st.geom = (uint8_t)G.geom;
           st.nx_k0 = (uint8_t)std::min(np, i * per); st.nx_k1 = (uint8_t)std::min(np, (i + 1) * per);
+          if (i >= req_steps) st.nx_k0 = st.nx_k1 = 0;
           st.nx_geom = (uint8_t)(has_next ? groups[gi + 1].geom : 0);
-          st.nx_c0b = (uint32_t)(has_next ? groups[gi + 1].c0 * 2 : 0);
+          st.nx_c0b = (uint32_t)(has_next ? groups[gi + 1].c0 * esz : 0);
           psteps[G.first + i] = st;
         }
       }
@@ -485,9 +496,11 @@ static int select_tile(const okp_conv* plan, const okp_conv_args* a) {
   const bool dense1 = ncls == 1 && a->out_step == 1 && a->out_oy == 0 && a->out_ox == 0 && a->out.h == a->ho && a->out.w == a->wo;
   const long patch_tiles = (long)ncls * a->n * (a->ho / 16) * (a->wo / 16) * (plan->cout_pad / 256);
   if (patch_on && plan->patch_steps_dev && plan->n_taps > plan->patch_n_geom && !a->dw_w_dev && a->ho % 16 == 0 && a->wo % 16 == 0 &&
-      ((tile == 6 && dense1) || (ncls == 4 && patch_tiles >= 256))) {
+      (((tile == 6 || (tile == 3 && plan->dtype == OKP_F32X3)) && dense1) || (ncls == 4 && patch_tiles >= 256))) {
     bool ok = true;
-    for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s];
+    for (int s = 0; s < plan->n_src; ++s) ok = ok && a->src[s].pix_stride >= plan->cin[s] && (a->src[s].pix_stride * okp_esz(plan->dtype)) % 8 == 0;
+    // (split-product plans: the fp16 side output / fp16 residual / subsampled output of the mixed configuration stay with the gather tiles)
+    if (plan->dtype == OKP_F32X3 && (a->out16.data || a->res_is_f16 || a->out_subsample == 2 || !a->out.data || plan->n_single_slices)) ok = false;
     if (ok) return 13;
   }
   return tile;

@@ -69,6 +69,7 @@ constexpr int kLdsStamps = kLdsGeo + OKP_PATCH_MAX_GEOM * kGeoEntries * 4;
 constexpr int kLdsTotal = kLdsStamps + kStampBytes;
 static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16-byte vector");
 static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
+static_assert(kLdsTotal <= 160 * 1024, "one workgroup's LDS is at most the CU's 160 KiB");
 
 template <typename T>
 __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
@@ -376,20 +377,24 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 }  // namespace
 
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p) {
-  if (!plan->patch_steps_dev || !okp_is16(plan->dtype)) return false;
+  const bool x3 = plan->dtype == OKP_F32X3;
+  if (!plan->patch_steps_dev || !(okp_is16(plan->dtype) || x3)) return false;
   if ((p.n_classes != 1 && p.n_classes != 4) || p.dw_w) return false;     // (okp_conv_forward has checked that the output grid fits)
   if (p.Ho % 16 || p.Wo % 16) return false;
+  // split-product plans: the fp16 side output, the fp16 residual and the subsampled fp32 output stay with the gather tiles
+  if (x3 && (p.out16 || p.res16 || p.out_sub2 || !p.out || plan->n_single_slices)) return false;
   for (int s = 0; s < plan->n_src; ++s) {
     // the patch of output block (y0, x0) starts at conv_stride * (y0, x0) + (oy, ox) in the source: the source must be
     // the map the stride implies, or the zero padding at its lower/right edge would differ from the gather kernel's
     if (p.src_pix_stride[s] < plan->cin[s]) return false;
+    // a table entry is (byte offset of the pixel | 3-bit column key): pixels must start on 8-byte boundaries
+    if ((p.src_pix_stride[s] * okp_esz(plan->dtype)) % 8) return false;
   }
   return true;
 }
 
-int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStream_t stream) {
-  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
-  OkpPatchParams p;
+// OkpIgemmParams of a launch -> the patch kernels' parameter block (both element types)
+int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatchParams& p) {
   std::memset(&p, 0, sizeof(p));
   for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
     const int ss = plan->patch_src[gi];
@@ -401,12 +406,15 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   p.n_geom = plan->patch_n_geom;
   for (int gi = 0; gi < plan->patch_n_geom; ++gi) {
     const int ss = plan->patch_src[gi];
+    // geom_src holds one bit per geometry (sources 0 / 1), geom_ph five (<= 18 rows); bit 31 of a table entry is the
+    // "outside" flag, which views below 2 GiB (check_view) leave free
+    if (ss < 0 || ss > 1 || plan->patch_PH[gi] > 18 || q.src_bytes[ss] >= 0x80000000u) { okp_set_error("okp_conv_forward: patch geometry %d outside what the in-loop tables encode", gi); return OKP_EINVAL; }
     p.geom_ph |= (uint32_t)plan->patch_PH[gi] << (5 * gi);
     p.geom_src |= (uint32_t)ss << gi;
     p.src_data[ss] = q.src[ss]; p.src_bytes[ss] = q.src_bytes[ss];
   }
   if (!p.src_data[1]) { p.src_data[1] = p.src_data[0]; p.src_bytes[1] = p.src_bytes[0]; }
-  p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias;
+  p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias; p.oscale = q.oscale;
   p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
   p.n_classes = q.n_classes; p.steps_per_class = plan->n_slices / q.n_classes;
   p.OH = q.OH; p.OW = q.OW; p.out_step = q.out_step; p.out_oy = q.out_oy; p.out_ox = q.out_ox;
@@ -417,6 +425,14 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   p.n_co_tiles = q.cout_pad / 256;
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;
+  return OKP_OK;
+}
+
+int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStream_t stream) {
+  if (!okp_patch_supported(plan, q)) { okp_set_error("okp_conv_forward: tile 13 (patch-resident kernel) does not apply to this plan / problem"); return OKP_EINVAL; }
+  OkpPatchParams p;
+  if (int e = okp_fill_patch_params(plan, q, p)) return e;
+  if (plan->dtype == OKP_F32X3) return okp_launch_igemm_patch_x3(plan, p, stream);
 #ifdef OKP_PATCH_STAMPS
   static uint32_t* dbg = nullptr;
   if (!dbg) (void)hipMalloc((void**)&dbg, 16 * kStampBytes);

@@ -138,11 +138,15 @@ struct OkpIgemmParams {
 struct OkpPatchStep {          // 16 bytes, built at plan creation
   uint32_t tap_bytes;          // byte offset of this step's tap inside the patch: ((dy - oy) * 18 + (dx - ox)) * 128 (row pitch 18 px)
   uint32_t nx_c0b;             // channel byte offset of the NEXT group's patch (prefetched during this group's steps)
-  uint8_t pbuf, nx_k0, nx_k1, nx_geom;  // patch buffer of this step; passes [k0, k1) of the next patch (geometry nx_geom) issued in this step
+  uint8_t pbuf, nx_k0, nx_k1, nx_geom;  // patch buffer of this step (bit 0; split-product plans: OKP_PSTEP_CVT_* in bits 1-2); passes [k0, k1) of the next patch (geometry nx_geom) issued in this step
   uint8_t geom, tx, c0q, grp_last;   // geometry of this step's patch; tx = patch column offset of the tap (the fragment swizzle is keyed on
                                // the column); c0q = first channel / 64 of the step's chunk; grp_last = last step of its (chunk, geometry) group
 };
+// Split-product plans (okp_igemm_patch_x3.hip): a patch arrives in LDS as fp32 and is split ONCE, in place, into fp16 hi | lo pairs.
+#define OKP_PSTEP_CVT_SELF 2u  // this step's patch finished landing in the previous step (or the tile's prologue): split it now, then a second barrier
+#define OKP_PSTEP_CVT_NEXT 4u  // last step of a group of >= 2 steps: the next group's patch has landed (requested in steps 0 .. n-2), split it during this step
 #define OKP_PATCH_MAX_GEOM 6
+static_assert(OKP_PATCH_MAX_GEOM * 5 <= 32, "OkpPatchParams.geom_ph packs 5 bits per geometry into one u32");
 struct OkpPatchGeom {          // one patch geometry: a source + the sub-lattice / window its taps read (a stride-2 3x3 has four: the parity classes)
   const void* data; uint32_t bytes;
   int32_t H, W, pix_stride;
@@ -157,6 +161,7 @@ struct OkpPatchParams {
   const void* src_data[2]; uint32_t src_bytes[2];
   const void* weights; uint32_t w_bytes; int32_t cout_pad, cout;
   const float* bias;
+  const float* oscale;         // OKP_F32X3 plans: per-output-channel factor of the accumulator (1 / the power of two its weights were scaled with)
   const OkpPatchStep* steps; int32_t n_steps;
   int32_t N, H, W, tiles_y, tiles_x;            // H x W = GEMM pixel grid (Ho x Wo)
   int32_t n_classes, steps_per_class, tiles_per_class;   // sub-pixel classes of a transposed convolution (1 otherwise)
@@ -228,3 +233,5 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
 int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
+int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatchParams& p);             // okp_igemm_patch.hip (shared by both patch kernels)
+int okp_launch_igemm_patch_x3(const okp_conv* plan, const OkpPatchParams& p, hipStream_t stream);      // okp_igemm_patch_x3.hip
