@@ -42,7 +42,8 @@ def _frames(n, seed=77):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, "float32x3", "float32mix"])
 def test_batch64_frame_independence_and_side_stream_determinism(dtype):
     """(a) two eager runs of the 64-frame step with the side streams on are bit-equal; (b) a frame gives the same bits
-    wherever it sits in the batch (the batch reversed); (c) frames 0, 17, 63 give the bits they give when run alone."""
+    wherever it sits in the batch (the batch reversed); (c) frames 0, 17, 63 give the bits they give when run alone (split-product
+    configurations: the values, to summation noise)."""
     from object_keypoints_amd import ops
     net = _net(dtype)
     x = _frames(64)                     # (the fp32-storage configurations run it as two passes of 32 frames: the 2 GiB view limit)
@@ -56,10 +57,20 @@ def test_batch64_frame_independence_and_side_stream_determinism(dtype):
         r = net.deployed(torch.flip(x, dims=[0]).contiguous())
         for u, v in zip(a, r):
             assert torch.equal(u, torch.flip(v, dims=[0]))            # (b)
+        # (c) 16-bit configurations: every tile of a plan sums in the same order, so a frame's bits do not depend on the batch size.
+        # Split-product configurations: the patch-resident kernel (16x16x32 MFMAs; the heuristic's choice at batch 64) and the gather
+        # tiles (32x32x16; batch 1) add the same products in another order - the same frame agrees to summation noise, not bit for bit
+        # (float32mix: that noise passes through fp16 rounding points, where 1e-6 upstream flips a rounding: its own measured frame-to-model
+        #  scatter, tests/precision/bounds.py, is the scale)
+        split = isinstance(dtype, str)
+        tol = 5e-4 if dtype == "float32mix" else 2e-5
         for i in (0, 17, 63):
             s = net.deployed(x[i:i + 1])
             for u, v in zip(a, s):
-                assert torch.equal(u[i:i + 1], v), f"frame {i} differs between batch 64 and batch 1"    # (c)
+                if split:
+                    assert float((u[i:i + 1] - v).abs().max()) <= tol * (1.0 + float(v.abs().max())), f"frame {i} differs between batch 64 and batch 1"
+                else:
+                    assert torch.equal(u[i:i + 1], v), f"frame {i} differs between batch 64 and batch 1"
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
