@@ -21,6 +21,8 @@
 //    channels of the same pixel: bias is the accumulator's initial value, ReLU and the bf16 rounding happen in
 //    registers, the pair is one dword and a half-wave's store is 128 contiguous bytes of one NHWC pixel (whole
 //    64-byte lines, two pixels per instruction) - no transposition through LDS.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -44,7 +46,8 @@ struct StemParams {
   uint32_t src_bytes;
   int32_t Hp, Wp, H, W;
   const void* wfrag;        // [wc 2][block 2][k-step 14][lane 64][16 B]  B-operand fragments
-  const float* bias;        // [128], natural channel order
+  const float* bias;        // [128], natural channel order (split-product plan: already multiplied with the channel's weight scale)
+  const float* oscale;      // split-product plan: [128] 1 / (power of two the channel's weights were multiplied with)
   void* out;
   uint32_t out_bytes;
   int32_t N, Ho, Wo, out_pix_stride;
@@ -210,20 +213,196 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
   }
 }
 
+// ---- split-product form (OKP_F32X3): fp32 NHWC output, every product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the fp16 matrix pipe ----
+// The generic tap-list kernel ran this layer of the float32x3 configuration at 2.1 TB/s of its output bytes (510 us per 32 frames:
+// seven K-slices between a prologue and an LDS-transposed epilogue).  Same structure as the 16-bit kernel above, with three changes:
+//  * the patch is kept in LDS as TWO planes in the 16-bit kernel's layout - fp16(x) and fp16(x - fp16(x)) - written by the threads that
+//    fetched the fp32 NCHW pixels (the split happens once per patch pixel, not per tap);
+//  * a wave owns 32 output channels (one column block) and all eight rows of the tile: its weight fragments, hi and lo, fill the 112
+//    registers the 16-bit kernel spends on 64 channels x hi only;
+//  * the accumulators start at bias x scale and are multiplied by 1 / scale at the end (the per-channel power of two that keeps the
+//    low halves of small weights normal numbers: okp_conv_create does the same for split-product convolution plans); a half-wave's
+//    store is 128 contiguous bytes (32 channels) of one fp32 NHWC pixel.
+__global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * PATCH_BYTES];      // [buffer][hi plane | lo plane]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+  u32x4 wh[KSTEPS], wl[KSTEPS];              // B-operand fragments of this wave's 32 channels: [wave][hi | lo][k-step][lane]
+  {
+    const u32x4* wf = reinterpret_cast<const u32x4*>(p.wfrag) + (size_t)wave * 2 * KSTEPS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) { wh[s] = wf[s * 64]; wl[s] = wf[(KSTEPS + s) * 64]; }
+  }
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const uint32_t ps4 = (uint32_t)p.out_pix_stride * 4u;                       // bytes per output pixel
+  const uint32_t st_lane = (uint32_t)(4 * h) * ps4 + (uint32_t)(32 * wave + j) * 4u;
+  const float bias0 = p.bias[32 * wave + j], osc = p.oscale[32 * wave + j];
+
+  auto tile_coords = [&](int tile, int& n, int& oy0, int& ox0) {
+    n = fastdiv(tile, p.div_tiles_frame);
+    const int r = tile - n * p.tiles_x * p.tiles_y;
+    const int ty = fastdiv(r, p.div_tiles_x);
+    oy0 = ty * TH;
+    ox0 = (r - ty * p.tiles_x) * TW;
+  };
+  constexpr int PPT = (PR * PC + 255) / 256;                // 6 patch pixels per thread
+  float pv[PPT][3];
+  auto load_patch = [&](int tile) {
+    int n, oy0, ox0;
+    tile_coords(tile, n, oy0, ox0);
+    const uint32_t plane = (uint32_t)p.H * (uint32_t)p.W * 4u;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / PC, col = idx - row * PC;
+      const int y = 2 * oy0 - 3 + row, x = 2 * ox0 - 3 + col;
+      const bool ok = idx < PR * PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const uint32_t off = ((uint32_t)(n * 3) * (uint32_t)p.H + (uint32_t)y) * (uint32_t)p.W * 4u + (uint32_t)x * 4u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(ok ? off + (uint32_t)c * plane : kInvalidOff), 0, 0));
+    }
+  };
+  auto store_patch = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < PATCH_BYTES / 8) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { hi[c] = (_Float16)pv[i][c]; lo[c] = (_Float16)(pv[i][c] - (float)hi[c]); }
+        hi[3] = (_Float16)0.f; lo[3] = (_Float16)0.f;
+        *reinterpret_cast<f16x4*>(smem + (2 * buf) * PATCH_BYTES + idx * 8) = hi;
+        *reinterpret_cast<f16x4*>(smem + (2 * buf + 1) * PATCH_BYTES + idx * 8) = lo;
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.n_tiles) return;
+  load_patch(tile);
+  store_patch(0);
+  __syncthreads();
+
+  int buf = 0;
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < p.n_tiles) load_patch(next);
+    int n, oy0, ox0;
+    tile_coords(tile, n, oy0, ox0);
+    const char* const patch = smem + (2 * buf) * PATCH_BYTES;
+    const int lane_off = (2 * j + 2 * h) * 8;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {                 // four groups of two output rows
+      f32x16 acc[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[0][e] = bias0; acc[1][e] = bias0; }
+      const int ry0 = 2 * g;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int ky = s >> 1, kx0 = 4 * (s & 1);
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const char* a = patch + (2 * (ry0 + r) + ky) * PITCH + kx0 * 8 + lane_off;
+          ph[r] = *reinterpret_cast<const u32x4*>(a);
+          pl[r] = *reinterpret_cast<const u32x4*>(a + PATCH_BYTES);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = H16<_Float16>::mfma32(pl[r], wh[s], acc[r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = H16<_Float16>::mfma32(ph[r], wl[s], acc[r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = H16<_Float16>::mfma32(ph[r], wh[s], acc[r]);
+      }
+      if (g == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next patch's pixels have arrived, older stores have drained
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + ry0 + r;
+        if (oy < p.Ho) {
+          const uint32_t row_off = (uint32_t)(((long)n * p.Ho + oy) * p.Wo + ox0) * ps4;       // scalar
+          const bool full = ox0 + TW <= p.Wo;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
+            const float v = fmaxf(acc[r][e] * osc, 0.f);
+            if (full || ox0 + i0 + 4 * h < p.Wo)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps4), 0);
+          }
+        }
+      }
+    }
+    if (next < p.n_tiles) store_patch(buf ^ 1);
+    __syncthreads();            // every thread's part of the next patch is in LDS; this patch is free
+    buf ^= 1;
+  }
+}
+
 }  // namespace
+
+static okp_stem* stem_create_x3(const float* w, const float* bias);
 
 struct okp_stem {
   void* wfrag_dev;
   float* bias_dev;
   int dtype;
+  float* oscale_dev;        // OKP_F32X3 only
 };
+
+
+// Split-product plan: fragments [wave 4][hi | lo][k-step 14][lane 64][8 fp16], column jc of wave w = channel 32 w + jc; a channel's
+// weights are multiplied by the power of two that puts the largest of them in [256, 512) before the split (its low halves are then
+// normal fp16 numbers down to 2^-12 of it), the bias by the same factor, and the kernel multiplies the accumulator by its inverse.
+static okp_stem* stem_create_x3(const float* w, const float* bias) {
+  std::vector<uint16_t> frag((size_t)4 * 2 * KSTEPS * 64 * 8, 0);
+  std::vector<float> bias_s(kCout), osc(kCout, 1.f);
+  for (int co = 0; co < kCout; ++co) {
+    float mx = 0.f;
+    for (int i = 0; i < 147; ++i) mx = std::max(mx, std::fabs(w[co * 147 + i]));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); sc = std::ldexp(1.f, 9 - e); }
+    osc[co] = 1.f / sc;
+    bias_s[co] = bias[co] * sc;
+    const int wv = co / 32, jc = co % 32;
+    for (int s = 0; s < KSTEPS; ++s)
+      for (int h = 0; h < 2; ++h) {
+        const int ky = s >> 1, kx0 = 4 * (s & 1), lane = jc + 32 * h;
+        uint16_t* dh = &frag[((((size_t)wv * 2 + 0) * KSTEPS + s) * 64 + lane) * 8];
+        uint16_t* dl = &frag[((((size_t)wv * 2 + 1) * KSTEPS + s) * 64 + lane) * 8];
+        for (int e = 0; e < 8; ++e) {
+          const int kx = kx0 + 2 * h + e / 4, c = e % 4;
+          if (kx < 7 && c < 3) {
+            const float v = w[((co * 3 + c) * 7 + ky) * 7 + kx] * sc;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            std::memcpy(&dh[e], &hi, 2); std::memcpy(&dl[e], &lo, 2);
+          }
+        }
+      }
+  }
+  okp_stem* st = new okp_stem{nullptr, nullptr, OKP_F32X3, nullptr};
+  if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
+      okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
+      okp_check_hip(hipMalloc((void**)&st->oscale_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
+      okp_check_hip(hipMemcpy(st->wfrag_dev, frag.data(), frag.size() * 2, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
+      okp_check_hip(hipMemcpy(st->bias_dev, bias_s.data(), kCout * 4, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
+      okp_check_hip(hipMemcpy(st->oscale_dev, osc.data(), kCout * 4, hipMemcpyHostToDevice), "okp_stem_create: copy")) {
+    okp_stem_destroy(st);
+    return nullptr;
+  }
+  return st;
+}
 
 // w: HOST fp32 [128][3][7][7] (BatchNorm folded), bias: HOST fp32 [128]
 extern "C" okp_stem* okp_stem_create(const float* w, const float* bias) { return okp_stem_create_dtype(OKP_BF16, w, bias); }
 
 extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const float* bias) {
   if (!w || !bias) { okp_set_error("okp_stem_create: null argument"); return nullptr; }
-  if (!okp_is16(dtype)) { okp_set_error("okp_stem_create: the stem kernel computes in bf16 or fp16 (dtype %d)", dtype); return nullptr; }
+  if (dtype == OKP_F32X3) return stem_create_x3(w, bias);
+  if (!okp_is16(dtype)) { okp_set_error("okp_stem_create: the stem kernel computes in bf16, fp16 or split products (dtype %d)", dtype); return nullptr; }
   std::vector<uint16_t> frag((size_t)2 * 2 * KSTEPS * 64 * 8, 0);
   for (int wc = 0; wc < 2; ++wc)
     for (int b = 0; b < 2; ++b)
@@ -238,7 +417,7 @@ extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const floa
             dst[e] = (kx < 7 && c < 3) ? okp_f32_to_16(dtype, w[((co * 3 + c) * 7 + ky) * 7 + kx]) : 0;
           }
         }
-  okp_stem* st = new okp_stem{nullptr, nullptr, dtype};
+  okp_stem* st = new okp_stem{nullptr, nullptr, dtype, nullptr};
   if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMemcpy(st->wfrag_dev, frag.data(), frag.size() * 2, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
@@ -253,14 +432,16 @@ extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const floa
 
 extern "C" void okp_stem_destroy(okp_stem* st) {
   if (!st) return;
-  (void)hipFree(st->wfrag_dev);
-  (void)hipFree(st->bias_dev);
+  if (st->wfrag_dev) (void)hipFree(st->wfrag_dev);
+  if (st->bias_dev) (void)hipFree(st->bias_dev);
+  if (st->oscale_dev) (void)hipFree(st->oscale_dev);
   delete st;
 }
 
 extern "C" int okp_stem_forward(const okp_stem* st, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream) {
   if (!st || !packed || !out || !packed->data || !out->data) { okp_set_error("okp_stem_forward: null argument"); return OKP_EINVAL; }
   if (n < 1 || h < 1 || w < 1) { okp_set_error("okp_stem_forward: empty problem"); return OKP_EINVAL; }
+  if (st->dtype == OKP_F32X3) { okp_set_error("okp_stem_forward: the split-product stem reads fp32 NCHW frames (okp_stem_forward_nchw); packed frames go through okp_conv_forward"); return OKP_EINVAL; }
   const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
   if (packed->pix_stride != 4 || packed->h != h + 6 || packed->w < 2 * (wo - 1) + 8 || packed->w < w + 6 || packed->w % 2 ||
       ((uintptr_t)packed->data) % 16) {
@@ -297,15 +478,16 @@ extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, i
   const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
   const int64_t src_bytes = (int64_t)n * 3 * h * w * 4;
   if (src_bytes >= 0x7FFF0000ll || out->bytes <= 0 || out->bytes >= 0x7FFF0000ll) { okp_set_error("okp_stem_forward_nchw: views must be < 2 GiB (sub-batch the frames)"); return OKP_EINVAL; }
-  if (out->h != ho || out->w != wo || out->pix_stride < kCout || (out->pix_stride * 2) % 64 || ((uintptr_t)out->data) % 64 || ((uintptr_t)frames_nchw_dev) % 4) {
+  const int esz = st->dtype == OKP_F32X3 ? 4 : 2;          // the split-product plan writes fp32 NHWC
+  if (out->h != ho || out->w != wo || out->pix_stride < kCout || (out->pix_stride * esz) % 64 || ((uintptr_t)out->data) % 64 || ((uintptr_t)frames_nchw_dev) % 4) {
     okp_set_error("okp_stem_forward_nchw: out must be %dx%d with 64-byte aligned pixels of >= 128 channels", ho, wo);
     return OKP_EINVAL;
   }
-  if ((int64_t)n * ho * wo * out->pix_stride * 2 > out->bytes + (int64_t)(out->pix_stride - kCout) * 2) { okp_set_error("okp_stem_forward_nchw: out view too small"); return OKP_EINVAL; }
+  if ((int64_t)n * ho * wo * out->pix_stride * esz > out->bytes + (int64_t)(out->pix_stride - kCout) * esz) { okp_set_error("okp_stem_forward_nchw: out view too small"); return OKP_EINVAL; }
   StemParams p;
   std::memset(&p, 0, sizeof(p));
   p.src = frames_nchw_dev; p.src_bytes = (uint32_t)src_bytes; p.H = h; p.W = w;
-  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev;
+  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev; p.oscale = st->oscale_dev;
   p.out = out->data; p.out_bytes = (uint32_t)out->bytes; p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
   p.tiles_x = (wo + TW - 1) / TW; p.tiles_y = (ho + TH - 1) / TH;
   const long tiles = (long)n * p.tiles_x * p.tiles_y;
@@ -315,7 +497,8 @@ extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, i
   p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   const int resident = 256 * 2;
   const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  if (st->dtype == OKP_BF16) hipLaunchKernelGGL((okp_stem_kernel<__bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (st->dtype == OKP_F32X3) hipLaunchKernelGGL(okp_stem_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else if (st->dtype == OKP_BF16) hipLaunchKernelGGL((okp_stem_kernel<__bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((okp_stem_kernel<_Float16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
 }

@@ -460,18 +460,21 @@ def pack_frames(frames, dtype):
 
 
 class StemPlan:
-    """The 16-bit (bf16 / fp16) 7x7/s2 stem (okp_stem_*): w [128,3,7,7] and bias [128] with BatchNorm folded (host fp32)."""
+    """The 7x7/s2 stem kernels (okp_stem_*): w [128,3,7,7] and bias [128] with BatchNorm folded (host fp32).  dtype bfloat16 / float16:
+    the 16-bit kernel; float32 inside ops.f32_split(): the split-product kernel (fp32 NHWC output, three-term products; it reads the
+    caller's fp32 NCHW frames: from_nchw only)."""
 
     def __init__(self, w, bias, dtype=torch.bfloat16):
         w = np.ascontiguousarray(w, dtype=np.float32)
         b = np.ascontiguousarray(bias, dtype=np.float32)
         if w.shape != (128, 3, 7, 7) or b.shape != (128,):
             raise OkpError("the stem kernel is 7x7, 3 -> 128 channels")
-        if dtype not in HALF_DTYPES:
-            raise OkpError("the stem kernel computes in bfloat16 or float16")
+        self.split = bool(dtype == torch.float32 and getattr(_MODE, "split", False))
+        if dtype not in HALF_DTYPES and not self.split:
+            raise OkpError("the stem kernel computes in bfloat16, float16 or (float32 inside ops.f32_split()) split products")
         self.dtype = dtype
         L = _lib.lib()
-        self._h = L.okp_stem_create_dtype(okp_dtype(dtype), w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        self._h = L.okp_stem_create_dtype(OKP_F32X3 if self.split else okp_dtype(dtype), w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         if not self._h:
             raise OkpError("okp_stem_create: " + L.okp_last_error().decode())
 
@@ -487,7 +490,7 @@ class StemPlan:
         """frames: fp32 NCHW [N,3,H,W] on the device (the reference's input layout); no packing pass."""
         require_cuda(frames, "frames")
         if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3 or out.dtype != self.dtype:
-            raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's 16-bit type")
+            raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's element type")
         frames = frames.contiguous()
         n, _, h, w = frames.shape
         T = _lib.torch_ops()
@@ -500,8 +503,8 @@ class StemPlan:
         COUNTERS["launches"] += 1
 
     def __call__(self, packed, out):
-        if packed.orig_hw is None or packed.dtype != self.dtype or out.dtype != self.dtype:
-            raise OkpError("stem input must be the output of ops.pack_frames in the plan's 16-bit type")
+        if packed.orig_hw is None or packed.dtype != self.dtype or out.dtype != self.dtype or self.split:
+            raise OkpError("stem input must be the output of ops.pack_frames in the plan's 16-bit type (the split-product stem reads NCHW frames: from_nchw)")
         h, w = packed.orig_hw
         pv, ov = packed.view(), out.view()
         _lib.check(_lib.lib().okp_stem_forward(self._h, packed.n, h, w, ctypes.byref(pv), ctypes.byref(ov), stream_handle()), "okp_stem_forward")

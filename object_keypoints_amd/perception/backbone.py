@@ -28,6 +28,7 @@ import os
 # (module attributes, flipped by tests that compare the paths; not environment switches)
 STEM_DIRECT = True       # 16-bit: the stem kernel reads fp32 NCHW frames itself (no pack launch)
 STEM_KERNEL = True       # 16-bit: dedicated stem kernel (okp_stem.hip); False = generic tap-list kernel
+STEM_X3_KERNEL = True    # split-product configuration on raw NCHW frames: the stem kernel's three-term form; False = pack + generic kernel
 UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
 SQUEEZE_TILE = 0         # tile code of the squeeze launch of a fire module that has no one-launch kernel (0 = heuristic)
 STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
@@ -107,6 +108,8 @@ class convolution(_HipModule):
                 raise OkpError("3-channel input is supported for the 7x7/s2 stem only")
             if dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and stride is None:
                 return StemPlan(w, b, dtype)
+            if stride == "direct":          # split-product stem kernel on fp32 NCHW frames (forward_frames)
+                return StemPlan(w, b, dtype)
             # one tap per kernel row: 8 pixels x 4 channels of the packed frame = 32 contiguous elements
             taps = []
             for r in range(7):
@@ -121,6 +124,14 @@ class convolution(_HipModule):
         otherwise pack (ops.pack_frames) + the generic path.  shadow (split-product plans): also write the fp16 copy."""
         if self.inp_dim == 3 and dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
             plan = self._plan(("p", dtype), lambda: self._build(dtype))
+            n, _, h, w = frames.shape
+            out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
+            plan.from_nchw(frames, out)
+            return out
+        if (dtype == torch.float32 and ops.F32_SPLIT and not shadow and self.inp_dim == 3 and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT
+                and STEM_X3_KERNEL):
+            # split-product configuration: the stem kernel's three-term form, fp32 NHWC out of fp32 NCHW in (no pack launch)
+            plan = self._plan(("px3", dtype), lambda: self._build(dtype, stride="direct"))
             n, _, h, w = frames.shape
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
             plan.from_nchw(frames, out)

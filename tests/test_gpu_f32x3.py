@@ -476,3 +476,64 @@ def test_audit_frames_falls_back_to_float32x3_on_unit_gain_weights():
     with pytest.warns(RuntimeWarning):
         assert pp.load_keypoint_net(sd, compute_dtype=torch.bfloat16, audit_frames=frames).configuration() == ops.F32X3
     assert pp.load_keypoint_net(sd, compute_dtype=ops.F32X3, audit_frames=frames).audit["checked"] is False
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 33, 33), (2, 64, 96), (1, 511, 511), (3, 47, 130)])
+def test_split_stem_kernel_matches_cpu_fp64(n, h, w):
+    """The stem kernel's split-product form (okp_stem_x3_kernel: fp32 NCHW frames in, fp32 NHWC out, three-term products) against
+    torch's fp64 CPU convolution, partial tiles included, and against the generic split-product path it replaces."""
+    from object_keypoints_amd import ops
+    dev = torch.device("cuda:0")
+    x = _rand((n, 3, h, w), 41)
+    wt = _rand((128, 3, 7, 7), 42) * (1.0 / np.sqrt(147.0))
+    wt[5] *= 1e-4                                   # a channel of small weights: the per-channel scale keeps its low halves
+    b = _rand((128,), 43) * 0.1
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=3)).float()
+    with ops.f32_split():
+        plan = ops.StemPlan(wt.numpy(), b.numpy(), torch.float32)
+    assert plan.split
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = ops.Act.empty(n, ho, wo, 128, torch.float32, dev)
+    out.t.fill_(float("nan"))
+    plan.from_nchw(x.to(dev), out)
+    got = out.to_nchw().cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= 2e-5 * (1.0 + float(ref.abs().max())), f"max err {err}"
+    assert float((got[:, 5] - ref[:, 5]).abs().max()) <= 3e-6 * float(ref[:, 5].abs().max()) + 1e-7      # bias 0.1 x 1e-4-sized weights
+    again = ops.Act.empty(n, ho, wo, 128, torch.float32, dev)
+    plan.from_nchw(x.to(dev), again)
+    assert torch.equal(again.t, out.t)
+
+
+def test_split_stem_is_what_the_network_launches_and_agrees_with_the_generic_path():
+    """hg.pre[0] of a float32x3 network on raw frames: one launch of the stem kernel (no pack launch), equal to the pack + generic
+    split-product kernel path to summation noise; plan / view mistakes are reported."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    dev = torch.device("cuda:0")
+    m = bb.convolution(7, 3, 128, stride=2).eval()
+    with torch.no_grad():
+        m.conv.weight.copy_(_rand((128, 3, 7, 7), 51) / np.sqrt(147.0)); m.bn.weight.copy_(1.0 + 0.1 * _rand((128,), 52)); m.bn.bias.copy_(0.1 * _rand((128,), 53))
+        m.bn.running_mean.copy_(0.1 * _rand((128,), 54)); m.bn.running_var.copy_(1.0 + 0.2 * _rand((128,), 55).abs())
+    x = _rand((2, 3, 95, 127), 56).to(dev)
+    with ops.f32_split():
+        l0 = ops.COUNTERS["launches"]
+        a = m.forward_frames(x, torch.float32)
+        assert ops.COUNTERS["launches"] - l0 == 1
+        bb.STEM_X3_KERNEL = False
+        try:
+            g = m.forward_frames(x, torch.float32)
+        finally:
+            bb.STEM_X3_KERNEL = True
+    assert float((a.t - g.t).abs().max()) <= 1e-5 * (1.0 + float(g.t.abs().max()))
+    with ops.f32_split():
+        plan = ops.StemPlan(np.zeros((128, 3, 7, 7), np.float32), np.zeros(128, np.float32), torch.float32)
+    with pytest.raises(ops.OkpError):
+        plan.from_nchw(x, ops.Act.empty(2, 48, 64, 128, torch.float16, dev))          # fp16 output of an fp32 plan
+    with pytest.raises(ops.OkpError):
+        plan.from_nchw(x, ops.Act.empty(2, 47, 64, 128, torch.float32, dev))          # wrong output size
+    with pytest.raises(ops.OkpError):
+        plan(ops.pack_frames(x, torch.float32), ops.Act.empty(2, 48, 64, 128, torch.float32, dev))    # packed frames: not this kernel
+    with pytest.raises(ops.OkpError):
+        ops.StemPlan(np.zeros((128, 3, 7, 7), np.float32), np.zeros(128, np.float32), torch.float32)      # fp32 outside f32_split()
