@@ -26,7 +26,10 @@ precision measured on the cpu_baseline's frames against the oracle (parity_field
 data-path collective as this run saw it (backend, ranks, payload, median all-gather time).  `roofline.counter_commit` /
 `stale` say which tree the committed PMC counters were collected on.  `power` (N=1): board power and shader clock sampled with rocm-smi
 while the step runs back to back AFTER the timed region, and the dominant kernel alone on normally distributed and on all-zero operands
-(the same instructions at different power: the kernel runs at the board's power limit).
+(the same instructions at different power: the kernel runs at the board's power limit); `--no-probes` skips these
+after-the-fact probes (the profiling passes of scripts/profile_all.sh use it: their per-kernel averages then hold the timed steps only).
+`--workload cups512` = BASELINE configs[3] (config/cups.json: K = 4 maps, four objects per frame, 64 frames per GPU, the all-gather
+payload [64 N, 4, cap, 4]); the default N = 1 line carries one rank's share of it as the `cups64` object.
 """
 import argparse
 import json
@@ -58,9 +61,12 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (tests)")
-    ap.add_argument("--workload", choices=["batch64", "stream8"], default="batch64",
-                    help="stream8: print only the BASELINE configs[4] object (the default run carries it as `stream8` next to the headline)")
+    ap.add_argument("--workload", choices=["batch64", "cups512", "stream8"], default="batch64",
+                    help="cups512: BASELINE configs[3] (K = 4, config/cups.json, four objects per frame) as the headline, at any N; "
+                         "stream8: print only the BASELINE configs[4] object (the default run carries both as `cups64` / `stream8` next to the headline)")
     ap.add_argument("--no-stream8", action="store_true", help="N=1: skip the configs[4] object")
+    ap.add_argument("--no-cups", action="store_true", help="N=1: skip the configs[3] object (`cups64`)")
+    ap.add_argument("--no-probes", action="store_true", help="skip the power / operand / collective probes behind the timed region (profiling passes)")
     return ap.parse_args(argv)
 
 
@@ -220,6 +226,28 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def kernel_time_share(kernel_sig, precision):
+    """Share of the step's kernel time the named kernel takes in the newest committed rocprofv3 kernel-stats table of this precision
+    (profiles/r*_<precision>_kernel_stats.csv), as a sentence naming the file; says so when there is none."""
+    import csv
+    import glob
+    import re
+    tag = "" if precision == "bf16" else precision + "_"
+    pat = re.compile(r"^r\d+[a-z]*_" + tag + r"kernel_stats\.csv$")
+    files = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", f"r*_{tag}kernel_stats.csv")) if pat.match(os.path.basename(f)))
+    if not files:
+        return "no committed kernel-stats table for this precision"
+    try:
+        with open(files[-1]) as f:
+            rows = list(csv.DictReader(f))
+        total = sum(float(r["TotalDurationNs"]) for r in rows)
+        plain = lambda name: name.replace("(anonymous namespace)::", "")
+        mine = sum(float(r["TotalDurationNs"]) for r in rows if any(sig in plain(r["Name"]) for sig in kernel_sig))
+        return f"{100.0 * mine / total:.1f} % of the kernel time in profiles/{os.path.basename(files[-1])}"
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return f"profiles/{os.path.basename(files[-1])} could not be read"
+
+
 def committed_counters(kernel_sig, precision="bf16"):
     """Counter figures of the dominant kernel from the committed PMC passes of this same command at this precision (bench.py
     cannot run the profiler on itself): HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
@@ -321,46 +349,70 @@ def cpu_baseline(seconds):
             keep)
 
 
+def oracle_maps(heatmaps_out):
+    """The oracle's heat / depth maps of the error-sample frames for a network of `heatmaps_out` maps (the checker of the configs[3]
+    object's parity fields; the K = 3 maps come out of cpu_baseline's timed sample)."""
+    import torch
+    from oracle import net as onet
+    from object_keypoints_amd import synth
+    torch.set_num_threads(usable_cores())
+    net = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=heatmaps_out), seed=0)
+    heat, depth, _ = onet.deployed_forward(net, torch.from_numpy(synth.frames(ERR_FRAMES, seed=1)))
+    return {"heat": heat.numpy(), "depth": depth.numpy()}
+
+
 TORCH_DTYPES = {"bf16": "bfloat16", "f16": "float16", "f32": "float32", "f32x3": "float32", "f32mix": "float32"}
 OBJECT_KEY = {"f32": "fp32", "f16": "fp16", "bf16": "bf16", "f32x3": "f32x3", "f32mix": "f32mix"}
 # substrings of the dominant kernel's name in the rocprofv3 CSVs (mangled where the tool's demangler gives up on _Float16 / __bf16)
 KERNEL_SIG = {"bf16": ("okp_igemm_patch_kernel",), "f16": ("okp_igemm_patch_kernel",),
               "f32": ("okp_igemm_kernel<float, 256, 256, 4, 2, 2, 128, 32, 1>", "okp_igemm_kernelIfLi256ELi256ELi4ELi2ELi2ELi128ELi32ELi1E"),
-              "f32x3": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"),
-              "f32mix": ("okp_igemm_kernel<F32S, 256, 256, 2, 4, 2, 128, 32, 1>", "F32SELi256ELi256ELi2ELi4ELi2ELi128ELi32ELi1E"),
+              "f32x3": ("okp_igemm_patch_x3_kernel",), "f32mix": ("okp_igemm_patch_x3_kernel",),
               "f32mix_hbm": ("okp_igemm_kernel<F32S, 128, 128,", "F32SELi128ELi128E")}
 KERNEL_NAME = {"bf16": "okp_igemm_patch_kernel<bf16,256co x 16x16px>", "f16": "okp_igemm_patch_kernel<f16,256co x 16x16px>",
-               "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_kernel<f32 split into 3 fp16 MFMA terms,256x256,src1>",
-               "f32mix": "okp_igemm_kernel<f32 split, 1 or 3 fp16 MFMA terms per tap,256x256,src1>",
+               "f32": "okp_igemm_kernel<f32,256x256,src1>", "f32x3": "okp_igemm_patch_x3_kernel<f32 split into 3 fp16 MFMA terms,256co x 16x16px>",
+               "f32mix": "okp_igemm_patch_x3_kernel<f32 split into 3 fp16 MFMA terms,256co x 16x16px> (`cnvs`, transposed convolutions)",
                "f32mix_hbm": "okp_igemm_kernel<f32 split,128x128> (1x1 convolutions / fire modules on fp32 tensors)"}
 
 
-def bump_maps(start, count, dev, keypoint_config=(1, 3)):
-    """Injected post-network maps for global frames start..start+count: 1-2 objects per frame."""
+# The two batch workloads: BASELINE configs[2] (the headline: valve, K = 3 maps, 1-2 objects per frame) and configs[3] (cups: K = 4 maps -
+# centre + three single-instance keypoint types, config/cups.json - and four objects per frame; 64 frames per GPU, 512 at 8 GPUs)
+WORKLOADS = {
+    "batch64": {"config": "configs[2]", "heatmaps_out": 3, "keypoint_config": (1, 3), "objects": lambda i: 1 + i % 2, "seed": 7, "what": "K=3 (valve)", "scenes": "1-2 objects/frame"},
+    "cups512": {"config": "configs[3]", "heatmaps_out": 4, "keypoint_config": (1, 1, 1), "objects": lambda i: 4, "seed": 31, "what": "K=4 (cups, config/cups.json)", "scenes": "4 objects/frame"},
+}
+
+
+def bump_maps(start, count, dev, wl):
+    """Injected post-network maps for global frames start..start+count of workload `wl`."""
     import numpy as np
     import torch
     from object_keypoints_amd import synth
-    scenes = [synth.bump_scene(list(keypoint_config), n_objects=1 + (start + i) % 2, seed=7, index=start + i) for i in range(count)]
+    scenes = [synth.bump_scene(list(wl["keypoint_config"]), n_objects=wl["objects"](start + i), seed=wl["seed"], index=start + i) for i in range(count)]
     to = lambda key: torch.from_numpy(np.stack([s[key] for s in scenes])).to(dev)
     n_peaks = sum(sum(len(p) for p in o["points"]) for s in scenes for o in s["objects"])
     return to("heat"), to("depth"), to("centers"), n_peaks
 
 
-def run_precision(name, ctx, steps, warmup):
+def run_precision(name, ctx, steps, warmup, workload="batch64"):
     """Timed steps of the hot path at one precision on this rank.  Returns (result dict, heat maps of the error sample)."""
     import torch
     from object_keypoints_amd import distributed as dist_, ops
     from object_keypoints_amd.perception.pipeline import BatchedKeypointPipeline
     dev, world, batch = ctx["dev"], ctx["world"], ctx["batch"]
+    wl = WORKLOADS[workload]
     dtype = getattr(torch, TORCH_DTYPES[name])
-    net = build_net({"f32x3": ops.F32X3, "f32mix": ops.F32MIX}.get(name, dtype)).to(dev)
-    pipe = BatchedKeypointPipeline(net, {"keypoint_config": [1, 3]}, ctx["camera"], capacity=64)
+    net = build_net({"f32x3": ops.F32X3, "f32mix": ops.F32MIX}.get(name, dtype), heatmaps_out=wl["heatmaps_out"]).to(dev)
+    pipe = BatchedKeypointPipeline(net, {"keypoint_config": list(wl["keypoint_config"])}, ctx["camera"], capacity=64)
     frames = ctx["frames"]
-    b_heat, b_depth, b_centers, n_peaks = ctx["bumps"]
+    if workload not in ctx["bumps"]:
+        ctx["bumps"][workload] = bump_maps(ctx["start"], batch, dev, wl)
+    b_heat, b_depth, b_centers, n_peaks = ctx["bumps"][workload]
     # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile;
     # float32mix has two populations: the HBM-bound 128x128 split tiles (1x1 convolutions / fire modules on fp32 tensors: the largest
     # share of its kernel time) and the MFMA-bound 256x256 split tile (`cnvs`, transposed convolutions)
-    gather = name in ("f32", "f32x3", "f32mix")
+    # split-product configurations: the patch-resident split kernel (tile 13 of fp32 plans: every 3x3 / transposed convolution of
+    # float32x3, `cnvs` and the transposed convolutions of float32mix - whose fp16 branches are float16 plans and do not match)
+    gather = name == "f32"
     pops = {"mfma": (dtype, (3,) if gather else (13,), 1 if gather else None, None)}
     if name == "f32mix":
         pops["hbm"] = (dtype, (2,), None, True)
@@ -375,6 +427,9 @@ def run_precision(name, ctx, steps, warmup):
     with torch.no_grad():
         for _ in range(warmup):
             out, gathered = step()
+        m0 = ops.COUNTERS["macs"]
+        net.deployed(frames)
+        gflop_per_frame = 2.0 * (ops.COUNTERS["macs"] - m0) / batch / 1e9       # what this network's launches multiply (K = 3: GFLOP_PER_FRAME)
         dist_.barrier(); torch.cuda.synchronize()
         timer.enabled = True
         t0 = time.perf_counter()
@@ -397,11 +452,12 @@ def run_precision(name, ctx, steps, warmup):
             cnt, yx, xyc = ops.peak_nms(h, cap=SAMPLE_CAP)
             pts = ops.lift_peaks(pipe.cam, cnt, xyc, d, int(pipe.max_index[0]), int(pipe.max_index[1]))
             sample = {k: v.cpu().numpy() for k, v in (("heat", h), ("depth", d), ("count", cnt), ("yx", yx), ("points", pts))}
-        coll = collective_probe(out["points"], batch, world, dev, own_group=ctx.get("probe_collective", False) and world == 1)
-        power = power_probe(step) if ctx.get("probe_collective", False) and world == 1 else None
+        probes = world == 1 and not ctx.get("no_probes", False)
+        coll = collective_probe(out["points"], batch, world, dev, own_group=probes and ctx.get("probe_collective", False)) if (probes or world > 1) else None
+        power = power_probe(step) if probes and ctx.get("probe_power", False) else None
         if power is not None and name in ("bf16", "f16"):
             power["dominant_kernel_alone"] = operand_probe(dtype, dev)
-        ctx["probe_collective"] = False        # (once per run: the headline precision)
+        ctx["probe_collective"] = ctx["probe_power"] = False        # (once per run: the headline precision; the configs[3] object asks for its own collective probe)
     value = batch * world * steps / elapsed
     n_launch, k_ms, k_flops, _ = timer.summary("mfma")
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -413,8 +469,11 @@ def run_precision(name, ctx, steps, warmup):
             "hbm_GBps": ctr["hbm_GBps"], "counter_source": ctr["counter_source"], "counter_commit": ctr["counter_commit"], "stale": ctr["stale"],
             "launches_timed": n_launch, "avg_launch_us": (k_ms * 1e3 / n_launch) if n_launch else None,
             "avg_gflop_per_launch": (k_flops / n_launch / 1e9) if n_launch else None}
-    res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-           "conv_stack_tflops_per_gpu": GFLOP_PER_FRAME * value / world / 1e3, "roofline": roof}
+    # algorithmic FLOPs per frame: SURVEY 8(d)'s figure for the K = 3 network; the K = 4 network of configs[3] by its own launches' MAC
+    # count (the mixed configuration launches part of the stem twice: not an algorithmic count, so never taken from there)
+    gf = GFLOP_PER_FRAME if workload == "batch64" else gflop_per_frame
+    res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "gflop_per_frame": gf,
+           "conv_stack_tflops_per_gpu": gf * value / world / 1e3, "roofline": roof}
     if name == "f32mix":
         # the population that takes the largest share of this configuration's kernel time is HBM-bound: it is the `roofline` object,
         # the MFMA-bound split tile moves to `roofline_mfma`
@@ -428,16 +487,19 @@ def run_precision(name, ctx, steps, warmup):
                            "counter_commit": ctr_h["counter_commit"], "stale": ctr_h["stale"],
                            "launches_timed": n_h, "avg_launch_us": (ms_h * 1e3 / n_h) if n_h else None,
                            "avg_algorithmic_MB_per_launch": (bytes_h / n_h / 1e6) if n_h else None,
-                           "share_of_kernel_time": "largest single kernel of the float32mix step (29.9 % in profiles/r03y_f32mix_kernel_stats.csv)"}
+                           "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f32mix_hbm"], name)}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
     if name == "f32mix":
-        res["roofline_mfma"]["mfma_terms"] = "1 (3x3 convolutions inside residual blocks) or 3 per tap"
+        res["roofline_mfma"]["mfma_terms"] = 3       # (the single-term branches of this configuration run on the fp16 patch kernel: float16 plans, not in this population)
     res["collective"] = coll
     if power is not None and name in ("bf16", "f16"):
         # the dense peak is quoted at 2.4 GHz; what the matrix pipe could deliver at the clock this board held under the step
         power["peak_at_sustained_clock_TFLOPs"] = peak * power["sclk_MHz_mean"] / power["sclk_MHz_peak_is_quoted_at"]
-        res["roofline"]["frac_at_sustained_clock"] = achieved / power["peak_at_sustained_clock_TFLOPs"]
+        # NOT a roofline fraction (the roofline's peak is the dense peak at 2.4 GHz, `roofline.frac`): the same rate against the peak
+        # rescaled to the clock rocm-smi reported under the step - a power diagnostic; the in-kernel clock reads up to 10 % lower
+        power["achieved_over_peak_at_smi_clock"] = {"value": achieved / power["peak_at_sustained_clock_TFLOPs"],
+                                                    "note": "not a roofline fraction: dominant kernel's rate / (2.5 PFLOP/s x rocm-smi sclk / 2.4 GHz)"}
     res["power"] = power
     del pipe, net
     torch.cuda.empty_cache()
@@ -683,8 +745,7 @@ def parity_fields(sample, oracle, camera_file):
     d2p = op.DetectionToPoint(); d2p.reset(cam)
     heat, depth = sample["heat"], sample["depth"]
     inter = union = 0
-    worst = 0.0
-    n_pts = 0
+    dists = []
     for n in range(heat.shape[0]):
         for k in range(heat.shape[1]):
             idx = op.peak_indices(oracle["heat"][n, k])
@@ -699,13 +760,18 @@ def parity_fields(sample, oracle, camera_file):
             want = d2p(np.stack(pts), oracle["depth"][n, k])
             for j, key in enumerate(theirs):
                 if key in mine:
-                    worst = max(worst, float(np.linalg.norm(sample["points"][n, k, mine[key], :3] - want[j])))
-                    n_pts += 1
+                    dists.append(float(np.linalg.norm(sample["points"][n, k, mine[key], :3] - want[j])))
+    dists = np.array(dists if dists else [0.0])
+    worst, n_pts = float(dists.max()), len(dists)
     e_d = np.abs(depth.astype(np.float64) - oracle["depth"].astype(np.float64))
     return {"heat_err_vs_oracle": heat_error(heat, oracle["heat"]),
             "depth_err_vs_oracle": {"max": float(e_d.max()), "mean": float(e_d.mean())},
             "peak_jaccard": inter / union if union else 1.0, "peaks_compared": union,
+            # (a random-weight network's depth maps are noise-like: ONE flipped depth pixel under a peak moves that point by the
+            #  depth difference - the max alone cannot tell such an outlier from a bias, the quantiles can)
             "p_C_err_m": worst, "p_C_points": n_pts,
+            "p_C_err_m_stats": {"median": float(np.median(dists)), "p99": float(np.quantile(dists, 0.99)), "max": worst,
+                                "n_over_1e-4": int((dists > 1e-4).sum()), "n": n_pts},
             "meets": {"heat_1e-3": bool(np.abs(heat - oracle["heat"]).max() <= 1e-3), "peaks_identical": inter == union,
                       "p_C_1e-4_m": worst <= 1e-4}}
 
@@ -716,10 +782,11 @@ def heat_error(got, want):
     return {"max": float(e.max()), "mean": float(e.mean()), "p99": float(np.quantile(e, 0.99)), "frames": int(got.shape[0])}
 
 
-def workload_string(batch, name, world):
-    return (f"BASELINE configs[2]: batch={batch}/GPU synthetic 511x511 frames, {name} activations+weights, fp32 accumulate, "
-            "CornerNet-Squeeze K=3 (valve) random-init procedural weights; fp32 NCHW frames -> stem -> hourglass+heads; "
-            "peak-NMS -> depth lifting -> object grouping on injected bump scenes (SURVEY 8(d), 1-2 objects/frame)"
+def workload_string(batch, name, world, workload="batch64"):
+    wl = WORKLOADS[workload]
+    return (f"BASELINE {wl['config']}: batch={batch}/GPU synthetic 511x511 frames, {name} activations+weights, fp32 accumulate, "
+            f"CornerNet-Squeeze {wl['what']} random-init procedural weights; fp32 NCHW frames -> stem -> hourglass+heads; "
+            f"peak-NMS -> depth lifting -> object grouping on injected bump scenes (SURVEY 8(d), {wl['scenes']})"
             + (" -> all-gather of 3D keypoints" if world > 1 else ""))
 
 
@@ -745,8 +812,8 @@ def rank_main(args):
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + start)
     frames = torch.randn((args.batch, 3, 511, 511), generator=gen, device=dev, dtype=torch.float32)
     with_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    ctx = {"dev": dev, "world": world, "batch": args.batch, "camera": camera, "frames": frames, "probe_collective": True,
-           "bumps": bump_maps(start, args.batch, dev),
+    ctx = {"dev": dev, "world": world, "batch": args.batch, "camera": camera, "frames": frames, "probe_collective": True, "probe_power": True,
+           "no_probes": args.no_probes, "start": start, "bumps": {},
            "err_frames": torch.from_numpy(synth.frames(ERR_FRAMES, seed=1)).to(dev) if with_cpu else None}
 
     if args.workload == "stream8":
@@ -754,13 +821,14 @@ def rank_main(args):
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
-    head, head_heat = run_precision(args.dtype, ctx, args.steps, args.warmup)
+    workload = args.workload                      # batch64 (configs[2], the headline) or cups512 (configs[3])
+    head, head_heat = run_precision(args.dtype, ctx, args.steps, args.warmup, workload)
     result = {
         "metric": "frames/sec keypoint inference (511x511 -> heatmaps+3D)",
         "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": workload_string(args.batch, args.dtype, world),
+        "config": {"workload": workload_string(args.batch, args.dtype, world, workload),
                    "frames_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"frame-dp{world}"},
         "conv_stack_tflops_per_gpu": head["conv_stack_tflops_per_gpu"],
         "roofline": head["roofline"],
@@ -768,7 +836,8 @@ def rank_main(args):
         "power": head["power"],
     }
     extra_heat = {}
-    if world == 1:
+    cups_heat = None
+    if world == 1 and workload == "batch64":
         for name in [d for d in args.extra_dtypes.split(",") if d and d != args.dtype]:
             # fp32 runs ~12x longer per step (157 TFLOP/s MFMA peak): fewer steps keep the default run within minutes
             # (with the driver's --steps 20 every precision still times at least 10 steps)
@@ -777,14 +846,27 @@ def rank_main(args):
             res["workload"] = workload_string(args.batch, name, world)
             res.pop("power", None)               # (probed once, on the headline precision)
             result[OBJECT_KEY[name]] = res
-    if world == 1 and not args.no_stream8:
+        if not args.no_cups:
+            # BASELINE configs[3], one rank's share (64 frames of the 512): the workload a `--workload cups512 --gpus 8` run weak-scales
+            ctx["probe_collective"] = True       # its payload ([64, 4, cap, 4]) through a one-rank RCCL group of its own
+            res, cups_heat = run_precision(args.dtype, ctx, max(10, args.steps // 2), min(args.warmup, 2), "cups512")
+            res["workload"] = workload_string(args.batch, args.dtype, world, "cups512")
+            res["dtype"] = args.dtype
+            res.pop("power", None)
+            result["cups64"] = res
+    if world == 1 and not args.no_stream8 and workload == "batch64":
         result["stream8"] = run_stream8(ctx)
     if with_cpu:
-        result["cpu_baseline"], oracle = cpu_baseline(args.cpu_seconds)
         cal = os.path.join(REPO, "config", "calibration.yaml")
-        result.update(parity_fields(head_heat, oracle, cal))
-        for name, smp in extra_heat.items():
-            result[OBJECT_KEY[name]].update(parity_fields(smp, oracle, cal))
+        if workload == "batch64":
+            result["cpu_baseline"], oracle = cpu_baseline(args.cpu_seconds)
+            result.update(parity_fields(head_heat, oracle, cal))
+            for name, smp in extra_heat.items():
+                result[OBJECT_KEY[name]].update(parity_fields(smp, oracle, cal))
+            if cups_heat is not None:
+                result["cups64"].update(parity_fields(cups_heat, oracle_maps(WORKLOADS["cups512"]["heatmaps_out"]), cal))
+        else:
+            result.update(parity_fields(head_heat, oracle_maps(WORKLOADS[workload]["heatmaps_out"]), cal))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if torch.distributed.is_initialized():

@@ -112,13 +112,30 @@ def strip_module_prefixes(sd):
 HEAT_BAR = 1e-3          # north_star: heat maps within 1e-3 of the fp32 reference
 
 
+AUDIT_AUTO = "auto"      # load_keypoint_net(audit_frames=...): audit a mixed plan on two synthetic frames when the caller gives none
+
+
 def _audited(net, audit_frames, heat_bar):
     """float32mix is a plan derived on ONE weight family: its single-term fp16 branches are cheap because BatchNorm
     gains attenuate them there.  With `audit_frames` the loaded network is priced on the device against float32x3 (fp32-grade, 2e-6)
     on the caller's frames (KeypointNet.precision_audit: two passes, no CPU reference) and, where the heat maps are further than
-    `heat_bar` apart - or not finite: fp16 operands overflow above 65504 - the network falls back to float32x3 with a warning."""
+    `heat_bar` apart - or not finite: fp16 operands overflow above 65504 - the network falls back to float32x3 with a warning.
+    The default (AUDIT_AUTO) audits a MIXED configuration on two synthetic frames, so that no mixed plan ships unverified on the
+    weights it was loaded with; 16-bit configurations are the caller's explicit choice of a precision outside the bar and are audited
+    only on request.  audit_frames=None skips the audit; for a mixed configuration that is said with a RuntimeWarning."""
     if audit_frames is None:
+        if getattr(net, "mixed", False):
+            import warnings
+            warnings.warn(f"{net.configuration()}: loaded without an audit - this mixed-precision plan was derived on one weight family and is "
+                          "UNVERIFIED on these weights (pass audit_frames, or leave the default, to price it against float32x3)", RuntimeWarning, stacklevel=3)
         return net
+    if isinstance(audit_frames, str):
+        if audit_frames != AUDIT_AUTO:
+            raise OkpError(f"audit_frames: a [n,3,H,W] tensor, None or '{AUDIT_AUTO}'")
+        if not net.mixed:
+            return net
+        from .. import synth
+        audit_frames = torch.from_numpy(synth.frames(2, seed=20251))
     if not (net.mixed or net.compute_dtype in ops.HALF_DTYPES):
         net.audit = {"configuration": net.configuration(), "checked": False, "reason": "fp32-grade configuration: nothing to audit"}
         return net
@@ -135,13 +152,14 @@ def _audited(net, audit_frames, heat_bar):
     return net
 
 
-def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_frames=None, heat_bar=HEAT_BAR):
+def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_frames=AUDIT_AUTO, heat_bar=HEAT_BAR):
     """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
     TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet.
     Entries of the file that are not KeypointNet parameters (loss buffers, metrics of the Lightning module) are ignored;
     a missing network tensor is an error.
-    audit_frames (opt-in; [n,3,H,W] float32, a handful of representative frames): price a mixed / 16-bit `compute_dtype` on these
-    weights and fall back to float32x3 when it misses `heat_bar` (see _audited; the result is in `net.audit`)."""
+    audit_frames ([n,3,H,W] float32, a handful of representative frames): price a mixed / 16-bit `compute_dtype` on these weights and
+    fall back to float32x3 when it misses `heat_bar` (see _audited; the result is in `net.audit`).  Default: a mixed configuration
+    ("float32mix") is audited on two synthetic frames; None skips the audit (with a RuntimeWarning for a mixed configuration)."""
     device = device or _device()
     if isinstance(model, models.KeypointNet):
         return _audited(model.to(device).eval(), audit_frames, heat_bar)

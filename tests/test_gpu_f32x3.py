@@ -537,3 +537,34 @@ def test_split_stem_is_what_the_network_launches_and_agrees_with_the_generic_pat
         plan(ops.pack_frames(x, torch.float32), ops.Act.empty(2, 48, 64, 128, torch.float32, dev))    # packed frames: not this kernel
     with pytest.raises(ops.OkpError):
         ops.StemPlan(np.zeros((128, 3, 7, 7), np.float32), np.zeros(128, np.float32), torch.float32)      # fp32 outside f32_split()
+
+
+def test_float32mix_is_audited_by_default_when_loaded():
+    """load_keypoint_net(compute_dtype="float32mix") WITHOUT audit_frames: the mixed plan is priced on two synthetic frames all the same -
+    on unit-gain weights (where it misses the heat bar by 3x) the caller gets float32x3 and a warning instead of an unverified plan; on
+    the derived-on weights it stays float32mix; audit_frames=None opts out and says so."""
+    import os
+    import sys
+    import warnings
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import pipeline as pp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "precision"))
+    import families
+    onet, _ = families.build_family("torch-default")
+    sd = {k: v.clone() for k, v in onet.state_dict().items()}
+    with pytest.warns(RuntimeWarning, match="falling back to float32x3"):
+        net = pp.load_keypoint_net(sd, compute_dtype=ops.F32MIX)
+    assert net.configuration() == ops.F32X3 and net.audit["checked"] and net.audit["fell_back"] and net.audit["frames"] == 2
+    case = cases.NET_CASES["valve_k3"]
+    vals = synth.fill_state_dict({k: tuple(v.shape) for k, v in onet.state_dict().items()}, seed=case["weight_seed"])
+    own = {k: torch.from_numpy(np.array(v)) for k, v in vals.items()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        kept = pp.load_keypoint_net(own, compute_dtype=ops.F32MIX)
+        assert not hasattr(pp.load_keypoint_net(own, compute_dtype=torch.bfloat16), "audit")      # 16-bit: the caller's explicit choice, audited on request only
+    assert kept.configuration() == ops.F32MIX and kept.audit["checked"] and not kept.audit["fell_back"]
+    with pytest.warns(RuntimeWarning, match="UNVERIFIED"):
+        raw = pp.load_keypoint_net(sd, compute_dtype=ops.F32MIX, audit_frames=None)
+    assert raw.configuration() == ops.F32MIX and not hasattr(raw, "audit")
+    with pytest.raises(pp.OkpError):
+        pp.load_keypoint_net(own, compute_dtype=ops.F32MIX, audit_frames="always")

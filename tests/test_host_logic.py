@@ -467,3 +467,56 @@ def test_bench_power_probe_parses_rocm_smi_and_tolerates_its_absence(tmp_path):
     silent.write_text("#!/bin/sh\necho nothing useful\n")
     silent.chmod(0o755)
     assert bench.power_probe(lambda: None, seconds=0.2, smi=str(silent), sync=lambda: None) is None
+
+
+def test_mixed_plan_loaded_without_an_audit_says_so():
+    """perception.pipeline._audited (the tail of load_keypoint_net): a mixed-precision network that skips the audit (audit_frames=None)
+    raises a RuntimeWarning naming the plan as unverified on these weights; fp32-grade and 16-bit configurations pass silently; the
+    default is the automatic audit, and any other string is refused.  (Host logic only: the audit itself needs the device.)"""
+    import inspect
+    import warnings
+    from object_keypoints_amd.perception import pipeline as pp
+
+    class Stub:
+        def __init__(self, mixed):
+            self.mixed = mixed
+
+        def configuration(self):
+            return "float32mix" if self.mixed else "float32x3"
+
+    with pytest.warns(RuntimeWarning, match="UNVERIFIED on these weights"):
+        assert pp._audited(Stub(True), None, pp.HEAT_BAR).mixed
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        pp._audited(Stub(False), None, pp.HEAT_BAR)
+        pp._audited(Stub(False), pp.AUDIT_AUTO, pp.HEAT_BAR)          # nothing mixed: nothing to audit, no device touched
+    with pytest.raises(pp.OkpError):
+        pp._audited(Stub(True), "sometimes", pp.HEAT_BAR)
+    assert inspect.signature(pp.load_keypoint_net).parameters["audit_frames"].default == pp.AUDIT_AUTO
+
+
+def test_bench_parity_fields_report_point_error_quantiles(tmp_path):
+    """bench.parity_fields: `p_C_err_m` (the maximum) comes with median / p99 / n_over_1e-4, so that one flipped depth pixel under one
+    peak (a 1.5 m outlier on a noise-like random-weight depth map) reads as an outlier and not as a bias."""
+    import bench
+    from oracle import pipeline as op
+    from object_keypoints_amd import synth
+    sc = synth.bump_scene([1, 3], n_objects=2, seed=7, index=5)
+    heat, depth = sc["heat"][None, :1].copy(), sc["depth"][None, :1].copy()         # one map (the two centres)
+    oracle = {"heat": heat, "depth": depth}
+    cal = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "calibration.yaml")
+    cam = op.eval_camera(cal)
+    d2p = op.DetectionToPoint(); d2p.reset(cam)
+    idx = op.peak_indices(heat[0, 0])
+    pts, _ = op.refine_peaks(heat[0, 0], idx)
+    want = d2p(np.stack(pts), depth[0, 0])
+    points = np.full((1, 1, bench.SAMPLE_CAP, 4), np.nan)
+    points[0, 0, :len(idx), :3] = want
+    points[0, 0, 1, 2] += 1.5                                        # one point 1.5 m off, the others exact
+    yx = np.zeros((1, 1, bench.SAMPLE_CAP, 2), np.int64); yx[0, 0, :len(idx)] = idx
+    sample = {"heat": heat, "depth": depth, "count": np.array([[len(idx)]]), "yx": yx, "points": points}
+    got = bench.parity_fields(sample, oracle, cal)
+    st = got["p_C_err_m_stats"]
+    assert len(idx) >= 2
+    assert abs(got["p_C_err_m"] - 1.5) < 1e-9 and st["max"] == got["p_C_err_m"] and st["n"] == len(idx)
+    assert st["n_over_1e-4"] == 1 and (st["median"] < 1e-9 or len(idx) == 2) and got["meets"]["p_C_1e-4_m"] is False and got["meets"]["peaks_identical"]
