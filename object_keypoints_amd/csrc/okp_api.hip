@@ -340,6 +340,26 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
           h[base] = uh; h[base + 16] = ul;
         }
       ok = ok && !okp_check_hip(hipMemcpy(plan->weights_dev, h.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+      // 1x1 plans consumed by the one-launch fire module of this configuration (okp_fire_x3.hip) also get their (scaled) weights in
+      // MFMA-fragment order, channels as rows: lane (i = l & 15, q = l >> 4) of wave w, k-step ks holds the hi (then the lo) halves of
+      // channel 16 w + i at K offset 32 ks + 8 q .. + 7 - one wave load = 1 KiB contiguous.  Built here: a plan is immutable afterwards.
+      if (ok && n_taps == 1 && n_src == 1 && cin[0] % 32 == 0 && cout % 16 == 0 && !tap_terms) {
+        const int ksteps = cin[0] / 32, n_waves = cout / 16;
+        std::vector<uint16_t> fr((size_t)n_waves * 2 * ksteps * 64 * 8);
+        for (int w = 0; w < n_waves; ++w)
+          for (int ks = 0; ks < ksteps; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int ch = 16 * w + (lane & 15), q = lane >> 4;
+              for (int e = 0; e < 8; ++e) {
+                const float v = packed[((size_t)ks * plan->cout_pad + ch) * 32 + 8 * q + e];      // (slice ks = channels 32 ks .. 32 ks + 31 of the one tap)
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                std::memcpy(&fr[((((size_t)w * 2 + 0) * ksteps + ks) * 64 + lane) * 8 + e], &hi, 2);
+                std::memcpy(&fr[((((size_t)w * 2 + 1) * ksteps + ks) * 64 + lane) * 8 + e], &lo, 2);
+              }
+            }
+        ok = !okp_check_hip(hipMalloc(&plan->fragT_dev, fr.size() * 2), "hipMalloc(fragment-order split weights)");
+        ok = ok && !okp_check_hip(hipMemcpy(plan->fragT_dev, fr.data(), fr.size() * 2, hipMemcpyHostToDevice), "hipMemcpy(fragment-order split weights)");
+      }
     } else {
       ok = !okp_check_hip(hipMemcpy(plan->weights_dev, packed.data(), w_bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
     }

@@ -543,7 +543,8 @@ int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int s
 extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand, const float* dw_w_dev, const float* dw_bias_dev,
                                 const okp_fire_args* a, void* stream) {
   if (!squeeze || !expand || !dw_w_dev || !dw_bias_dev || !a || !a->x.data || !a->out.data) { okp_set_error("okp_fire_forward: null argument"); return OKP_EINVAL; }
-  if (!okp_is16(squeeze->dtype) || expand->dtype != squeeze->dtype) { okp_set_error("okp_fire_forward: the fused fire kernel takes bf16 or fp16 plans of one type"); return OKP_EINVAL; }
+  const bool x3 = squeeze->dtype == OKP_F32X3;
+  if (!(okp_is16(squeeze->dtype) || x3) || expand->dtype != squeeze->dtype) { okp_set_error("okp_fire_forward: the fused fire kernel takes bf16, fp16 or split-product (OKP_F32X3) plans of one type"); return OKP_EINVAL; }
   if (squeeze->n_taps != 1 || expand->n_taps != 1 || squeeze->n_src != 1 || expand->n_src != 1) { okp_set_error("okp_fire_forward: squeeze/expand must be single-tap 1x1 plans"); return OKP_EINVAL; }
   const int cin = squeeze->cin[0], mid = squeeze->cout, half = expand->cout;
   if (expand->cin[0] != mid || half != mid) { okp_set_error("okp_fire_forward: expects expand cin == squeeze cout == half (sr = 2)"); return OKP_EINVAL; }
@@ -552,6 +553,26 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
   if (a->skip && (a->stride != 1 || cin != 2 * half)) { okp_set_error("okp_fire_forward: skip needs stride 1 and cin == cout"); return OKP_EINVAL; }
   const int ho = (a->x.h - 1) / a->stride + 1, wo = (a->x.w - 1) / a->stride + 1;
   if (a->out.h != ho || a->out.w != wo) { okp_set_error("okp_fire_forward: out is %dx%d, expected %dx%d", a->out.h, a->out.w, ho, wo); return OKP_EINVAL; }
+  if (x3) {
+    // split-product plans: fp32 tensors; okp_fire_x3.hip has the 256 -> 128 -> 256 module with skip at stride 1
+    if (!okp_fire_x3_supported(cin, mid, half, a->stride, a->skip) || squeeze->n_single_slices || expand->n_single_slices || !squeeze->fragT_dev || !expand->fragT_dev) {
+      okp_set_error("okp_fire_forward: the split-product one-launch kernel takes 256 -> 128 -> 256 at stride 1 with skip (three-term plans); run the squeeze plan and the fused tail instead");
+      return OKP_EINVAL;
+    }
+    if (a->x.pix_stride % 4 || a->out.pix_stride % 4 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half || ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) {
+      okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL;
+    }
+    if (a->x.bytes <= 0 || a->x.bytes >= 0x7FFF0000ll || a->out.bytes <= 0 || a->out.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: views must be < 2 GiB"); return OKP_EINVAL; }
+    OkpFire2Params q;
+    memset(&q, 0, sizeof(q));
+    q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
+    q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.Ho = ho; q.Wo = wo; q.out_ps = a->out.pix_stride;
+    q.N = a->n; q.skip = a->skip;
+    q.w1 = squeeze->fragT_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev; q.s1 = squeeze->oscale_dev;
+    q.wa = expand->fragT_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev; q.sa = expand->oscale_dev;
+    q.wd = dw_w_dev; q.bd = dw_bias_dev;
+    return okp_launch_fire_x3(q, (hipStream_t)stream);
+  }
   if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||
       ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) { okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL; }
   if (a->x.bytes <= 0 || a->x.bytes >= 0x7FFF0000ll) { okp_set_error("okp_fire_forward: x spans %lld bytes; views must be < 2 GiB", (long long)a->x.bytes); return OKP_EINVAL; }

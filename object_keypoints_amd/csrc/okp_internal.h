@@ -182,8 +182,12 @@ struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 12
   const void* w1; int32_t w1_cout_pad; const float* b1;     // squeeze plan: packed [slice][cout_pad][128 B] bf16
   const void* wa; int32_t wa_cout_pad; const float* ba;     // expand plan
   const float* wd; const float* bd;                         // depth-wise [9][128] fp32, bias [128]
+  const float* s1; const float* sa;                         // okp_fire_x3.hip (split-product plans): output scales of the squeeze / expand plan
   int32_t SH, SW, IH, IW, IP, RPR, tiles_y, tiles_x, n_tiles;
   OkpFastDiv div_tiles_frame, div_tiles_x, div_sw, div_iw, div_rpr;
+#ifdef OKP_FIRE_STAMPS
+  uint32_t* dbg;               // debug build: shader-clock stamps at the phase boundaries of every workgroup's second tile
+#endif
 };
 
 struct OkpFireChainModule {   // okp_fire_chain.hip
@@ -218,7 +222,8 @@ struct okp_conv {
   int32_t patch_n_geom;
   int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
   void* frag_dev;          // single-tap 16-bit plans: weights re-laid in MFMA-fragment order (built by okp_conv_create; NULL otherwise)
-  void* fragT_dev;         // the same with the channel-as-ROW order of okp_fire2 (row i of block b = channel 32 w + 8 (i >> 2) + 4 b + (i & 3))
+  void* fragT_dev;         // the same with the channel-as-ROW order of okp_fire2 (row i of block b = channel 32 w + 8 (i >> 2) + 4 b + (i & 3));
+                           // single-tap OKP_F32X3 plans: [cout / 16][hi | lo][cin / 32][lane][8 fp16], row i of wave w = channel 16 w + i (okp_fire_x3.hip)
 };
 
 void okp_set_error(const char* fmt, ...);
@@ -231,6 +236,8 @@ int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hi
 int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_chain.hip: fragment-order weight copy of a 1x1 plan
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
+bool okp_fire_x3_supported(int cin, int mid, int half, int stride, int skip);     // okp_fire_x3.hip: one-launch fire module of split-product plans
+int okp_launch_fire_x3(OkpFire2Params p, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
 int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
 int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatchParams& p);             // okp_igemm_patch.hip (shared by both patch kernels)

@@ -330,7 +330,7 @@ FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256),
 
 
 def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
-    """One-launch fire module (bf16): see okp_fire_forward in include/okp.h."""
+    """One-launch fire module (16-bit plans: okp_fire2.hip; split-product plans: okp_fire_x3.hip): see okp_fire_forward in include/okp.h."""
     T = _lib.torch_ops()
     if T is not None:
         _dispatch(T.fire_forward, squeeze._h, expand._h, wd_dev, bd_dev, x.t, x.c0, out.t, out.c0, stride, bool(skip), stream_int())
@@ -393,6 +393,14 @@ def fire_fusable(inp_dim, mid, stride, h, w):
     if stride == 2 and not FUSE_FIRE_S2:
         return False
     return FUSE_FIRE and (inp_dim, mid) in _FIRE2_CONFIGS.get(stride, ()) and min(h, w) // stride >= FUSE_FIRE_MIN_HW
+
+
+FUSE_FIRE_X3 = True     # split-product plans: the one-launch fire module okp_fire_x3.hip (256 -> 128 -> 256 with skip, stride 1)
+FUSE_FIRE_X3_MIN_HW = 16
+
+
+def fire_fusable_x3(inp_dim, mid, stride, skip, h, w):
+    return FUSE_FIRE_X3 and (inp_dim, mid) == (256, 128) and stride == 1 and skip and min(h, w) >= FUSE_FIRE_X3_MIN_HW
 
 
 LIGHT_EVENTS = True     # forks / joins through okp_stream_wait_stream (events without a system-scope fence); False: torch's wait_stream

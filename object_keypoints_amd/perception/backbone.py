@@ -304,7 +304,8 @@ class fire_module(_HipModule):
         squeeze, expand, wd, bd = self._plan(("p", x.dtype), lambda: self._build(x.dtype, x.t.device))
         half = self.out_dim // 2
         ho, wo = conv_out_size(x.h, 3, self.stride, 1), conv_out_size(x.w, 3, self.stride, 1)
-        if x.dtype in ops.HALF_DTYPES and ops.fire_fusable(self.inp_dim, self.mid, self.stride, x.h, x.w):
+        if (x.dtype in ops.HALF_DTYPES and ops.fire_fusable(self.inp_dim, self.mid, self.stride, x.h, x.w)) or \
+                (squeeze.split and expand.split and ops.fire_fusable_x3(self.inp_dim, self.mid, self.stride, self.skip, x.h, x.w)):
             out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
             ops.fire_fused(squeeze, expand, wd, bd, x, out, self.stride, self.skip)
             return out

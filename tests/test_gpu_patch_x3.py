@@ -221,3 +221,38 @@ def test_patch_x3_at_batch64_against_cpu_convolution(case):
     for i in frames:
         ref = ref_fn(i)
         assert float((nchw(out.t, i) - ref).abs().max()) <= tol(ref), i
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (2, 20, 37), (3, 64, 64), (64, 32, 32), (64, 64, 64)])
+def test_split_fire_module_in_one_launch(n, h, w):
+    """okp_fire_x3_kernel (fire_module 256 -> 128 -> 256 with skip in split-product mode: x ring split once in LDS, squeeze tile resident)
+    against the oracle's fire_module (torch CPU fp32) and against the two-launch path it replaces, partial tiles and the bench's batch
+    included (frames 0 / middle / last), bit-reproducible."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    o = onet.load_synthetic(onet.fire_module(256, 256), seed=21)
+    m = bb.fire_module(256, 256)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x = torch.randn((n, h, w, 256), generator=gen, device="cuda")
+    with ops.f32_split():
+        l0 = ops.COUNTERS["launches"]
+        got = m(ops.Act(x))
+        assert ops.COUNTERS["launches"] - l0 == 1
+        again = m(ops.Act(x))
+        ops.FUSE_FIRE_X3 = False
+        try:
+            two = m(ops.Act(x))
+            assert ops.COUNTERS["launches"] - l0 == 4
+        finally:
+            ops.FUSE_FIRE_X3 = True
+    assert torch.equal(again.t, got.t)
+    sample = sorted({0, n // 2, n - 1})
+    with torch.no_grad():
+        ref = o(x[sample].permute(0, 3, 1, 2).cpu().double() if False else x[sample].permute(0, 3, 1, 2).cpu())
+    g = got.t[sample].permute(0, 3, 1, 2).cpu()
+    scale = 1.0 + float(ref.abs().max())
+    assert float((g - ref).abs().max()) <= 2e-5 * scale
+    assert float((got.t - two.t).abs().max()) <= 1e-5 * scale
