@@ -104,8 +104,9 @@ typedef struct okp_conv_args {
   int32_t out_step, out_oy, out_ox;/* sub-pixel placement (1,0,0 for ordinary convs) */
   okp_tensor res;                  /* optional residual, same spatial mapping as out; data==NULL if none */
   int32_t tile;                    /* 0 = auto; 1 = 64x64, 2 = 128x128, 3 = 256x256 (32x32 MFMA); 4 = 128x256 on a half-slice ring;
-                                      6 / 8 = 256x256 / 64x64 on 16x16 MFMAs (16-bit types); 13 = patch-resident 3x3 kernel (16-bit types,
-                                      cout_pad % 256 == 0, whole 16x16-pixel blocks; OKP_EINVAL where it does not apply) */
+                                      6 / 8 = 256x256 / 64x64 on 16x16 MFMAs (16-bit types); 13 = patch-resident 3x3 kernel (16-bit types and
+                                      OKP_F32X3 plans, cout_pad % 256 == 0, whole 16x16-pixel blocks; OKP_EINVAL where it does not apply);
+                                      14 = the same 16-bit kernel on 32x32x16 MFMAs (MFMA-shape A/B; never the heuristic's choice) */
   /* Optional fused depth-wise branch (the fire-module tail, CornerNet_Squeeze.py:15-17,25-30): the same launch
    * also computes  dw_out[..., c] = act(dw_bias[c] + dw_res[..., c] + sum_{3x3 taps} dw_w[tap][c] * src[0][..., c])
    * for c in [0, cout) with the plan's conv_stride[0] and pad 1, so that `expand 1x1 || depth-wise 3x3` of one

@@ -439,8 +439,8 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   }
   if (a->out.pix_stride < plan->cout || (a->res.data && a->res.pix_stride < plan->cout)) { okp_set_error("okp_conv_forward: out/res pix_stride < cout %d", plan->cout); return OKP_EINVAL; }
   if (a->res.data && (a->res.h != (sub2 ? a->out16.h : a->out.h) || a->res.w != (sub2 ? a->out16.w : a->out.w))) { okp_set_error("okp_conv_forward: residual spatial size differs from out"); return OKP_EINVAL; }
-  if (a->tile < 0 || a->tile > 13 || !((1u << a->tile) & 0x215Fu)) {       // 0 (heuristic), 1, 2, 3, 4, 6, 8, 13
-    okp_set_error("okp_conv_forward: tile %d is not one of 0 (heuristic), 1, 2, 3, 4, 6, 8, 13", a->tile); return OKP_EINVAL;
+  if (a->tile < 0 || a->tile > 14 || !((1u << a->tile) & 0x615Fu)) {       // 0 (heuristic), 1, 2, 3, 4, 6, 8, 13, 14
+    okp_set_error("okp_conv_forward: tile %d is not one of 0 (heuristic), 1, 2, 3, 4, 6, 8, 13, 14", a->tile); return OKP_EINVAL;
   }
 
   OkpIgemmParams p;

@@ -39,6 +39,12 @@ int okp_select_tile(int dtype, int cout_pad, long P) {
 
 int okp_launch_igemm(const okp_conv* plan, const OkpIgemmParams& p, int tile, hipStream_t stream) {
   if (tile == 13) return okp_launch_igemm_patch(plan, p, stream);       // patch-resident 3x3 kernel (okp_igemm_patch.hip)
+  if (tile == 14) {                                                       // ... its 32x32x16 instantiation (16-bit plans; MFMA-shape A/B)
+    if (!okp_is16(plan->dtype)) { okp_set_error("okp_conv_forward: tile 14 is the 16-bit patch-resident kernel on 32x32x16 MFMAs"); return OKP_EINVAL; }
+    OkpIgemmParams q = p;
+    q.mfma32 = 1;
+    return okp_launch_igemm_patch(plan, q, stream);
+  }
   if (tile == 0) tile = okp_select_tile(plan->dtype, p.cout_pad, (long)p.N * p.Ho * p.Wo);
   if (plan->dtype == OKP_BF16) return launch_tile<__bf16>(plan, p, tile, stream);
   if (plan->dtype == OKP_F16) return launch_tile<_Float16>(plan, p, tile, stream);

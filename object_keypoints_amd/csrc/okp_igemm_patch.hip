@@ -42,7 +42,11 @@ namespace {
 // of 16 pixels only; for the taps with column offset 1 and 2 every pixel-fragment read took two passes per 256 bytes
 // (SQ_LDS_BANK_CONFLICT = 30 percent of SQ_LDS_IDX_ACTIVE).  This table is conflict-free for column offsets 0, 1 and 2.
 constexpr uint32_t kPatchKeys = 0x7ac788u;
-__device__ __forceinline__ uint32_t patch_key(int col) { return (kPatchKeys >> (3 * (col >> 1))) & 7u; }
+// MT = 32 (the 32x32x16 instantiation, tile 14: the MFMA-shape experiment of round 5): a 32-row fragment is two patch rows of 16 columns and
+// lane bit 4 the row, so every lane group holds each column once with one k-group: the plain key (col >> 1) & 7 is conflict-free there.
+template <int MT> __device__ __forceinline__ uint32_t patch_key(int col) {
+  return MT == 16 ? (kPatchKeys >> (3 * (col >> 1))) & 7u : (uint32_t)(col >> 1) & 7u;
+}
 
 constexpr int kWStage = 256 * 128;                 // one K-step of weights: 256 rows x 128 B
 constexpr int kPitch = 18;                         // patch row pitch in pixels (16-wide patches leave two columns unused)
@@ -71,11 +75,14 @@ static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16
 static_assert(256 * 512 <= kLdsSteps, "epilogue staging (256 px x 256 ch bf16) must not reach the step table");
 static_assert(kLdsTotal <= 160 * 1024, "one workgroup's LDS is at most the CU's 160 KiB");
 
-template <typename T>
+template <typename T, int MT = 16>
 __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchParams p) {
   using x4_t = typename H16<T>::x4;
   using x8_t = typename H16<T>::x8;
-  constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
+  static_assert(MT == 16 || MT == 32, "MFMA tile");
+  constexpr int TCO = 64 / MT, TPX = 128 / MT;     // accumulator tiles per wave: 64 channels x 128 pixels (16x16: 4 x 8, 32x32: 2 x 4)
+  constexpr int AREGS = MT * MT / 64;
+  using acc_t = typename Mma<T, MT>::acc_t;
   __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
   char* const steps_lds = smem + kLdsSteps;
   char* const bias_lds = smem + kLdsBias;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       const int i = idx / kPitch, j = idx - i * kPitch;
       const int ys = G.conv_stride * y0 + G.oy + i * G.step, xs = G.conv_stride * x0 + G.ox + j * G.step;
       const bool ok = idx < G.npx && j < G.PW && ys >= 0 && ys < G.H && xs >= 0 && xs < G.W;
-      return ok ? ((uint32_t)((n * G.H + ys) * G.W + xs) * (uint32_t)(G.pix_stride * 2)) | patch_key(j) : kInvalidOff;
+      return ok ? ((uint32_t)((n * G.H + ys) * G.W + xs) * (uint32_t)(G.pix_stride * 2)) | patch_key<MT>(j) : kInvalidOff;
     };
     // the in-loop form: addresses from the tile's offset table, everything else from registers (no scalar loads)
     auto issue_patch_tab = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
         if (blk * 8 >= npx) continue;                           // wave-uniform: nothing of this block is inside the patch
         const int idx = blk * 8 + (lane >> 3);
         const int i = idx / kPitch, j = idx - i * kPitch;
-        const int ch = (lane & 7) ^ (int)patch_key(j);          // swizzle by the patch COLUMN: the same for every tap row
+        const int ch = (lane & 7) ^ (int)patch_key<MT>(j);      // swizzle by the patch COLUMN: the same for every tap row
         const int ys = yb + i * step, xs = xb + j * step;
         const bool ok = idx < npx && j < PW && ys >= 0 && ys < H && xs >= 0 && xs < W;
         const uint32_t off = ok ? (uint32_t)((n * H + ys) * W + xs) * (uint32_t)ps2 + c0b + (uint32_t)ch * 16u : kInvalidOff;
@@ -174,11 +181,13 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       }
     };
 
-    f32x4 acc[TCO][TPX];
+    acc_t acc[TCO][TPX];
 #pragma unroll
     for (int i = 0; i < TCO; ++i)
 #pragma unroll
-      for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TPX; ++j)
+#pragma unroll
+        for (int e = 0; e < AREGS; ++e) acc[i][j][e] = 0.f;
 
     // this tile's offset tables (read by the in-loop requests, all of them behind the first K-step's barrier)
     for (int g = 0; g < p.n_geom; ++g)
@@ -222,11 +231,42 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
 
       const char* const wt = smem + (t & 1) * kWStage;
       const char* const pbase = smem + kLdsPatch + pbuf * kPatchBuf;
+      if constexpr (MT == 32) {
+        // 32x32x16 MFMAs: a K-step is four sub-steps of K = 16; a pixel fragment = two patch rows of 16 columns (lane bit 4 = the row),
+        // lane half h32 supplies k = 16 s + 8 h32 .. + 7 = chunk 2 s + h32.  Fragments double-buffered over the sub-steps.
+        const int r32 = lane & 31, h32 = lane >> 5;
+        const char* const bb = pbase + tap_bytes + (uint32_t)(((wpx * 8 + (r32 >> 4)) * kPitch + (r32 & 15)) * 128);
+        const uint32_t bsw = patch_key<32>((r32 & 15) + dxo);
+        auto lda = [&](int sub, int i) { return *reinterpret_cast<const u32x4*>(wt + swz<128>((wco * TCO + i) * 32 + r32, 2 * sub + h32)); };
+        auto ldb = [&](int sub, int j) { return *reinterpret_cast<const u32x4*>(bb + j * (2 * kPitch * 128) + ((((uint32_t)(2 * sub + h32)) ^ bsw) << 4)); };
+        u32x4 fa[2][TCO], fb[2][TPX];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) fa[0][i] = lda(0, i);
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) fb[0][j] = ldb(0, j);
+        if (more) issue_w(t + 1, (t + 1) & 1);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (sub + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) fa[(sub + 1) & 1][i] = lda(sub + 1, i);
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) fb[(sub + 1) & 1][j] = ldb(sub + 1, j);
+          }
+          if (sub == 1 && next_patch) issue_patch_tab(nx_geom, nx_c0b, nx_k0, nx_k1, pbuf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) acc[i][j] = H16<T>::mfma32(fa[sub & 1][i], fb[sub & 1][j], acc[i][j]);
+        }
+      } else {
       // Fragment addresses: row index and swizzle of the weights depend on the lane only; a pixel fragment j of the
       // wave is patch row (8 wpx + j + dy), columns fr + dx - with the swizzle keyed on the COLUMN its term is the same
       // for all eight j, which are then reached by immediate offsets of one row pitch (kPitch * 128 bytes).
       const char* const bb = pbase + tap_bytes + (uint32_t)((wpx * TPX * kPitch + fr) * 128);
-      const uint32_t bsw = patch_key(fr + dxo);
+      const uint32_t bsw = patch_key<16>(fr + dxo);
       // Fragment pipeline: the pixel fragments are read two at a time, one pair ahead of the eight MFMAs that use
       // them, and the second k-step's weight fragments during the first k-step - so the LDS reads of a wave run
       // under its own MFMAs instead of in a burst after the barrier that all eight waves issue (and wait for) together.
@@ -289,6 +329,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
       __builtin_amdgcn_sched_barrier(0);
       mma8(a1, bq0, S2{});
       mma8(a1, bq1, S3{});
+          }
     }
 #ifdef OKP_PATCH_STAMPS
     {
@@ -306,16 +347,20 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_kernel(const OkpPatchPara
     // ---- epilogue: bias, bf16, transposition through LDS, residual + ReLU on the way out, 512-byte pixel rows ----
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
-      const int co_l = (wco * TCO + i) * 16 + 4 * fh;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + co_l * 4);
 #pragma unroll
-      for (int j = 0; j < TPX; ++j) {
-        const int prow = (wpx * TPX + j) * 16 + fr;
-        char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
-        x4_t o;
+      for (int g = 0; g < AREGS / 4; ++g) {
+        // accumulator rows: 16x16 -> 4 (lane >> 4) + e; 32x32 -> 8 g + 4 (lane >> 5) + e (four consecutive channels per lane and group)
+        const int co_l = (wco * TCO + i) * MT + (MT == 32 ? 8 * g + 4 * (lane >> 5) : 4 * fh);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + co_l * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][e] + bv[e]);
-        *reinterpret_cast<x4_t*>(dst) = o;
+        for (int j = 0; j < TPX; ++j) {
+          const int prow = (wpx * TPX + j) * MT + (lane & (MT - 1));
+          char* dst = smem + prow * 512 + ((((co_l * 2) >> 4) ^ (prow & 7)) << 4) + ((co_l * 2) & 15);
+          x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (T)(acc[i][j][4 * g + e] + bv[e]);
+          *reinterpret_cast<x4_t*>(dst) = o;
+        }
       }
     }
     __syncthreads();
@@ -440,8 +485,11 @@ int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& q, hipStr
   p.dbg = dbg;
 #endif
   const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
-  if (plan->dtype == OKP_BF16) hipLaunchKernelGGL(okp_igemm_patch_kernel<__bf16>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(okp_igemm_patch_kernel<_Float16>, grid, block, 0, stream, p);
+  if (q.mfma32) {         // tile 14: the 32x32x16 instantiation (same wave tile; kept for the MFMA-shape A/B, never the heuristic's choice)
+    if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 32>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 32>), grid, block, 0, stream, p);
+  } else if (plan->dtype == OKP_BF16) hipLaunchKernelGGL((okp_igemm_patch_kernel<__bf16, 16>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((okp_igemm_patch_kernel<_Float16, 16>), grid, block, 0, stream, p);
 #ifdef OKP_PATCH_STAMPS
   if (getenv("OKP_PATCH_STAMPS_PRINT")) {
     (void)hipStreamSynchronize(stream);

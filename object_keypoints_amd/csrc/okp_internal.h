@@ -130,6 +130,7 @@ struct OkpIgemmParams {
   void* out16;             // OKP_F32X3: optional fp16 copy of the result (same pixel mapping as out); out may then be NULL
   int32_t out16_pix_stride, res16;   // res16: the residual tensor is fp16
   int32_t out_sub2, OH2, OW2;        // OKP_F32X3: the fp32 output keeps even rows / columns only (tensor of OH2 x OW2 pixels); out16 is full size
+  int32_t mfma32;                    // tile 14: the patch-resident 16-bit kernel on 32x32x16 MFMAs (experiment)
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 

@@ -12,12 +12,12 @@ rng = np.random.default_rng(0)
 n = 64
 
 
-def conv_case(hw, cin, stride, scale, dtype=torch.bfloat16):
+def conv_case(hw, cin, stride, scale, dtype=torch.bfloat16, tile=0):
     wt = (rng.standard_normal((256, cin, 3, 3)) / np.sqrt(cin * 9) * scale).astype(np.float32)
     plan = ops.ConvPlan(dtype, [cin], [stride], 256, conv_taps(wt), np.zeros(256, np.float32), relu=True)
     x = ops.Act((torch.randn(n, hw * stride, hw * stride, cin, device=dev) * scale).to(torch.bfloat16 if dtype == torch.bfloat16 else torch.float32 if dtype == ops.F32X3 else dtype))
     out = ops.Act.empty(n if dtype != ops.F32X3 else n, hw, hw, 256, x.t.dtype, dev)
-    return lambda: plan([x], out, hw, hw)
+    return lambda: plan([x], out, hw, hw, tile=tile)
 
 
 def fire_case(hw):
@@ -37,12 +37,21 @@ def stem_case():
     return lambda: pre0(frames, torch.bfloat16) if False else net.backbone.stem(frames, torch.bfloat16)
 
 
-cases = [("patch kernel, 3x3 256->256 at 64x64, random operands", conv_case(64, 256, 1, 1.0)),
-         ("patch kernel, 3x3 256->256 at 64x64, all-zero operands", conv_case(64, 256, 1, 0.0)),
-         ("patch kernel, 3x3 256->256 at 128x128, random operands", conv_case(128, 256, 1, 1.0)),
-         ("patch kernel, stride-2 3x3 128->256 at 128x128", conv_case(128, 128, 2, 1.0)),
-         ("okp_fire2 256->128->256 at 64x64", fire_case(64)),
-         ("okp_fire2 256->128->256 at 32x32", fire_case(32))]
+# usage: probe_kernel_power.py [shapes]   (shapes: 16x16x32 against 32x32x16 instantiation of the patch kernel, tile 13 / 14, J per launch)
+if len(sys.argv) > 1 and sys.argv[1] == "shapes":
+    cases = []
+    for hw, cin, st in ((64, 256, 1), (128, 256, 1), (64, 256, 2)):
+        for tile, nm in ((13, "16x16x32"), (14, "32x32x16"), (13, "16x16x32"), (14, "32x32x16")):
+            cases.append((f"patch kernel {nm}, 3x3 {cin}->256 at {hw}x{hw} stride {st}, random operands", conv_case(hw, cin, st, 1.0, tile=tile)))
+    cases.append(("patch kernel 16x16x32, 3x3 256->256 at 64x64, all-zero operands", conv_case(64, 256, 1, 0.0, tile=13)))
+    cases.append(("patch kernel 32x32x16, 3x3 256->256 at 64x64, all-zero operands", conv_case(64, 256, 1, 0.0, tile=14)))
+else:
+  cases = [("patch kernel, 3x3 256->256 at 64x64, random operands", conv_case(64, 256, 1, 1.0)),
+           ("patch kernel, 3x3 256->256 at 64x64, all-zero operands", conv_case(64, 256, 1, 0.0)),
+           ("patch kernel, 3x3 256->256 at 128x128, random operands", conv_case(128, 256, 1, 1.0)),
+           ("patch kernel, stride-2 3x3 128->256 at 128x128", conv_case(128, 128, 2, 1.0)),
+           ("okp_fire2 256->128->256 at 64x64", fire_case(64)),
+           ("okp_fire2 256->128->256 at 32x32", fire_case(32))]
 with torch.no_grad():
     for name, fn in cases:
         for _ in range(20): fn()
@@ -53,4 +62,4 @@ with torch.no_grad():
         for _ in range(50): fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
-        print(f"{name:62s} {us:8.1f} us per launch   {r['board_W_mean']:7.0f} W   {r['sclk_MHz_mean']:6.0f} MHz   ({r['samples']} samples)" if r else f"{name}: no rocm-smi")
+        print(f"{name:78s} {us:8.1f} us per launch   {r['board_W_mean']:7.0f} W   {r['sclk_MHz_mean']:6.0f} MHz   {r['board_W_mean'] * us * 1e-6:6.3f} J per launch   ({r['samples']} samples)" if r else f"{name}: no rocm-smi")

@@ -416,7 +416,7 @@ def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
         plan = ops.ConvPlan(dtype, [256, 256], [1, 1], 256, taps, b.numpy(), relu=True)
         srcs = [ops.Act.from_nchw(a.to(dev), dtype), ops.Act.from_nchw(c.to(dev), dtype)]
     outs = {}
-    tiles = (6, 13)
+    tiles = (6, 13, 3, 14)          # (14: the patch-resident kernel on 32x32x16 MFMAs, the MFMA-shape experiment: sums in the order of gather tile 3)
     for tile in tiles:
         big = ops.Act(torch.full((n, h, w, 288), -7.0, dtype=dtype, device=dev))
         plan(srcs, big.slice(16, 256), h, w, res=res, tile=tile)
@@ -426,6 +426,7 @@ def test_patch_resident_kernel_matches_gather_kernel(case, dtype):
         got = outs[tile][..., 16:272].permute(0, 3, 1, 2)
         assert float((got - ref).abs().max()) <= _tol(dtype, ref), tile
     assert torch.equal(outs[13], outs[6])
+    assert torch.equal(outs[14], outs[3])
 
 @pytest.mark.gpu
 def test_patch_resident_kernel_refuses_other_shapes():
