@@ -26,6 +26,7 @@
 //    16-byte chunk position inside a row is rotated by 2*(row>>2) so that the 16x16 fragment reads are conflict-free.
 //  * The depth-wise branch reads its 3x3 neighbourhoods from the LDS squeeze tile (runs of 4 pixels share a
 //    3 x 6 window), weights in registers for the duration of the phase.
+#include <cstdio>
 #include <cstring>
 
 #include <cstdlib>
@@ -71,6 +72,15 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
     default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
   }
 }
+
+#ifdef OKP_FIRE_STAMPS
+// Debug build (OKP_EXTRA_CFLAGS=-DOKP_FIRE_STAMPS, printed with OKP_FIRE_STAMPS_PRINT=1; scripts/probe_fire2.py): shader-clock stamps of every
+// wave at the phase boundaries of its workgroup's SECOND tile, workgroups 0..15: [wg][wave 8][8] u32.  OKP_FIRE_NOSKIP=1: timing ablation
+// without the skip requests (wrong results).
+#define F2_STAMP(i) do { if (second && lane == 0 && blockIdx.x < 16) { uint64_t t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(blockIdx.x * 8 + w) * 8 + (i)] = (uint32_t)t_; } } while (0)
+#else
+#define F2_STAMP(i) do {} while (0)
+#endif
 
 template <typename T, int CIN, int MID, int STR>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
@@ -235,6 +245,10 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   for (; tile < p.n_tiles; tile += gridDim.x) {
     int n, y0, x0;
     tile_origin(tile, n, y0, x0);
+#ifdef OKP_FIRE_STAMPS
+    const bool second = tile == (int)(blockIdx.x + gridDim.x);
+#endif
+    F2_STAMP(0);
     // opaque copies: the per-(block, register) pixel arithmetic below is tile-invariant, and hoisting ~100 such
     // values out of the tile loop costs more registers than recomputing them (a multiply-high each)
     int qt = q, tidt = tid;
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         for (int b = 0; b < 2; ++b)
           acc[pb][b] = H16<T>::mfma16(WRING ? wr[b] : w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
     }
+    F2_STAMP(1);
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     u32x4 waf[2][KS2];
 #pragma unroll
@@ -345,6 +360,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     __syncthreads();
+    F2_STAMP(2);
     // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
     {
       // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
@@ -402,6 +418,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
     asm volatile("" ::: "memory");             // keep the stores here (the scheduler otherwise sinks them below phase 2b)
+    F2_STAMP(3);
 
     // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         }
       }
     }
+    F2_STAMP(4);
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
   }
 }
@@ -521,6 +539,30 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
   p.div_rpr = okp_fastdiv((uint32_t)p.RPR);
   const int resident = 256 * (mid == 128 ? 2 : 1);
   const dim3 grid((unsigned)(p.n_tiles < resident ? p.n_tiles : resident)), block((unsigned)(2 * mid));
+#ifdef OKP_FIRE_STAMPS
+  static uint32_t* dbg = nullptr;
+  if (!dbg) (void)hipMalloc((void**)&dbg, 16 * 8 * 8 * 4);
+  (void)hipMemsetAsync(dbg, 0, 16 * 8 * 8 * 4, stream);
+  p.dbg = dbg;
+  struct Print { OkpFire2Params p; int mid; hipStream_t stream; uint32_t* dbg; ~Print() {
+    if (!getenv("OKP_FIRE_STAMPS_PRINT")) return;
+    (void)hipStreamSynchronize(stream);
+    uint32_t h[16 * 8 * 8];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const int nw = mid / 32;
+    printf("fire2 stamps (tile %d x %d interior, %d tiles, %d waves): clocks per wave of the second tile: squeeze GEMM (ring) | s -> LDS + barrier | expand GEMM + stores | depth-wise branch (+ next tile's requests)\n", p.IH, p.IW, p.n_tiles, nw);
+    double sum[4] = {0, 0, 0, 0}; int cnt = 0;
+    for (int wg = 0; wg < 16; ++wg)
+      for (int w = 0; w < nw; ++w) {
+        const uint32_t* a = &h[(wg * 8 + w) * 8];
+        if (!a[4]) continue;
+        if (wg % 5 == 0 && (w == 0 || w == nw - 1)) printf("wg %2d wave %d: %6u | %6u | %6u | %6u\n", wg, w, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3]);
+        for (int i = 0; i < 4; ++i) sum[i] += a[i + 1] - a[i];
+        ++cnt;
+      }
+    if (cnt) printf("mean: %.0f | %.0f | %.0f | %.0f  = %.0f clocks per tile\n", sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, (sum[0] + sum[1] + sum[2] + sum[3]) / cnt);
+  } } print_at_exit{p, mid, stream, dbg};
+#endif
   if (stride == 1) {
     if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 1>), grid, block, 0, stream, p);
     else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 1>), grid, block, 0, stream, p);
@@ -588,6 +630,9 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
     q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.Ho = ho; q.Wo = wo; q.out_ps = a->out.pix_stride;
     q.N = a->n; q.skip = a->skip;
+#ifdef OKP_FIRE_STAMPS
+    if (getenv("OKP_FIRE_NOSKIP")) q.skip = 0;       // timing ablation of the debug build (wrong results): no skip values are requested
+#endif
     if (int e = okp_ensure_frags(squeeze, (hipStream_t)stream)) return e;
     if (int e = okp_ensure_frags(expand, (hipStream_t)stream)) return e;
     q.w1 = squeeze->fragT_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev;
