@@ -215,7 +215,11 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
       // returned (the barrier frees their stage / patch buffer for the next LDS-DMA)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; stage (t+1)&1 and the other patch buffer are free
+#ifdef OKP_X3_ABL_NOCVT                          // timing ablation (wrong results): patches are never split
+      if (false) {
+#else
       if (cvt_self) {
+#endif
         split_patch(pbuf, 18 * (int)((p.geom_ph >> (5 * (w3 & 0xff))) & 31u));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -262,7 +266,9 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
       __builtin_amdgcn_sched_barrier(0);
       // the next group's patch: every request was issued before this step and has landed (this step's barrier); nobody reads that
       // buffer before the next barrier, in front of which every wave waits for its own LDS writes
+#ifndef OKP_X3_ABL_NOCVT
       if (cvt_next) split_patch(pbuf ^ 1, 18 * (int)((p.geom_ph >> (5 * nx_geom)) & 31u));
+#endif
     }
     __syncthreads();                               // all waves done with the last stage and patch before LDS is reused
 
