@@ -253,7 +253,7 @@ def committed_counters(kernel_sig, precision="bf16"):
     cannot run the profiler on itself): HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) and, when present, MFMA-busy / LDS-wait fractions from
     the SQ pass.  Files: profiles/r*_pmc_hbm_traffic.json / r*_sq_counters.json for the bf16 headline,
-    profiles/r*_<precision>_pmc_hbm_traffic.json / ..._sq_counters.json for the others (scripts/profile_r03.sh).  Null when absent."""
+    profiles/r*_<precision>_pmc_hbm_traffic.json / ..._sq_counters.json for the others (scripts/profile_all.sh).  Null when absent."""
     import glob
     import re
     res = {"traffic": None, "traffic_source": None, "mfma_busy": None, "lds_wait": None, "hbm_GBps": None, "counter_source": None,

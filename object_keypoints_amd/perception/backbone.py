@@ -460,7 +460,7 @@ class hg_module(nn.Module):
             low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)
             return self.up2(low3, up1)
         main = torch.cuda.current_stream()
-        side = self._side_stream(x.t.device)
+        skey, side = self._side_stream(x.t.device)
         ops.stream_wait(side, main)                     # x is ready on the side stream
         # Tensor lifetimes across the two streams WITHOUT Tensor.record_stream (the caching allocator answers a recorded use with an
         # event record on the using stream when the tensor dies - a marker packet in the MAIN queue right behind every merge, 6-8 us of
@@ -470,9 +470,10 @@ class hg_module(nn.Module):
         #    does afterwards;
         #  * up1 (side stream's pool) is read by the merge on the main stream: it is kept alive until this side stream next waits for
         #    the main stream (the next fork that uses it), from where on every side-stream kernel comes after that merge.
-        held = _HELD_BRANCH_OUTPUTS.setdefault(side.cuda_stream, [])
+        # (all bookkeeping is keyed by the _SIDE_STREAMS key - device, MAIN stream, level group - not by the side stream's raw handle:
+        #  torch hands out pooled handles, so two entries may share one)
+        held = _HELD_BRANCH_OUTPUTS.setdefault(skey, [])
         held.clear()                                    # (the wait above orders the side stream behind the merges that read these)
-        jkey = (main.cuda_stream, side.cuda_stream)
         joined = False
         try:
             with torch.cuda.stream(side):
@@ -480,11 +481,11 @@ class hg_module(nn.Module):
             # A join covers every branch enqueued on that side stream before it: levels that share a side stream are nested, the inner
             # level's branch is enqueued later and joined first, so the outer level finds its branch already joined and skips the
             # barrier packet (6 us on the main queue).
-            seq = _SIDE_SEQ[side.cuda_stream] = _SIDE_SEQ.get(side.cuda_stream, 0) + 1
+            seq = _SIDE_SEQ[skey] = _SIDE_SEQ.get(skey, 0) + 1
             low3 = self._low_path(x)
-            if _JOINED_SEQ.get(jkey, 0) < seq:
+            if _JOINED_SEQ.get(skey, 0) < seq:
                 ops.stream_wait(main, side)             # join before the merge
-                _JOINED_SEQ[jkey] = _SIDE_SEQ[side.cuda_stream]
+                _JOINED_SEQ[skey] = _SIDE_SEQ.get(skey, seq)
             joined = True
             out = self.up2(low3, up1)
             held.append(up1.t)
@@ -492,7 +493,7 @@ class hg_module(nn.Module):
         finally:
             if not joined:                              # a launch failed between fork and join: x must outlive the branch kernels
                 ops.stream_wait(main, side)
-                _JOINED_SEQ[jkey] = _SIDE_SEQ.get(side.cuda_stream, 0)
+                _JOINED_SEQ[skey] = _SIDE_SEQ.get(skey, 0)
 
     def _low_path(self, x):
         if isinstance(self.low2, _FireSeq):             # innermost level: low1, low2, low3 are one list of fire modules
@@ -507,26 +508,29 @@ class hg_module(nn.Module):
         # keyed by the MAIN stream as well: a pass that runs (or is being captured) on another stream - another host thread, a
         # second pipeline's hipGraph capture - gets its own side streams instead of recording into a foreign capture
         group = _SIDE_STREAM_OF_LEVEL[4 - self.n] if 1 <= self.n <= 4 else 0
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, group)
+        main = torch.cuda.current_stream(device).cuda_stream
+        key = (device.type, device.index, main, group)
         st = _SIDE_STREAMS.get(key)
         if st is None:
-            if len(_SIDE_STREAMS) >= _SIDE_STREAMS_MAX:          # main streams come and go (host threads, captures): oldest entries first
-                for old in list(_SIDE_STREAMS)[:len(_SIDE_STREAMS) - _SIDE_STREAMS_MAX + 1]:
+            # main streams come and go (host threads, captures): oldest entries first - but never an entry of the CURRENT main stream (an
+            # outer level of this very pass may be between its fork and its join on it), and nothing at all while a capture is active
+            # (Stream.synchronize is illegal there, and a pass on another thread may be mid-flight on any entry): the table then simply grows
+            if len(_SIDE_STREAMS) >= _SIDE_STREAMS_MAX and not torch.cuda.is_current_stream_capturing():
+                for old in [k for k in _SIDE_STREAMS if k[2] != main][:len(_SIDE_STREAMS) - _SIDE_STREAMS_MAX + 1]:
                     gone = _SIDE_STREAMS.pop(old)
                     gone.synchronize()
-                    _HELD_BRANCH_OUTPUTS.pop(gone.cuda_stream, None)
-                    _SIDE_SEQ.pop(gone.cuda_stream, None)
-                    for jk in [k for k in _JOINED_SEQ if k[1] == gone.cuda_stream]:
-                        del _JOINED_SEQ[jk]
+                    _HELD_BRANCH_OUTPUTS.pop(old, None)
+                    _SIDE_SEQ.pop(old, None)
+                    _JOINED_SEQ.pop(old, None)
             st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-        return st
+        return key, st
 
 
 _SIDE_STREAMS = {}
 _SIDE_STREAMS_MAX = 48           # (main stream, level group) entries kept: 16 main streams' worth
 _SIDE_STREAM_OF_LEVEL = (0, 1, 2, 2)   # side stream of the 64x64, 32x32, 16x16, 8x8 level (every other assignment swept: within noise, DESIGN App. A)
-_SIDE_SEQ, _JOINED_SEQ = {}, {}  # branches enqueued per side stream; (main, side) -> newest branch a join has covered
-_HELD_BRANCH_OUTPUTS = {}        # side stream handle -> branch outputs the main stream may still be reading (hg_module.forward)
+_SIDE_SEQ, _JOINED_SEQ = {}, {}  # per _SIDE_STREAMS key: branches enqueued on that side stream; newest branch a join of its main stream has covered
+_HELD_BRANCH_OUTPUTS = {}        # _SIDE_STREAMS key -> branch outputs the main stream may still be reading (hg_module.forward)
 
 
 class _MergeMod(nn.Sequential):

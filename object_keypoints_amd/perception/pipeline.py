@@ -53,6 +53,12 @@ class _OpaqueGlobal:
 
 
 MAX_OPAQUE_GLOBALS = 256        # a training checkpoint names a handful of foreign classes; a file that names more is not one
+# torch.serialization.safe_globals is PROCESS-global, not thread-local: while the stubs of one checkpoint are registered, a concurrent
+# torch.load(weights_only=True) on another thread would resolve those foreign names to inert stubs instead of refusing them.  The
+# loads of this module take the lock; other threads' own torch.load calls cannot be held off from here - load model files before
+# starting threads that unpickle untrusted data.
+import threading
+_OPAQUE_LOAD_LOCK = threading.Lock()
 
 
 def _load_with_opaque_globals(path):
@@ -63,15 +69,21 @@ def _load_with_opaque_globals(path):
     run; what a stub 'constructs' is another stub.  Needed for the reference's training checkpoints: pytorch-lightning 1.2.1
     (requirements.txt) keys the `callbacks` dict of a checkpoint by the callback CLASS (ModelCheckpoint, scripts/train.py:170) and
     stores hyper-parameter objects.  Residual trust: torch's VM itself and the tensor / storage rebuilders on its default allow-list
-    (tests/test_host_logic.py pins that the allow-list names nothing outside torch, collections and builtins' containers)."""
-    names = list(torch.serialization.get_unsafe_globals_in_checkpoint(path))
+    (tests/test_host_logic.py pins that the allow-list names nothing outside torch, collections and builtins' containers).
+    Zip-format files only (torch.save's format since 1.6; get_unsafe_globals_in_checkpoint reads nothing else): a legacy-format
+    checkpoint that names foreign globals is refused with that explanation - re-save it with a current torch."""
+    try:
+        names = list(torch.serialization.get_unsafe_globals_in_checkpoint(path))
+    except Exception as e:
+        raise OkpError(f"{path}: cannot list the globals of this file ({type(e).__name__}: {e}); checkpoints that name classes outside torch "
+                       "must be in torch.save's zip format (re-save a legacy-format file with a current torch)") from e
     if len(names) > MAX_OPAQUE_GLOBALS:
         raise OkpError(f"{path}: names {len(names)} globals outside torch's weights-only allow-list; not a training checkpoint")
     stubs = []
     for full in names:
         module, _, name = full.rpartition(".")
         stubs.append((type(name or "opaque", (_OpaqueGlobal,), {"__module__": "okp_opaque." + module}), full))
-    with torch.serialization.safe_globals(stubs):
+    with _OPAQUE_LOAD_LOCK, torch.serialization.safe_globals(stubs):
         return torch.load(path, map_location="cpu", weights_only=True)
 
 
