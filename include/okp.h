@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 4     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream */
+#define OKP_ABI_VERSION 5     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
+                                 5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14 */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -134,7 +135,7 @@ typedef struct okp_conv_args {
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
-/* The tile code (1..8, 13) the launch heuristic picks for these args when args->tile == 0. */
+/* The tile code (1..8, 13; never 14) the launch heuristic picks for these args when args->tile == 0. */
 int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* args);
 /* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
 int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
@@ -145,6 +146,9 @@ int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
  * squeeze: 1-tap plan cin -> mid (bias = folded bn1, no activation); expand: 1-tap plan mid -> half (bias = first half
  * of folded bn2); dw_w_dev [9][half] / dw_bias_dev [half]: depth-wise weights with the second half of bn2 folded.
  * cin and mid multiples of 64, mid == half <= 256.  out has 2*half channels: [expand | depth-wise].
+ * Plans of one type: OKP_BF16 / OKP_F16 (okp_fire2.hip: the shapes okp_fire_forward reports in its error message), or OKP_F32X3
+ * (okp_fire_x3.hip: fp32 x / out, three-term products; 256 -> 128 -> 256 at stride 1 with skip).  OKP_EINVAL for other shapes: run the
+ * squeeze plan and the fused tail (okp_conv_forward with dw_*) instead.
  * ---------------------------------------------------------------------------------- */
 typedef struct okp_fire_args {
   int32_t n;
@@ -230,11 +234,13 @@ int okp_preprocess_u8(int dtype, const uint8_t* frames_nhwc_dev, int32_t n, int3
  * ---------------------------------------------------------------------------------- */
 typedef struct okp_stem okp_stem;
 okp_stem* okp_stem_create(const float* w_host, const float* bias_host);                       /* bf16 */
-okp_stem* okp_stem_create_dtype(int dtype, const float* w_host, const float* bias_host);    /* OKP_BF16 or OKP_F16 */
+okp_stem* okp_stem_create_dtype(int dtype, const float* w_host, const float* bias_host);    /* OKP_BF16, OKP_F16, or OKP_F32X3: the split-product
+                                                                                               form (fp32 NHWC output; okp_stem_forward_nchw only) */
 void okp_stem_destroy(okp_stem* stem);
 int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream);
 /* Same layer straight from the reference's input layout, fp32 NCHW frames (n,3,h,w): the bf16 rounding and the zero
- * padding happen while the input patch is staged in LDS, so okp_pack_frames and its round trip through HBM are not needed. */
+ * padding happen while the input patch is staged in LDS, so okp_pack_frames and its round trip through HBM are not needed.
+ * OKP_F32X3 plans: `out` is an fp32 NHWC view; every product is the three-term fp16 split (fp32-grade, as OKP_F32X3 convolution plans). */
 int okp_stem_forward_nchw(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream);
 
 /* ------------------------------------------------------------------------------------

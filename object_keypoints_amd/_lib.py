@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 LIB_PATH = os.environ.get("OKP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_hip.so")   # OKP_LIB: A/B builds
 
 OKP_F32, OKP_BF16, OKP_F16, OKP_F32X3 = 0, 1, 2, 3
-OKP_ABI = 4
+OKP_ABI = 5
 CAM_EQUIDISTANT, CAM_RADTAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 HEAD_MAX_OUT = 32
