@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     from object_keypoints_amd import _lib
     bound = {n for n, _, _ in _lib.SIGNATURES}
     assert declared == bound, f"ctypes binding and header disagree: {declared ^ bound}"
-    assert _lib.lib().okp_abi_version() == 4
+    assert _lib.lib().okp_abi_version() == 5 == _lib.OKP_ABI
 
 
 def test_struct_layouts_match_the_header():
