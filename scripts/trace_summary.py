@@ -4,16 +4,28 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 packs = [i for i, r in enumerate(rows) if "okp_pack_frames" in r["Kernel_Name"] or "okp_preprocess" in r["Kernel_Name"]]
-if not packs:      # bf16 path: the stem kernel reads the frames itself and is the first launch of a step
-    packs = [i for i, r in enumerate(rows) if "okp_stem_kernel" in r["Kernel_Name"]]
-sel = rows[packs[-1]:]
+if not packs:      # the stem kernels read the frames themselves and are the first launch of a step
+    packs = [i for i, r in enumerate(rows) if "okp_stem_kernel" in r["Kernel_Name"] or "okp_stem_x3_kernel" in r["Kernel_Name"]]
+first = len(packs) - 1
+# (fp32-storage configurations run the stem and pre[1] in two frame chunks: the launches then come in pairs - a short gap inside a step, a long
+#  one between steps - and the step starts at the first of its pair)
+ts = lambda i: int(rows[packs[i]]["Start_Timestamp"])
+if first >= 2 and (ts(first) - ts(first - 1)) < 0.5 * (ts(first - 1) - ts(first - 2)):
+    first -= 1
+sel = rows[packs[first]:]
 def short(n):
+    if "okp_igemm_patch_x3_kernel" in n:
+        return "okp_igemm_patch_x3_kernel"
     if "okp_igemm_patch_kernel" in n:
         return "okp_igemm_patch_kernel"
+    if "okp_igemm_kernel<" in n:
+        m = re.search(r"okp_igemm_kernel<(?:\(anonymous namespace\)::)?(\w+), (\d+), (\d+), \d+, \d+, (\d+), (\d+), (\d+), (\d+)>", n)
+        if m:
+            return f"igemm<{m.group(1)},{m.group(2)}x{m.group(3)},ring{m.group(4)}x{m.group(5)}B,mfma{m.group(6)},src{m.group(7)}>"
     if "okp_igemm_kernelI" in n:
         m = re.search(r"okp_igemm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
         return f"igemm<{ 'bf16' if 'DF16b' in m.group(1) else 'f32'},{m.group(2)}x{m.group(3)},ring{m.group(4)}x{m.group(5)}B,mfma{m.group(6)},src{m.group(7)}>"
-    for k in ("okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_heads_kernel", "okp_peak_nms", "okp_stem_kernel", "okp_fire_chain_kernel", "okp_fire2_kernel", "okp_group_objects", "okp_lift_peaks"):
+    for k in ("okp_stem_x3_kernel", "okp_fire_x3_kernel", "okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_heads_kernel", "okp_peak_nms", "okp_stem_kernel", "okp_fire_chain_kernel", "okp_fire2_kernel", "okp_group_objects", "okp_lift_peaks"):
         if k in n: return k
     return n[:40]
 t0 = int(sel[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in sel)
