@@ -408,14 +408,14 @@ def run_precision(name, ctx, steps, warmup, workload="batch64"):
         ctx["bumps"][workload] = bump_maps(ctx["start"], batch, dev, wl)
     b_heat, b_depth, b_centers, n_peaks = ctx["bumps"][workload]
     # dominant kernel: 16-bit = the patch-resident 3x3 kernel (tile 13, one symbol for one and two sources); fp32 = 256x256 gather tile;
-    # float32mix has two populations: the HBM-bound 128x128 split tiles (1x1 convolutions / fire modules on fp32 tensors: the largest
-    # share of its kernel time) and the MFMA-bound 256x256 split tile (`cnvs`, transposed convolutions)
+    # float32x3 = the split-product patch kernel; float32mix has three populations (below)
     # split-product configurations: the patch-resident split kernel (tile 13 of fp32 plans: every 3x3 / transposed convolution of
     # float32x3, `cnvs` and the transposed convolutions of float32mix - whose fp16 branches are float16 plans and do not match)
     gather = name == "f32"
     pops = {"mfma": (dtype, (3,) if gather else (13,), 1 if gather else None, None)}
     if name == "f32mix":
         pops["hbm"] = (dtype, (2,), None, True)
+        pops["mfma16"] = (torch.float16, (13,), None, None)        # the single-term fp16 branches: the fp16 patch kernel, the largest share of its kernel time
     timer = KernelTimer(pops)
     ops.LAUNCH_HOOK = timer
 
@@ -475,19 +475,29 @@ def run_precision(name, ctx, steps, warmup, workload="batch64"):
     res = {"value": value, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "gflop_per_frame": gf,
            "conv_stack_tflops_per_gpu": gf * value / world / 1e3, "roofline": roof}
     if name == "f32mix":
-        # the population that takes the largest share of this configuration's kernel time is HBM-bound: it is the `roofline` object,
-        # the MFMA-bound split tile moves to `roofline_mfma`
+        # three populations: `roofline` = the kernel with the largest share of this configuration's kernel time, the fp16 patch kernel of its
+        # single-term residual branches (conv1 / conv2 of pre[1], pre[2], inters[0]); `roofline_mfma` = the split-product patch kernel (`cnvs`,
+        # transposed convolutions: three MFMA terms); `roofline_hbm` = the 128x128 split tiles on fp32 tensors (1x1 convolutions)
         n_h, ms_h, _, bytes_h = timer.summary("hbm")
         ctr_h = committed_counters(KERNEL_SIG["f32mix_hbm"], name)
         ach = bytes_h / (ms_h * 1e-3) / 1e9 if ms_h > 0 else 0.0
         res["roofline_mfma"] = roof
-        res["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAME["f32mix_hbm"], "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                           "frac": ach / PEAK_HBM_GBPS, "traffic": ctr_h["traffic"], "traffic_unit": "HBM bytes/launch",
-                           "traffic_source": ctr_h["traffic_source"], "hbm_GBps": ctr_h["hbm_GBps"], "counter_source": ctr_h["counter_source"],
-                           "counter_commit": ctr_h["counter_commit"], "stale": ctr_h["stale"],
-                           "launches_timed": n_h, "avg_launch_us": (ms_h * 1e3 / n_h) if n_h else None,
-                           "avg_algorithmic_MB_per_launch": (bytes_h / n_h / 1e6) if n_h else None,
-                           "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f32mix_hbm"], name)}
+        res["roofline_hbm"] = {"bound": "hbm", "kernel": KERNEL_NAME["f32mix_hbm"], "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                               "frac": ach / PEAK_HBM_GBPS, "traffic": ctr_h["traffic"], "traffic_unit": "HBM bytes/launch",
+                               "traffic_source": ctr_h["traffic_source"], "hbm_GBps": ctr_h["hbm_GBps"], "counter_source": ctr_h["counter_source"],
+                               "counter_commit": ctr_h["counter_commit"], "stale": ctr_h["stale"],
+                               "launches_timed": n_h, "avg_launch_us": (ms_h * 1e3 / n_h) if n_h else None,
+                               "avg_algorithmic_MB_per_launch": (bytes_h / n_h / 1e6) if n_h else None,
+                               "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f32mix_hbm"], name)}
+        n_6, ms_6, fl_6, _ = timer.summary("mfma16")
+        ctr_6 = committed_counters(KERNEL_SIG["f16"], name)
+        ach6 = fl_6 / (ms_6 * 1e-3) / 1e12 if ms_6 > 0 else 0.0
+        res["roofline"] = {"bound": "mfma", "kernel": KERNEL_NAME["f16"] + " (single-term residual branches)", "achieved": ach6, "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach6 / peak, "traffic": ctr_6["traffic"], "traffic_unit": "HBM bytes/launch", "traffic_source": ctr_6["traffic_source"],
+                           "mfma_busy": ctr_6["mfma_busy"], "lds_wait": ctr_6["lds_wait"], "hbm_GBps": ctr_6["hbm_GBps"], "counter_source": ctr_6["counter_source"],
+                           "counter_commit": ctr_6["counter_commit"], "stale": ctr_6["stale"], "launches_timed": n_6,
+                           "avg_launch_us": (ms_6 * 1e3 / n_6) if n_6 else None, "avg_gflop_per_launch": (fl_6 / n_6 / 1e9) if n_6 else None, "mfma_terms": 1,
+                           "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f16"], name)}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
     if name == "f32mix":
