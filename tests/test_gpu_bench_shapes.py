@@ -164,11 +164,12 @@ def test_fused_heads_at_bench_batch(dtype):
         assert float((a - b).abs().max()) <= 2e-2 * scale + 2e-3
 
 
-@pytest.mark.parametrize("side,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (True, "float32mix")])
+@pytest.mark.parametrize("side,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (True, "float32mix"), (True, "float32x3")])
 def test_graph_replay_equals_eager_at_batch64(side, dtype):
     """hipGraph replays of the 64-frame step are bit-equal to the eager step, five replays in a row, with the hourglass branches
-    captured serially and forked onto side streams (bf16), and for the mixed configuration (fp16 sub-networks, casts, fp16 side
-    outputs and the chunked high-resolution front inside the capture)."""
+    captured serially and forked onto side streams (bf16), for the mixed configuration (fp16 sub-networks, casts, fp16 side
+    outputs and the chunked high-resolution front inside the capture) and for the split-product configuration (its stem, patch-resident
+    and one-launch fire kernels of round 5 under capture)."""
     from object_keypoints_amd.perception import pipeline as pp
     from object_keypoints_amd.perception.utils import camera_utils as cu
     from oracle import pipeline as op

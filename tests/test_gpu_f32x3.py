@@ -568,3 +568,26 @@ def test_float32mix_is_audited_by_default_when_loaded():
     assert raw.configuration() == ops.F32MIX and not hasattr(raw, "audit")
     with pytest.raises(pp.OkpError):
         pp.load_keypoint_net(own, compute_dtype=ops.F32MIX, audit_frames="always")
+
+
+def test_split_stem_at_the_bench_chunk_of_32_frames():
+    """okp_stem_x3_kernel on one front chunk of the 64-frame float32x3 step (32 frames of 511 x 511: 16 384 tiles on the persistent
+    512-workgroup grid, 1.07 GB of output) against torch's CPU convolution on frames 0, 15 and 31; a frame gives the same bits wherever
+    it sits in the batch."""
+    from object_keypoints_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    x = torch.randn((32, 3, 511, 511), generator=g, device=dev)
+    wt = _rand((128, 3, 7, 7), 61) * (1.0 / np.sqrt(147.0))
+    b = _rand((128,), 62) * 0.1
+    with ops.f32_split():
+        plan = ops.StemPlan(wt.numpy(), b.numpy(), torch.float32)
+    out = ops.Act.empty(32, 256, 256, 128, torch.float32, dev)
+    plan.from_nchw(x, out)
+    for i in (0, 15, 31):
+        ref = F.relu(F.conv2d(x[i:i + 1].cpu().double(), wt.double(), b.double(), stride=2, padding=3)).float()
+        got = out.t[i:i + 1].permute(0, 3, 1, 2).cpu()
+        assert float((got - ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max())), i
+    rev = ops.Act.empty(32, 256, 256, 128, torch.float32, dev)
+    plan.from_nchw(torch.flip(x, dims=[0]).contiguous(), rev)
+    assert torch.equal(torch.flip(rev.t, dims=[0]), out.t)
