@@ -256,3 +256,73 @@ def test_split_fire_module_in_one_launch(n, h, w):
     scale = 1.0 + float(ref.abs().max())
     assert float((g - ref).abs().max()) <= 2e-5 * scale
     assert float((got.t - two.t).abs().max()) <= 1e-5 * scale
+
+
+def test_patch_x3_random_shapes_against_the_gather_tile():
+    """Seeded sweep over the shapes the heuristic can hand to the split-product patch kernel: input channels 32..160 (one to five chunks,
+    ragged against the 64-channel pairs), one or two channel tiles, 1..5 frames, maps of 16..80 pixels per side in steps of 16 (so that
+    tiles sit on every image border), stride 1 / 2, with and without residual, with and without a strided 1x1 second source.  The
+    gather tile of the same plan is the checker (the same products in another order), a CPU fp64 convolution the anchor for a sample."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    rng = np.random.default_rng(20251004)
+    dev = torch.device("cuda:0")
+    for case in range(24):
+        cin = int(rng.choice([32, 64, 96, 128, 160]))
+        cout = int(rng.choice([256, 256, 512]))
+        n = int(rng.integers(1, 6))
+        h, w = (int(v) for v in rng.choice([16, 32, 48, 64, 80], size=2))
+        stride = int(rng.choice([1, 1, 2]))
+        res = bool(rng.integers(0, 2))
+        skip = int(rng.choice([0, 0, 32, 64])) if stride == 1 else 0
+        g = torch.Generator(device=dev); g.manual_seed(1000 + case)
+        x = torch.randn((n, h * stride, w * stride, cin), generator=g, device=dev)
+        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        taps, cins, strides, srcs = conv_taps(wt), [cin], [stride], [ops.Act(x)]
+        if skip:
+            ws = (rng.standard_normal((cout, skip)) / np.sqrt(skip)).astype(np.float32)
+            taps = taps + [(1, 0, 0, ws)]; cins.append(skip); strides.append(2)
+            srcs.append(ops.Act(torch.randn((n, 2 * h, 2 * w, skip), generator=g, device=dev)))
+        r = ops.Act(torch.randn((n, h, w, cout), generator=g, device=dev)) if res else None
+        with ops.f32_split():
+            plan = ops.ConvPlan(torch.float32, cins, strides, cout, taps, b, relu=True)
+        o13 = ops.Act.empty(n, h, w, cout, torch.float32, dev)
+        o3 = ops.Act.empty(n, h, w, cout, torch.float32, dev)
+        plan(srcs, o13, h, w, res=r, tile=13)
+        plan(srcs, o3, h, w, res=r, tile=3)
+        scale = 1.0 + float(o3.t.abs().max())
+        assert float((o13.t - o3.t).abs().max()) <= 1e-5 * scale, (case, cin, cout, n, h, w, stride, res, skip)
+        if case % 6 == 0:
+            ref = F.conv2d(x[:1].permute(0, 3, 1, 2).cpu().double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), stride=stride, padding=1)
+            if skip:
+                ref = ref + F.conv2d(srcs[1].t[:1].permute(0, 3, 1, 2).cpu().double(), torch.from_numpy(ws).double()[:, :, None, None], stride=2)
+            if res:
+                ref = ref + r.t[:1].permute(0, 3, 1, 2).cpu().double()
+            assert float((o13.t[:1].permute(0, 3, 1, 2).cpu().double() - F.relu(ref)).abs().max()) <= 2e-5 * scale, case
+
+
+def test_fire_x3_random_map_sizes_against_the_two_launch_path():
+    """Seeded sweep of okp_fire_x3 over map sizes 16..70 (partial tiles in both directions, maps narrower than a tile row) and 1..4 frames
+    against the squeeze + fused-tail launches of the same module."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    o = onet.load_synthetic(onet.fire_module(256, 256), seed=33)
+    m = bb.fire_module(256, 256)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    rng = np.random.default_rng(7)
+    dev = torch.device("cuda:0")
+    for case in range(12):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(16, 71)), int(rng.integers(16, 71))
+        g = torch.Generator(device=dev); g.manual_seed(case)
+        x = ops.Act(torch.randn((n, h, w, 256), generator=g, device=dev))
+        with ops.f32_split():
+            got = m(x)
+            ops.FUSE_FIRE_X3 = False
+            try:
+                two = m(x)
+            finally:
+                ops.FUSE_FIRE_X3 = True
+        assert float((got.t - two.t).abs().max()) <= 1e-5 * (1.0 + float(two.t.abs().max())), (case, n, h, w)
