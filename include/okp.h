@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 5     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
-                                 5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14 */
+#define OKP_ABI_VERSION 6     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
+                                 5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14
+                                 6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -132,6 +133,18 @@ typedef struct okp_conv_args {
    * stride-2 projected skip of the next residual block (py_utils/utils.py:177-185: stem -> pre[1], pre[1] -> pre[2]) while the block's
    * conv1 reads the fp16 copy: three quarters of the fp32 bytes are never read. */
   int32_t out_subsample;
+  /* PAIR FORMAT (OKP_F32X3 plans on the patch-resident kernel, tile 13, only).  A pair-format tensor has the geometry of an fp32 tensor
+   * (4 bytes per element, the same h / w / pix_stride / bytes) but every aligned group of 8 channels holds
+   *     [ hi(c0) .. hi(c0+7) | lo(c0) .. lo(c0+7) ]   as 2 x 8 fp16,   hi = fp16(x), lo = fp16(x - hi)
+   * - exactly what the kernel's in-LDS split makes of the 8 fp32 values (okp_igemm_patch_x3.hip), so a consumer that is handed a pair
+   * tensor skips that split and computes bit-identical results.  A tensor whose only readers are 3x3 convolutions of split-product plans
+   * (conv1 -> conv2 inside a residual block, hourglass -> cnvs, py_utils/utils.py:158-185, py_utils/modules.py:84-92) is written this way
+   * by its producer: the conversion happens once per element in the producer's epilogue instead of once per element, chunk and consumer
+   * tile on landed LDS patches, between the K-steps.
+   * src_pairs: bit s set = src[s] is in pair format (cin[s] % 32 == 0).  out_pairs != 0: `out` is written in pair format (cout % 8 == 0;
+   * the residual, if any, stays fp32).  Any other tile, plan type, out16 / res_is_f16 / out_subsample / depth-wise branch: OKP_EINVAL. */
+  int32_t src_pairs;
+  int32_t out_pairs;
 } okp_conv_args;
 
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
@@ -242,6 +255,10 @@ int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, cons
  * padding happen while the input patch is staged in LDS, so okp_pack_frames and its round trip through HBM are not needed.
  * OKP_F32X3 plans: `out` is an fp32 NHWC view; every product is the three-term fp16 split (fp32-grade, as OKP_F32X3 convolution plans). */
 int okp_stem_forward_nchw(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream);
+/* OKP_F32X3 stems: the same launch with `out` written in PAIR FORMAT (okp_conv_args.src_pairs: [8 x fp16 hi | 8 x fp16 lo] per 8 channels
+ * in the geometry of the fp32 tensor) - for a stem whose readers, conv1 and the projected skip of pre[1] (py_utils/utils.py:158-185), both
+ * run on the patch-resident split-product kernel. */
+int okp_stem_forward_nchw_pairs(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Final 1x1 convolutions of the three heads, NHWC -> NCHW fp32, optional sigmoid per output.

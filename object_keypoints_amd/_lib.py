@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 LIB_PATH = os.environ.get("OKP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_hip.so")   # OKP_LIB: A/B builds
 
 OKP_F32, OKP_BF16, OKP_F16, OKP_F32X3 = 0, 1, 2, 3
-OKP_ABI = 5
+OKP_ABI = 6
 CAM_EQUIDISTANT, CAM_RADTAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 HEAD_MAX_OUT = 32
@@ -35,7 +35,7 @@ class okp_conv_args(Structure):
                 ("out_step", c_int32), ("out_oy", c_int32), ("out_ox", c_int32),
                 ("res", okp_tensor), ("tile", c_int32),
                 ("dw_w_dev", c_void_p), ("dw_bias_dev", c_void_p), ("dw_out", okp_tensor), ("dw_res", okp_tensor),
-                ("n_classes", c_int32), ("out16", okp_tensor), ("res_is_f16", c_int32), ("out_subsample", c_int32)]
+                ("n_classes", c_int32), ("out16", okp_tensor), ("res_is_f16", c_int32), ("out_subsample", c_int32), ("src_pairs", c_int32), ("out_pairs", c_int32)]
 
 
 class okp_fire_args(Structure):
@@ -82,6 +82,7 @@ SIGNATURES = [
     ("okp_stem_destroy", None, [c_void_p]),
     ("okp_stem_forward", c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),
     ("okp_stem_forward_nchw", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(okp_tensor), c_void_p]),
+    ("okp_stem_forward_nchw_pairs", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, POINTER(okp_tensor), c_void_p]),
     ("okp_head_out_forward", c_int, [c_int, POINTER(okp_head_out_args), c_void_p]),
     ("okp_heads_forward", c_int, [c_void_p, c_void_p, POINTER(okp_head_out_args), POINTER(okp_tensor), c_void_p]),
     ("okp_peak_nms", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -425,6 +425,14 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
                a->out16.h != a->ho || a->out16.w != a->wo || a->out.h != (a->ho + 1) / 2 || a->out.w != (a->wo + 1) / 2)) {
     okp_set_error("okp_conv_forward: out_subsample 2 needs an OKP_F32X3 plan, a full-grid out16, out_step 1 and out of ceil(ho/2) x ceil(wo/2) pixels"); return OKP_EINVAL;
   }
+  if (a->src_pairs || a->out_pairs) {
+    bool ok = x3 && !a->out16.data && !a->res_is_f16 && !sub2 && !a->dw_w_dev && a->out.data && (a->src_pairs >> plan->n_src) == 0 && a->src_pairs >= 0 && plan->cout % 8 == 0;
+    for (int s = 0; s < plan->n_src; ++s) if ((a->src_pairs >> s) & 1) ok = ok && plan->cin[s] % 32 == 0 && a->src[s].pix_stride % 8 == 0;
+    if (!ok) {
+      okp_set_error("okp_conv_forward: src_pairs / out_pairs (pair-format tensors) belong to OKP_F32X3 plans with an fp32-geometry out, whole 32-channel chunks per pair source, and no out16 / res_is_f16 / out_subsample / depth-wise branch");
+      return OKP_EINVAL;
+    }
+  }
   if (a->out16.data) {
     if (int e = check_view("out16", a->out16, 2, true)) return e;
     if ((!sub2 && (a->out16.h != a->out.h || a->out16.w != a->out.w)) || a->out16.pix_stride < plan->cout) { okp_set_error("okp_conv_forward: out16 does not match out"); return OKP_EINVAL; }
@@ -478,6 +486,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.n_single_slices = plan->n_single_slices / p.n_classes;
   p.out16 = a->out16.data; p.out16_pix_stride = a->out16.pix_stride; p.res16 = a->res_is_f16 ? 1 : 0;
   if (sub2) { p.out_sub2 = 1; p.OH2 = a->out.h; p.OW2 = a->out.w; p.OH = a->out16.h; p.OW = a->out16.w; }
+  p.src_pairs = a->src_pairs; p.out_pairs = a->out_pairs ? 1 : 0;
   if (a->dw_w_dev) {
     if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
     if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }
@@ -487,7 +496,12 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
     p.dw_w = a->dw_w_dev; p.dw_bias = a->dw_bias_dev; p.dw_out = a->dw_out.data; p.dw_res = a->dw_res.data;
     p.dw_out_pix_stride = a->dw_out.pix_stride; p.dw_res_pix_stride = a->dw_res.pix_stride;
   }
-  return okp_launch_igemm(plan, p, a->tile ? a->tile : select_tile(plan, a), (hipStream_t)stream);
+  const int tile = a->tile ? a->tile : select_tile(plan, a);
+  if ((p.src_pairs || p.out_pairs) && tile != 13) {
+    okp_set_error("okp_conv_forward: pair-format tensors are read / written by the patch-resident split-product kernel only (tile 13; this launch: tile %d)", tile);
+    return OKP_EINVAL;
+  }
+  return okp_launch_igemm(plan, p, tile, (hipStream_t)stream);
 }
 
 // Tile heuristic of a launch.  The patch-resident kernel (13) takes over from the 256x256 gather tile where a source has

@@ -467,6 +467,7 @@ int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatc
   p.div_tiles_frame = okp_fastdiv((uint32_t)(p.tiles_y * p.tiles_x)); p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
   p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
+  p.pairs = ((uint32_t)q.src_pairs & 3u) | (q.out_pairs ? 4u : 0u);
   p.n_co_tiles = q.cout_pad / 256;
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;

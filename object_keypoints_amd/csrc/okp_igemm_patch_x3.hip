@@ -57,6 +57,8 @@ static_assert(sizeof(OkpPatchStep) == 16, "step table entries are read as one 16
 static_assert(kStagePx * 1024 <= kLdsSteps, "epilogue staging must not reach the step table");
 static_assert(kLdsTotal <= 160 * 1024, "one workgroup's LDS is at most the CU's 160 KiB");
 
+// OUT_PAIRS: the output is written in pair format (okp_conv_args.out_pairs; an instantiation of its own: the two store loops in one kernel spill)
+template <bool OUT_PAIRS>
 __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchParams p) {
   constexpr int TCO = 4, TPX = 8;                  // 16x16 accumulator tiles per wave: 64 channels x 128 pixels
   __shared__ __attribute__((aligned(16))) char smem[kLdsTotal];
@@ -208,8 +210,10 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
       const bool more = t + 1 < t1;
       const bool next_in_class = (int)(w3 >> 24) + 1 < t1;         // the next group still belongs to this class
       const bool next_patch = nx_k1 > nx_k0 && next_in_class;
-      const bool cvt_self = (pk & OKP_PSTEP_CVT_SELF) || t == t0;  // (a class's first patch was requested by the tile's prologue)
-      const bool cvt_next = (pk & OKP_PSTEP_CVT_NEXT) && next_in_class;
+      // (a source in pair format arrives split: okp_conv_args.src_pairs)
+      const bool in_pairs = (p.pairs >> ((p.geom_src >> (w3 & 0xff)) & 1u)) & 1u, nx_pairs = (p.pairs >> ((p.geom_src >> nx_geom) & 1u)) & 1u;
+      const bool cvt_self = ((pk & OKP_PSTEP_CVT_SELF) || t == t0) && !in_pairs;   // (a class's first patch was requested by the tile's prologue)
+      const bool cvt_next = (pk & OKP_PSTEP_CVT_NEXT) && next_in_class && !nx_pairs;
 
       // my part of step t's weights (and of the patches requested so far) has landed, and my fragment reads of step t-1 have
       // returned (the barrier frees their stage / patch buffer for the next LDS-DMA)
@@ -294,45 +298,96 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
         }
       }
       __syncthreads();
-      constexpr int U = kStagePx * 64 / 512;         // 16-byte items (4 channels of one pixel) per thread and pass: a wave = one pixel row
-      constexpr int UH = 8;                          // residual vectors in flight together
+      if constexpr (OUT_PAIRS) {
+        // pair-format output (okp_conv_args.out_pairs): a thread takes 8 adjacent channels of a pixel - two 16-byte chunks of the staged
+        // row - and writes [hi | lo] as one 32-byte piece; a wave = two pixel rows
+        constexpr int U2 = kStagePx * 32 / 512, UH2 = 4;
 #pragma unroll 1
-      for (int ub = 0; ub < U; ub += UH) {
-        u32x4 rres[UH];
-        uint32_t ooff[UH];
+        for (int ub = 0; ub < U2; ub += UH2) {
+          u32x4 rra[UH2], rrb[UH2];
+          uint32_t ooff[UH2];
 #pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          const int it = tid + (ub + u) * 512;
-          const int q = it & 63, prow = pass * kStagePx + (it >> 6);
-          const int co = co0 + q * 4;
-          const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
-          ooff[u] = co < p.cout ? opix : kInvalidOff;
+          for (int u = 0; u < UH2; ++u) {
+            const int it = tid + (ub + u) * 512;
+            const int q8 = it & 31, prow = pass * kStagePx + (it >> 5);
+            const int co = co0 + q8 * 8;
+            const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
+            ooff[u] = co < p.cout ? opix : kInvalidOff;
+          }
+          if (p.res) {
+#pragma unroll
+            for (int u = 0; u < UH2; ++u) {
+              const int q8 = (tid + (ub + u) * 512) & 31;
+              const int co = co0 + q8 * 8;
+              const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
+              const char* const rp = static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 4;
+              rra[u] = *reinterpret_cast<const u32x4*>(rp); rrb[u] = *reinterpret_cast<const u32x4*>(rp + 16);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UH2; ++u) {
+            const int it = tid + (ub + u) * 512;
+            const int q8 = it & 31, lrow = it >> 5;
+            f32x4 va = *reinterpret_cast<const f32x4*>(smem + lrow * 1024 + (((2 * q8) ^ (lrow & 7)) << 4));
+            f32x4 vb = *reinterpret_cast<const f32x4*>(smem + lrow * 1024 + (((2 * q8 + 1) ^ (lrow & 7)) << 4));
+            if (ooff[u] == kInvalidOff) continue;
+            if (p.res) {
+              const f32x4 ra = __builtin_bit_cast(f32x4, rra[u]), rb = __builtin_bit_cast(f32x4, rrb[u]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { va[e] += ra[e]; vb[e] += rb[e]; }
+            }
+            if (relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], 0.f); vb[e] = fmaxf(vb[e], 0.f); }
+            }
+            u32x4 hi, lo;
+            okp_split8(__builtin_bit_cast(u32x4, va), __builtin_bit_cast(u32x4, vb), hi, lo);
+            char* const op = static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q8 * 8) * 4;
+            *reinterpret_cast<u32x4*>(op) = hi;
+            *reinterpret_cast<u32x4*>(op + 16) = lo;
+          }
         }
-        if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
+      } else {
+      constexpr int U = kStagePx * 64 / 512;         // 16-byte items (4 channels of one pixel) per thread and pass: a wave = one pixel row
+        constexpr int UH = 8;                          // residual vectors in flight together
+#pragma unroll 1
+        for (int ub = 0; ub < U; ub += UH) {
+          u32x4 rres[UH];
+          uint32_t ooff[UH];
 #pragma unroll
           for (int u = 0; u < UH; ++u) {
-            const int q = (tid + (ub + u) * 512) & 63;
+            const int it = tid + (ub + u) * 512;
+            const int q = it & 63, prow = pass * kStagePx + (it >> 6);
             const int co = co0 + q * 4;
-            const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
-            rres[u] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 4);
+            const uint32_t opix = (uint32_t)((n * p.OH + (y0 + (prow >> 4)) * p.out_step + p.out_oy + (cls >> 1)) * p.OW + (x0 + (prow & 15)) * p.out_step + p.out_ox + (cls & 1));
+            ooff[u] = co < p.cout ? opix : kInvalidOff;
           }
-        }
+          if (p.res) {                                 // one uniform branch, unconditional loads (clamped): all UH in flight together
 #pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          const int it = tid + (ub + u) * 512;
-          const int q = it & 63, lrow = it >> 6;
-          f32x4 v = *reinterpret_cast<const f32x4*>(smem + lrow * 1024 + ((q ^ (lrow & 7)) << 4));
-          if (ooff[u] == kInvalidOff) continue;
-          if (p.res) {
-            const f32x4 r = __builtin_bit_cast(f32x4, rres[u]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
+            for (int u = 0; u < UH; ++u) {
+              const int q = (tid + (ub + u) * 512) & 63;
+              const int co = co0 + q * 4;
+              const uint32_t opix = ooff[u] == kInvalidOff ? 0u : ooff[u];
+              rres[u] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.res) + ((size_t)opix * p.res_pix_stride + (co < p.cout ? co : 0)) * 4);
+            }
           }
-          if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int u = 0; u < UH; ++u) {
+            const int it = tid + (ub + u) * 512;
+            const int q = it & 63, lrow = it >> 6;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + lrow * 1024 + ((q ^ (lrow & 7)) << 4));
+            if (ooff[u] == kInvalidOff) continue;
+            if (p.res) {
+              const f32x4 r = __builtin_bit_cast(f32x4, rres[u]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += r[e];
+            }
+            if (relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q * 4) * 4) = v;
           }
-          *reinterpret_cast<f32x4*>(static_cast<char*>(p.out) + ((size_t)ooff[u] * p.out_pix_stride + co0 + q * 4) * 4) = v;
         }
       }
       __syncthreads();                               // staging is free again: the next pass / the next tile's LDS-DMA may overwrite it
@@ -345,6 +400,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
 int okp_launch_igemm_patch_x3(const okp_conv* plan, const OkpPatchParams& p, hipStream_t stream) {
   if (plan->dtype != OKP_F32X3 || !p.oscale) { okp_set_error("okp_conv_forward: the split-product patch kernel takes OKP_F32X3 plans"); return OKP_EINVAL; }
   const dim3 grid((unsigned)(p.n_tiles < 256 ? p.n_tiles : 256)), block(512);
-  hipLaunchKernelGGL(okp_igemm_patch_x3_kernel, grid, block, 0, stream, p);
+  if (p.pairs & 4u) hipLaunchKernelGGL(okp_igemm_patch_x3_kernel<true>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(okp_igemm_patch_x3_kernel<false>, grid, block, 0, stream, p);
   return okp_check_hip(hipGetLastError(), "okp_igemm_patch_x3 launch");
 }

@@ -129,6 +129,7 @@ struct OkpIgemmParams {
   int32_t n_single_slices; // OKP_F32X3: leading single-term K-slices (the plan sorts them first)
   void* out16;             // OKP_F32X3: optional fp16 copy of the result (same pixel mapping as out); out may then be NULL
   int32_t out16_pix_stride, res16;   // res16: the residual tensor is fp16
+  int32_t src_pairs, out_pairs;      // OKP_F32X3 on the patch-resident kernel: sources (bit s) / output in pair format (okp_conv_args.src_pairs / out_pairs)
   int32_t out_sub2, OH2, OW2;        // OKP_F32X3: the fp32 output keeps even rows / columns only (tensor of OH2 x OW2 pixels); out16 is full size
   int32_t mfma32;                    // tile 14: the patch-resident 16-bit kernel on 32x32x16 MFMAs (experiment)
   OkpTapDev taps[OKP_MAX_TAPS];
@@ -171,6 +172,7 @@ struct OkpPatchParams {
   void* out; uint32_t out_bytes; int32_t out_pix_stride;
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
   int32_t act, n_co_tiles, n_tiles;
+  uint32_t pairs;              // okp_igemm_patch_x3.hip: bit s = source s arrives in pair format (its patches are not split), bit 2 = out is written in pair format
 #ifdef OKP_PATCH_STAMPS
   uint32_t* dbg;
 #endif

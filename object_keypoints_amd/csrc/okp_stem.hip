@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256, 2) void okp_stem_kernel(const StemParams p) {
 //  * the accumulators start at bias x scale and are multiplied by 1 / scale at the end (the per-channel power of two that keeps the
 //    low halves of small weights normal numbers: okp_conv_create does the same for split-product convolution plans); a half-wave's
 //    store is 128 contiguous bytes (32 channels) of one fp32 NHWC pixel.
+//  * PAIRS: the output in pair format (include/okp.h, okp_conv_args: [8 x fp16 hi | 8 x fp16 lo] per 8 channels - what the split-product
+//    patch kernel of pre[1] would make of the fp32 values in LDS).  A lane holds one channel of a pixel: it splits its value, exchanges
+//    the packed (hi, lo) with its neighbour lane and stores one dword as before - even lanes the hi halves of channels j, j + 1, odd
+//    lanes the lo halves of j - 1, j - so a half-wave's store is still the 128 contiguous bytes of 32 channels of one pixel.
+template <bool PAIRS>
 __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * PATCH_BYTES];      // [buffer][hi plane | lo plane]
   const int tid = threadIdx.x;
@@ -239,7 +244,11 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
   }
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
   const uint32_t ps4 = (uint32_t)p.out_pix_stride * 4u;                       // bytes per output pixel
-  const uint32_t st_lane = (uint32_t)(4 * h) * ps4 + (uint32_t)(32 * wave + j) * 4u;
+  const uint32_t st_lane = (uint32_t)(4 * h) * ps4 + (PAIRS ? (uint32_t)(32 * wave) * 4u + (uint32_t)(j >> 3) * 32u + (uint32_t)((j & 7) >> 1) * 4u + (uint32_t)(j & 1) * 16u
+                                                                : (uint32_t)(32 * wave + j) * 4u);
+  // v_perm_b32 selector of the stored dword from {neighbour's (hi, lo), own (hi, lo)}: even lanes [own hi, neighbour's hi], odd lanes
+  // [neighbour's lo, own lo] (bytes 0-3 = second operand, 4-7 = first)
+  const uint32_t pair_sel = (j & 1) ? 0x03020706u : 0x05040100u;
   const float bias0 = p.bias[32 * wave + j], osc = p.oscale[32 * wave + j];
 
   auto tile_coords = [&](int tile, int& n, int& oy0, int& ox0) {
@@ -330,8 +339,17 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
           for (int e = 0; e < 16; ++e) {
             const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
             const float v = fmaxf(acc[r][e] * osc, 0.f);
+            uint32_t word = __builtin_bit_cast(uint32_t, v);
+            if constexpr (PAIRS) {
+              f16x2 hl;
+              hl[0] = (_Float16)v;
+              hl[1] = (_Float16)(v - (float)hl[0]);                   // exact difference, as okp_split8 forms it
+              const uint32_t own = __builtin_bit_cast(uint32_t, hl);
+              const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
+              word = __builtin_amdgcn_perm(nb, own, pair_sel);
+            }
             if (full || ox0 + i0 + 4 * h < p.Wo)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps4), 0);
+              __builtin_amdgcn_raw_buffer_store_b32(word, rs_o, (int)st_lane, (int)(row_off + (uint32_t)i0 * ps4), 0);
           }
         }
       }
@@ -472,8 +490,9 @@ extern "C" int okp_stem_forward(const okp_stem* st, int32_t n, int32_t h, int32_
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
 }
 
-extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream) {
+static int stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, bool pairs, void* stream) {
   if (!st || !frames_nchw_dev || !out || !out->data) { okp_set_error("okp_stem_forward_nchw: null argument"); return OKP_EINVAL; }
+  if (pairs && st->dtype != OKP_F32X3) { okp_set_error("okp_stem_forward_nchw_pairs: the pair format belongs to OKP_F32X3 stems"); return OKP_EINVAL; }
   if (n < 1 || h < 1 || w < 1) { okp_set_error("okp_stem_forward_nchw: empty problem"); return OKP_EINVAL; }
   const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
   const int64_t src_bytes = (int64_t)n * 3 * h * w * 4;
@@ -497,8 +516,17 @@ extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, i
   p.div_tiles_x = okp_fastdiv((uint32_t)p.tiles_x);
   const int resident = 256 * 2;
   const int grid = p.n_tiles < resident ? p.n_tiles : resident;
-  if (st->dtype == OKP_F32X3) hipLaunchKernelGGL(okp_stem_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (st->dtype == OKP_F32X3 && pairs) hipLaunchKernelGGL(okp_stem_x3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else if (st->dtype == OKP_F32X3) hipLaunchKernelGGL(okp_stem_x3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else if (st->dtype == OKP_BF16) hipLaunchKernelGGL((okp_stem_kernel<__bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((okp_stem_kernel<_Float16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_stem launch");
+}
+
+extern "C" int okp_stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream) {
+  return stem_forward_nchw(st, n, h, w, frames_nchw_dev, out, false, stream);
+}
+
+extern "C" int okp_stem_forward_nchw_pairs(const okp_stem* st, int32_t n, int32_t h, int32_t w, const float* frames_nchw_dev, const okp_tensor* out, void* stream) {
+  return stem_forward_nchw(st, n, h, w, frames_nchw_dev, out, true, stream);
 }

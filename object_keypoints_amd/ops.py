@@ -124,12 +124,14 @@ def require_cuda(t, what):
 class Act:
     """NHWC activation view: a contiguous device tensor [N,H,W,Ctot] and a channel window."""
 
-    __slots__ = ("t", "c0", "c", "orig_hw", "shadow", "compact")
+    __slots__ = ("t", "c0", "c", "orig_hw", "shadow", "compact", "pairs")
 
     def __init__(self, t, c0=0, c=None):
         self.orig_hw = None          # set by pack_frames: (H, W) of the un-padded frame
         self.shadow = None           # mixed configuration: fp16 copy of an fp32 stream tensor, written by its producer (ConvPlan(out16=...))
         self.compact = False         # ... and this fp32 tensor holds the even rows / columns of the grid only (out_subsample=2); shadow: full grid
+        self.pairs = False           # split-product plans: the float32 storage holds [8 x fp16 hi | 8 x fp16 lo] per 8 channels (okp_conv_args.out_pairs):
+                                     # written by ConvPlan(out_pairs=True), read by the patch-resident 3x3 kernel only - every other op refuses it
         require_cuda(t, "activation")
         if t.dim() != 4 or not t.is_contiguous():
             raise OkpError("activation must be a contiguous [N,H,W,C] tensor")
@@ -145,9 +147,16 @@ class Act:
     dtype = property(lambda s: s.t.dtype)
 
     def slice(self, c0, c):
-        return Act(self.t, self.c0 + c0, c)
+        a = Act(self.t, self.c0 + c0, c)
+        if self.pairs:
+            if c0 % 8 or c % 8:
+                raise OkpError("a pair-format activation is sliced in whole 8-channel groups")
+            a.pairs = True
+        return a
 
-    def view(self):
+    def view(self, pairs_ok=False):
+        if self.pairs and not pairs_ok:
+            raise OkpError("this activation is in pair format ([hi | lo] fp16 per 8 channels): only a split-product 3x3 ConvPlan reads it")
         esz = self.t.element_size()
         return _lib.okp_tensor(self.t.data_ptr() + self.c0 * esz, self.h, self.w, self.t.shape[3],
                                self.t.numel() * esz - self.c0 * esz)
@@ -163,10 +172,38 @@ class Act:
         return Act(x.permute(0, 2, 3, 1).contiguous().to(dtype))
 
     def to_nchw(self):
+        if self.pairs:
+            return self.pairs_to_float().to_nchw()
         return self.t[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
+
+    def pairs_to_float(self):
+        """hi + lo of a pair-format activation as an ordinary float32 one (torch kernels: tests and debugging, not the hot path)."""
+        if not self.pairs or self.c0 % 8 or self.c % 8:
+            raise OkpError("pairs_to_float: a pair-format activation with whole 8-channel groups")
+        n, h, w, ct = self.t.shape
+        hl = self.t.view(torch.float16).view(n, h, w, ct // 8, 2, 8)[:, :, :, self.c0 // 8:(self.c0 + self.c) // 8]
+        return Act((hl[..., 0, :].float() + hl[..., 1, :].float()).reshape(n, h, w, self.c).contiguous())
+
+    @staticmethod
+    def float_to_pairs(t):
+        """A float32 [N,H,W,C] tensor in pair format (C % 8 == 0): hi = fp16(x), lo = fp16(x - hi), as the kernels split (tests)."""
+        require_cuda(t, "activation")
+        n, h, w, c = t.shape
+        x = t.float().reshape(n, h, w, c // 8, 8)
+        hi = x.half()
+        lo = (x - hi.float()).half()
+        a = Act(torch.stack((hi, lo), dim=4).reshape(n, h, w, c * 2).contiguous().view(torch.float32))
+        a.pairs = True
+        return a
 
 
 _NULL_TENSOR = _lib.okp_tensor(None, 0, 0, 0, 0)
+
+
+def _refuse_pairs(*acts):
+    for a in acts:
+        if a is not None and getattr(a, "pairs", False):
+            raise OkpError("this activation is in pair format ([hi | lo] fp16 per 8 channels): only a split-product 3x3 ConvPlan reads it")
 
 
 class ConvPlan:
@@ -223,6 +260,21 @@ class ConvPlan:
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
+    def picks_patch(self, n, ho, wo, src_pix_strides, out_step=1, n_classes=1, tile=0):
+        """True if a launch of this shape (dense output of ho*out_step x wo*out_step pixels, no depth-wise branch / fp16 side output) runs
+        on the patch-resident kernel (tile 13 of okp_conv_forward's heuristic, okp_conv_select_tile) - the one kernel that reads and
+        writes pair-format activations."""
+        tile = tile or FORCE_TILE
+        if tile:
+            return tile == 13
+        a = _lib.okp_conv_args()
+        a.n, a.ho, a.wo = n, ho, wo
+        for i, ps in enumerate(src_pix_strides):
+            a.src[i] = _lib.okp_tensor(1, 1, 1, ps, 1)          # (the heuristic reads pixel strides and the output grid only)
+        a.out = _lib.okp_tensor(1, ho * out_step, wo * out_step, self.cout, 1)
+        a.out_step, a.n_classes = out_step, n_classes
+        return _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a)) == 13
+
     def _algorithmic_bytes(self, srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample):
         """Compulsory HBM bytes of one launch (bench.py's roofline of HBM-bound launches): every source pixel the taps sample once,
         every output element once (+ the fp16 copy), the residual once; weights not counted (L2-resident, shared by all tiles)."""
@@ -244,8 +296,11 @@ class ConvPlan:
             b += opx * self.cout * esz(dw[2]) + (opx * self.cout * esz(dw[3]) if dw[3] is not None else 0)
         return b
 
-    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True, out_subsample=1):
+    def __call__(self, srcs, out, ho, wo, res=None, out_step=1, oy=0, ox=0, tile=0, dw=None, n_classes=1, out16=None, write_out=True, out_subsample=1,
+                 out_pairs=False):
         """dw = (w_dev [9,cout] fp32, bias_dev [cout] fp32, dw_out Act, dw_res Act|None): fused depth-wise 3x3 branch.
+        out_pairs (split-product 3x3 plans on the patch-resident kernel): `out` is written in pair format (Act.pairs); sources that are
+        in pair format are passed as such (okp_conv_args.src_pairs / out_pairs).
         Split-product plans: out16 = fp16 Act that receives the result as well (write_out=False: only that copy is written; `out` then
         only describes the grid), and `res` may be an fp16 tensor (okp_conv_args.out16 / res_is_f16)."""
         for s in srcs:
@@ -268,7 +323,12 @@ class ConvPlan:
             raise OkpError("write_out=False needs out16")
         if out_subsample not in (1, 2) or (out_subsample == 2 and out16 is None):
             raise OkpError("out_subsample is 1 or 2, and 2 needs out16")
-        extended = out16 is not None or res16
+        src_pairs = sum(1 << i for i, s in enumerate(srcs) if s.pairs)
+        if (src_pairs or out_pairs) and not self.split:
+            raise OkpError("pair-format activations belong to split-product (ops.F32X3) plans")
+        if (res is not None and res.pairs) or (dw is not None and (src_pairs or out_pairs)):
+            raise OkpError("pair format: the residual stays float32, and the depth-wise branch does not take it")
+        extended = out16 is not None or res16 or bool(src_pairs) or bool(out_pairs)
         macs = out.n * ho * wo * self.cout * self.alg_k
         macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
         tile = tile or FORCE_TILE
@@ -295,7 +355,9 @@ class ConvPlan:
             a = _lib.okp_conv_args()
             a.n, a.ho, a.wo = out.n, ho, wo
             for i, s in enumerate(srcs):
-                a.src[i] = s.view()
+                a.src[i] = s.view(pairs_ok=True)
+            a.src_pairs, a.out_pairs = src_pairs, 1 if out_pairs else 0
+            out.pairs = False
             a.out = out.view()
             if not write_out:
                 a.out.data = None
@@ -318,19 +380,22 @@ class ConvPlan:
                 a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
                 token = hook.before(self, a.tile, macs)
             _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
+            out.pairs = bool(out_pairs)
+            COUNTERS["pair_outputs"] += 1 if out_pairs else 0
             if hook is not None:
                 hook.after(token)
         COUNTERS["macs"] += macs + macs_dw
         COUNTERS["launches"] += 1
 
 
-COUNTERS = {"macs": 0, "launches": 0}
+COUNTERS = {"macs": 0, "launches": 0, "pair_outputs": 0}
 LAUNCH_HOOK = None      # bench.py: object with before(plan, tile, macs) / after(token) bracketing conv launches
 FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256), 0 = heuristic
 
 
 def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
     """One-launch fire module (16-bit plans: okp_fire2.hip; split-product plans: okp_fire_x3.hip): see okp_fire_forward in include/okp.h."""
+    _refuse_pairs(x)
     T = _lib.torch_ops()
     if T is not None:
         _dispatch(T.fire_forward, squeeze._h, expand._h, wd_dev, bd_dev, x.t, x.c0, out.t, out.c0, stride, bool(skip), stream_int())
@@ -357,6 +422,7 @@ FUSE_FIRE_CHAIN = True          # consecutive 512-channel fire modules on <= 4x4
 
 def fire_chain(modules, x, out):
     """modules: list of (squeeze plan, expand plan, dw weights, dw bias) of consecutive fire(512, 512) modules; x, out: Acts."""
+    _refuse_pairs(x)
     n = len(modules)
     T = _lib.torch_ops()
     if T is not None:
@@ -416,6 +482,7 @@ def stream_wait(waiter, signaller):
 
 def cast(src, dtype):
     """Act -> Act of another element type (okp_cast: fp32 <-> fp16 / bf16): the boundary of an fp16 sub-network inside the fp32 stream."""
+    _refuse_pairs(src)
     if src.c0 != 0 or src.c != src.t.shape[3]:
         raise OkpError("cast takes a whole tensor, not a channel window")
     out = Act(torch.empty(src.t.shape, dtype=dtype, device=src.t.device))
@@ -426,6 +493,7 @@ def cast(src, dtype):
 
 def add_f16_f32(a16, b32, relu=True):
     """relu(a + b): a an fp16 Act, b an fp32 Act of the same shape -> fp32 Act (okp_add_f16_f32)."""
+    _refuse_pairs(a16, b32)
     if a16.dtype != torch.float16 or b32.dtype != torch.float32 or a16.t.shape != b32.t.shape or a16.c0 or b32.c0 or a16.c != a16.t.shape[3] or b32.c != b32.t.shape[3]:
         raise OkpError("add_f16_f32 takes whole float16 / float32 tensors of one shape")
     out = Act(torch.empty_like(b32.t))
@@ -435,6 +503,7 @@ def add_f16_f32(a16, b32, relu=True):
 
 
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):
+    _refuse_pairs(src, res)
     dt = okp_dtype(src.dtype)
     sv, ov = src.view(), out.view()
     rv = res.view() if res is not None else None
@@ -494,15 +563,24 @@ class StemPlan:
         except Exception:
             pass
 
-    def from_nchw(self, frames, out):
-        """frames: fp32 NCHW [N,3,H,W] on the device (the reference's input layout); no packing pass."""
+    def from_nchw(self, frames, out, out_pairs=False):
+        """frames: fp32 NCHW [N,3,H,W] on the device (the reference's input layout); no packing pass.
+        out_pairs (split-product stem): `out` is written in pair format (Act.pairs; okp_stem_forward_nchw_pairs)."""
         require_cuda(frames, "frames")
         if frames.dtype != torch.float32 or frames.dim() != 4 or frames.shape[1] != 3 or out.dtype != self.dtype:
             raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's element type")
         frames = frames.contiguous()
         n, _, h, w = frames.shape
         T = _lib.torch_ops()
-        if T is not None:
+        out.pairs = False
+        if out_pairs:
+            if not self.split:
+                raise OkpError("pair-format output belongs to the split-product stem")
+            ov = out.view()
+            _lib.check(_lib.lib().okp_stem_forward_nchw_pairs(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw_pairs")
+            out.pairs = True
+            COUNTERS["pair_outputs"] += 1
+        elif T is not None:
             _dispatch(T.stem_forward_nchw, self._h, frames, out.t, out.c0, stream_int())
         else:
             ov = out.view()
@@ -588,6 +666,7 @@ def _head_out_args(n, h, w, outputs, w_dev, bias_dev):
 
 def head_out(src, outputs, w_dev, bias_dev):
     """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
+    _refuse_pairs(src)
     T = _lib.torch_ops()
     if T is not None:
         _dispatch(T.head_out_forward, src.t, src.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
@@ -605,6 +684,7 @@ FUSE_HEADS = True    # 16-bit, 128 features: the three heads of a stack in one l
 
 def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):
     """The three prediction heads in one launch (okp_heads_forward): l1 256 -> 384, l2 block-diagonal 384 -> 96 plans."""
+    _refuse_pairs(x)
     T = _lib.torch_ops()
     if T is not None:
         _dispatch(T.heads_forward, l1._h, l2._h, x.t, x.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],

@@ -29,6 +29,10 @@ import os
 STEM_DIRECT = True       # 16-bit: the stem kernel reads fp32 NCHW frames itself (no pack launch)
 STEM_KERNEL = True       # 16-bit: dedicated stem kernel (okp_stem.hip); False = generic tap-list kernel
 STEM_X3_KERNEL = True    # split-product configuration on raw NCHW frames: the stem kernel's three-term form; False = pack + generic kernel
+PAIR_TENSORS = True      # split-product configuration: a tensor whose only readers are 3x3 convolutions on the patch-resident kernel is written
+                         # in pair format ([hi | lo] fp16 per 8 channels, okp_conv_args.out_pairs) by its producer, so that its consumers do
+                         # not split every landed patch between their K-steps: conv1 -> conv2 of the residual blocks, pre[1] -> pre[2],
+                         # hourglass -> cnvs.  Bit-identical results (the same split, done once per element in the producer's epilogue)
 UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
 SQUEEZE_TILE = 0         # tile code of the squeeze launch of a fire module that has no one-launch kernel (0 = heuristic)
 STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
@@ -119,9 +123,19 @@ class convolution(_HipModule):
             return ConvPlan(dtype, [32], [stride or 2], self.out_dim, taps, b, relu=True, alg_k=147)
         return ConvPlan(dtype, [self.inp_dim], [self.stride], self.out_dim, conv_taps(w), b, relu=True)
 
-    def forward_frames(self, frames, dtype, shadow=False, compact=False):
+    def takes_pairs(self, n, h, w, dtype):
+        """This 3x3 convolution reads a pair-format input of n x h x w pixels (PAIR_TENSORS): a pure split-product plan whose launch runs
+        on the patch-resident kernel."""
+        if not (PAIR_TENSORS and dtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX and self.inp_dim != 3 and self.k > 1):
+            return False
+        plan = self._plan(("p", dtype), lambda: self._build(dtype))
+        return bool(getattr(plan, "split", False)) and plan.picks_patch(n, conv_out_size(h, self.k, self.stride, self.pad),
+                                                                        conv_out_size(w, self.k, self.stride, self.pad), [self.inp_dim])
+
+    def forward_frames(self, frames, dtype, shadow=False, compact=False, out_pairs=False):
         """The stem on raw fp32 NCHW frames.  bf16: one launch of the dedicated kernel reading the frames directly;
-        otherwise pack (ops.pack_frames) + the generic path.  shadow (split-product plans): also write the fp16 copy."""
+        otherwise pack (ops.pack_frames) + the generic path.  shadow (split-product plans): also write the fp16 copy.
+        out_pairs (split-product stem kernel only; the caller checks Act.pairs): the result in pair format (PAIR_TENSORS)."""
         if self.inp_dim == 3 and dtype in ops.HALF_DTYPES and self.out_dim == 128 and STEM_KERNEL and STEM_DIRECT:
             plan = self._plan(("p", dtype), lambda: self._build(dtype))
             n, _, h, w = frames.shape
@@ -134,7 +148,7 @@ class convolution(_HipModule):
             plan = self._plan(("px3", dtype), lambda: self._build(dtype, stride="direct"))
             n, _, h, w = frames.shape
             out = Act.empty(n, conv_out_size(h, 7, 2, 3), conv_out_size(w, 7, 2, 3), self.out_dim, dtype, frames.device)
-            plan.from_nchw(frames, out)
+            plan.from_nchw(frames, out, out_pairs=bool(out_pairs and PAIR_TENSORS and not ops.F32_MIX))
             return out
         if (shadow and compact and ops.F32_MIX and ops.MIX_STEM_FP16 and dtype == torch.float32 and self.inp_dim == 3 and self.out_dim == 128
                 and STEM_KERNEL and STEM_DIRECT):
@@ -253,23 +267,43 @@ class residual(_HipModule):
                 out.shadow = ops.cast(out, torch.float16)
         return out
 
-    def forward(self, x, shadow=False, out=None, out_shadow=None, compact=False):
+    def on_patch_kernel(self, n, h, w, dtype, in_pix_stride=None):
+        """(conv1, conv2) of an input of n x h x w pixels run on the patch-resident split-product kernel, i.e. may exchange pair-format
+        tensors (PAIR_TENSORS): pure split-product plans only - the mixed configuration keeps its fp16 side outputs."""
+        if not (PAIR_TENSORS and dtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX):
+            return False, False
+        p1, p2 = self._plan(("p", dtype), lambda: self._build(dtype))
+        if not p1.split:
+            return False, False
+        ho, wo = conv_out_size(h, self.k, self.stride, self.pad), conv_out_size(w, self.k, self.stride, self.pad)
+        ps = in_pix_stride or self.inp_dim
+        return (p1.picks_patch(n, ho, wo, [ps]),
+                p2.picks_patch(n, ho, wo, [self.out_dim, ps] if self.projected else [self.out_dim]))
+
+    def takes_pairs(self, n, h, w, dtype):
+        """The block reads a pair-format input: conv1 and the projected skip inside conv2's launch both run on the patch-resident kernel
+        (an identity skip adds the input in fp32: such a block takes fp32 tensors)."""
+        return self.projected and all(self.on_patch_kernel(n, h, w, dtype))
+
+    def forward(self, x, shadow=False, out=None, out_shadow=None, compact=False, out_pairs=False):
         """out / out_shadow: optional destination (an Act over a frame range of a larger tensor) of the block's result and of its fp16
         copy - hg.forward runs the two high-resolution layers in frame chunks and the rest of the network in one pass.
         compact (mixed configuration, with shadow): the fp32 result is kept at even rows / columns only (its one fp32 reader is the
-        next block's stride-2 skip)."""
+        next block's stride-2 skip).  out_pairs: write the result in pair format if conv2 runs on the patch-resident kernel (the
+        caller has checked that every reader takes it: residual.takes_pairs); the returned Act's `pairs` says whether it was."""
         if ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16 and x.dtype == torch.float32:
             return self._forward_mixed16(x, shadow, out, out_shadow, compact)
         p1, p2 = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         ho, wo = conv_out_size(x.h, self.k, self.stride, self.pad), conv_out_size(x.w, self.k, self.stride, self.pad)
+        on1, on2 = self.on_patch_kernel(x.n, x.h, x.w, x.dtype, x.t.shape[3])
         t = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
-        p1([x], t, ho, wo)
+        p1([x], t, ho, wo, out_pairs=on1 and on2)       # conv1 -> conv2: one writer, one reader
         if out is None:
             out = Act.empty(x.n, ho, wo, self.out_dim, x.dtype, x.t.device)
         if self.projected:
-            p2([t, x], out, ho, wo)
+            p2([t, x], out, ho, wo, out_pairs=out_pairs and on2)
         else:
-            p2([t], out, ho, wo, res=x)
+            p2([t], out, ho, wo, res=x, out_pairs=out_pairs and on2)
         return out
 
 
@@ -351,12 +385,15 @@ class unpool_merge(_HipModule):
                 for a in (0, 1) for bb in (0, 1) for dy, ky in sel[a] for dx, kx in sel[bb]]
         return ConvPlan(dtype, [self.dim], [1], self.dim, taps, b, relu=False)
 
-    def forward(self, low, up1):
+    def forward(self, low, up1, out_pairs=False):
+        """out_pairs (split-product plans, PAIR_TENSORS): the merged map in pair format if this launch runs on the patch-resident kernel."""
         plan = self._plan(("p", low.dtype), lambda: self._build(low.dtype))
         if up1.h != 2 * low.h or up1.w != 2 * low.w:
             raise OkpError("unpool_merge: up1 must be twice the size of low")
         out = Act.empty(low.n, 2 * low.h, 2 * low.w, self.dim, low.dtype, low.t.device)
-        plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4, tile=UNPOOL_TILE)     # four output parities, one launch
+        out_pairs = bool(out_pairs and PAIR_TENSORS and plan.split and not ops.F32_MIX
+                         and plan.picks_patch(low.n, low.h, low.w, [low.t.shape[3]], out_step=2, n_classes=4, tile=UNPOOL_TILE))
+        plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4, tile=UNPOOL_TILE, out_pairs=out_pairs)     # four output parities, one launch
         return out
 
 
@@ -446,10 +483,11 @@ class hg_module(nn.Module):
         self.low3 = make_layer_revr(next_dim, curr_dim, modules[0])
         self.up2 = make_unpool_layer(curr_dim)
 
-    def forward(self, x):
+    def forward(self, x, out_pairs=False):
         """up1(x) and the whole low path are independent until the merge.  The low path is a long chain of small,
         latency-bound launches that leave most of the 256 CUs idle, so up1 runs on a side HIP stream and fills
-        them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph)."""
+        them (ops.SIDE_STREAMS; the streams fork/join with events, which also captures cleanly into a hipGraph).
+        out_pairs: the caller's only reader of the result takes pair format (unpool_merge.forward, PAIR_TENSORS)."""
         if ops.F32_MIX and x.dtype == torch.float32 and self.n <= ops.MIX_FP16_LEVELS:
             # mixed configuration: this level and everything below it run in fp16 on the fused fp16 kernels (ops.F32MIX)
             return ops.cast(self.forward(ops.cast(x, torch.float16)), torch.float32)
@@ -458,7 +496,7 @@ class hg_module(nn.Module):
                 held.clear()
             up1 = self.up1(x)
             low3 = self._low_path(x)                   # max1 is the identity (CornerNet_Squeeze.py:32-33)
-            return self.up2(low3, up1)
+            return self.up2(low3, up1, out_pairs=out_pairs)
         main = torch.cuda.current_stream()
         skey, side = self._side_stream(x.t.device)
         ops.stream_wait(side, main)                     # x is ready on the side stream
@@ -487,7 +525,7 @@ class hg_module(nn.Module):
                 ops.stream_wait(main, side)             # join before the merge
                 _JOINED_SEQ[skey] = _SIDE_SEQ.get(skey, seq)
             joined = True
-            out = self.up2(low3, up1)
+            out = self.up2(low3, up1, out_pairs=out_pairs)
             held.append(up1.t)
             return out
         finally:
@@ -577,7 +615,7 @@ class hg(_HipModule):
         cp = [mix16 and ops.MIX_COMPACT and r.projected and r.stride == 2 for r in (self.pre[1], self.pre[2])]
         if isinstance(x, torch.Tensor):
             n, (fh, fw), sdtype = x.shape[0], x.shape[2:4], dtype
-            stem = lambda c0, c1, sh: self.pre[0].forward_frames(x[c0:c1], dtype, shadow=sh, compact=sh and cp[0])
+            stem = lambda c0, c1, sh: self.pre[0].forward_frames(x[c0:c1], dtype, shadow=sh, compact=sh and cp[0], out_pairs=stem_pairs)
         else:                                   # packed frames (ops.pack_frames / pack_frames_u8 / preprocess_u8)
             n, (fh, fw), sdtype = x.n, x.orig_hw, x.dtype
 
@@ -587,12 +625,16 @@ class hg(_HipModule):
                 return self.pre[0](xi, shadow=sh, compact=sh and cp[0])
         want_shadow = mix16 and sdtype == torch.float32
         chunk = self.front_chunk(n, fh, fw, sdtype, compact=want_shadow and cp[0])
+        # pair format between the stem and pre[1] (both of its launches read the stem's map): every frame chunk's launches on the patch kernel
+        stem_pairs = all(self.pre[1].takes_pairs(min(n, q + chunk) - q, conv_out_size(fh, 7, 2, 3), conv_out_size(fw, 7, 2, 3), sdtype)
+                         for q in range(0, n, chunk))
         if chunk < n:
             # fp32 tensors: the stem output (128 channels at half resolution, 33.5 MB per frame) of a whole batch would pass the 2 GiB
             # view limit of the 32-bit buffer offsets.  Only the stem and pre[1] see that resolution: they run per frame chunk and
             # pre[1] writes straight into its range of the full batch's tensor; everything behind it runs in ONE pass (the chains of
             # small launches in the hourglasses cost the same for 32 frames as for 64).
             inter = None
+            pairs1 = None
             for c0 in range(0, n, chunk):
                 c1 = min(n, c0 + chunk)
                 a = stem(c0, c1, want_shadow)
@@ -605,15 +647,26 @@ class hg(_HipModule):
                     inter.compact = c2
                     if want_shadow:
                         inter.shadow = Act.empty(n, ho, wo, r.out_dim, torch.float16, a.t.device)
+                    # pair format between pre[1] and pre[2]: every chunk's launch and both of pre[2]'s must be on the patch-resident kernel
+                    pairs1 = (self.pre[2].takes_pairs(n, ho, wo, sdtype)
+                              and all(r.on_patch_kernel(min(n, q + chunk) - q, ah, aw, sdtype, a.t.shape[3])[1] for q in range(0, n, chunk)))
                 sh = Act(inter.shadow.t[c0:c1]) if inter.shadow is not None else None
-                self.pre[1](a, shadow=sh is not None, out=Act(inter.t[c0:c1]), out_shadow=sh, compact=inter.compact)
+                part = self.pre[1](a, shadow=sh is not None, out=Act(inter.t[c0:c1]), out_shadow=sh, compact=inter.compact, out_pairs=pairs1)
+                if part.pairs != bool(pairs1):
+                    raise OkpError("hg.forward: a frame chunk of pre[1] did not keep the tensor format of the others")
+            inter.pairs = bool(pairs1)
         else:
-            inter = self.pre[1](stem(0, n, want_shadow), shadow=mix16, compact=want_shadow and cp[1])
+            a = stem(0, n, want_shadow)
+            r = self.pre[1]
+            ah, aw = (a.shadow.h, a.shadow.w) if a.compact else (a.h, a.w)
+            pairs1 = self.pre[2].takes_pairs(n, conv_out_size(ah, r.k, r.stride, r.pad), conv_out_size(aw, r.k, r.stride, r.pad), sdtype)
+            inter = r(a, shadow=mix16, compact=want_shadow and cp[1], out_pairs=pairs1)
         inter = self.pre[2](inter)
         cnvs = []
         last = len(self.hgs) - 1
         for i, (hg_, cnv_) in enumerate(zip(self.hgs, self.cnvs)):
-            cnv = cnv_(hg_(inter))
+            # (the hourglass's merged map has one reader, cnvs[i]: pair format where that 3x3 takes it)
+            cnv = cnv_(hg_(inter, out_pairs=cnv_.takes_pairs(inter.n, inter.h, inter.w, inter.dtype)))
             cnvs.append(cnv)
             if i < last:
                 merge = self._plan(("m", i, inter.dtype), lambda: self._build_merge(i, inter.dtype))

@@ -1,0 +1,185 @@
+"""Pair-format tensors between split-product 3x3 convolutions (okp_conv_args.src_pairs / out_pairs, ABI 6; backbone.PAIR_TENSORS).
+
+A pair-format tensor keeps the geometry of an fp32 tensor but holds [8 x fp16 hi | 8 x fp16 lo] per 8 channels - exactly what the
+patch-resident split-product kernel (okp_igemm_patch_x3.hip) makes of 8 fp32 values in LDS.  The format changes WHERE the split happens
+(once per element in the producer's epilogue instead of on every landed patch), never a result: every test here asks for bit equality
+with the fp32-tensor path on the same operands."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed):
+    from object_keypoints_amd import synth
+    return torch.from_numpy(synth.normal_like(f"pairs{seed}", shape, seed))
+
+
+def _act(x):
+    from object_keypoints_amd import ops
+    return ops.Act.from_nchw(x.cuda(), torch.float32)
+
+
+def _pairs(a):
+    from object_keypoints_amd import ops
+    return ops.Act.float_to_pairs(a.t)
+
+
+def test_pair_format_round_trip_matches_the_kernel_split():
+    """Act.float_to_pairs (torch) is the split the kernels perform: hi = fp16(x), lo = fp16(x - hi); hi + lo is x to 2^-22."""
+    from object_keypoints_amd import ops
+    x = _act(_rand((2, 64, 16, 16), 1) * 3.0)
+    p = _pairs(x)
+    assert p.pairs and p.t.shape == x.t.shape and p.t.dtype == torch.float32
+    back = p.pairs_to_float()
+    assert float((back.t - x.t).abs().max()) <= 2.0 ** -21 * float(x.t.abs().max())
+    hl = p.t.view(torch.float16).view(2, 16, 16, 8, 2, 8)
+    assert torch.equal(hl[..., 0, :].reshape(2, 16, 16, 64), x.t.half())
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,stride,res", [
+    (32, 256, 1, 16, 16, 1, False),
+    (64, 256, 2, 32, 48, 1, True),
+    (96, 512, 3, 16, 32, 1, False),
+    (32, 256, 2, 16, 32, 2, False),     # stride 2: four parity patches per chunk, none of them split
+    (128, 256, 1, 32, 16, 2, True),
+    (256, 256, 2, 16, 16, 1, True),
+])
+def test_pair_source_and_pair_output_are_bit_identical_to_fp32_tensors(cin, cout, n, h, w, stride, res):
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    x = _rand((n, cin, h * stride, w * stride), 2)
+    wt = _rand((cout, cin, 3, 3), 3) / np.sqrt(cin * 9)
+    b = _rand((cout,), 4) * 0.1
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [cin], [stride], cout, conv_taps(wt.numpy()), b.numpy(), relu=True)
+    xa = _act(x)
+    ra = _act(_rand((n, cout, h, w), 5)) if res else None
+    ref = ops.Act.empty(n, h, w, cout, torch.float32, xa.t.device)
+    plan([xa], ref, h, w, res=ra, tile=13)
+    # (a) pair-format source: the patches arrive split
+    got = ops.Act.empty(n, h, w, cout, torch.float32, xa.t.device)
+    plan([_pairs(xa)], got, h, w, res=ra, tile=13)
+    assert not got.pairs and torch.equal(got.t, ref.t)
+    # (b) pair-format output: the epilogue splits what it would have stored
+    outp = ops.Act.empty(n, h, w, cout, torch.float32, xa.t.device)
+    plan([xa], outp, h, w, res=ra, tile=13, out_pairs=True)
+    assert outp.pairs and torch.equal(outp.t.view(torch.int32), _pairs(ref).t.view(torch.int32))
+    # (c) both
+    outp2 = ops.Act.empty(n, h, w, cout, torch.float32, xa.t.device)
+    plan([_pairs(xa)], outp2, h, w, res=ra, tile=13, out_pairs=True)
+    assert torch.equal(outp2.t.view(torch.int32), outp.t.view(torch.int32))
+
+
+@pytest.mark.parametrize("mask", [1, 2, 3])
+def test_pair_format_per_source_of_a_two_source_plan(mask):
+    """conv2 + projected 1x1/s2 skip of `residual` (py_utils/utils.py:177-185): either source, or both, in pair format."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    n, c0, c1, cout, h, w = 2, 64, 96, 256, 32, 16
+    t = _act(_rand((n, c0, h, w), 6)); x = _act(_rand((n, c1, 2 * h, 2 * w), 7))
+    w2 = _rand((cout, c0, 3, 3), 8) / np.sqrt(c0 * 9); ws = _rand((cout, c1, 1, 1), 9) / np.sqrt(c1)
+    taps = conv_taps(w2.numpy()) + [(1, 0, 0, np.ascontiguousarray(ws.numpy()[:, :, 0, 0]))]
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [c0, c1], [1, 2], cout, taps, (_rand((cout,), 10) * 0.1).numpy(), relu=True)
+    ref = ops.Act.empty(n, h, w, cout, torch.float32, t.t.device)
+    plan([t, x], ref, h, w, tile=13)
+    got = ops.Act.empty(n, h, w, cout, torch.float32, t.t.device)
+    plan([_pairs(t) if mask & 1 else t, _pairs(x) if mask & 2 else x], got, h, w, tile=13, out_pairs=True)
+    assert torch.equal(got.t.view(torch.int32), _pairs(ref).t.view(torch.int32))
+
+
+def test_pair_output_of_the_transposed_convolution_classes():
+    """unpool_merge (CornerNet_Squeeze.py:35-36): four sub-pixel classes with the up1 residual, written in pair format."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone
+    torch.manual_seed(3)
+    m = backbone.unpool_merge(256).cuda().eval()
+    low = _act(_rand((4, 256, 16, 16), 11)); up1 = _act(_rand((4, 256, 32, 32), 12))
+    with ops.f32_split():
+        plan = m._build(torch.float32)
+    ref = ops.Act.empty(4, 32, 32, 256, torch.float32, low.t.device)
+    plan([low], ref, 16, 16, res=up1, out_step=2, n_classes=4, tile=13)
+    got = ops.Act.empty(4, 32, 32, 256, torch.float32, low.t.device)
+    plan([low], got, 16, 16, res=up1, out_step=2, n_classes=4, tile=13, out_pairs=True)
+    assert torch.equal(got.t.view(torch.int32), _pairs(ref).t.view(torch.int32))
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 37, 51), (3, 511, 511)])
+def test_stem_pair_output_is_the_split_of_its_fp32_output(n, h, w):
+    """okp_stem_forward_nchw_pairs: the split-product stem writing pair format = the pairs of what okp_stem_forward_nchw writes (odd sizes:
+    partial tiles at the right / lower edge)."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import backbone
+    torch.manual_seed(5)
+    m = backbone.convolution(7, 3, 128, stride=2).cuda().eval()
+    frames = torch.from_numpy(synth.normal_like("stem_pairs", (n, 3, h, w), 15)).cuda()
+    with ops.f32_split():
+        plan = m._build(torch.float32, stride="direct")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ref = ops.Act.empty(n, ho, wo, 128, torch.float32, frames.device)
+    plan.from_nchw(frames, ref)
+    got = ops.Act(torch.zeros(n, ho, wo, 128, dtype=torch.float32, device=frames.device))
+    plan.from_nchw(frames, got, out_pairs=True)
+    assert got.pairs and torch.equal(got.t.view(torch.int32), _pairs(ref).t.view(torch.int32))
+
+
+def test_pair_format_is_refused_everywhere_else():
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception.backbone import conv_taps
+    from object_keypoints_amd._lib import OkpError
+    cin = cout = 256
+    wt = _rand((cout, cin, 3, 3), 13) / np.sqrt(cin * 9)
+    x = _act(_rand((1, cin, 16, 16), 14))
+    out = ops.Act.empty(1, 16, 16, cout, torch.float32, x.t.device)
+    with ops.f32_split():
+        split_plan = ops.ConvPlan(torch.float32, [cin], [1], cout, conv_taps(wt.numpy()), None, relu=True)
+    exact_plan = ops.ConvPlan(torch.float32, [cin], [1], cout, conv_taps(wt.numpy()), None, relu=True)
+    with pytest.raises(OkpError, match="patch-resident"):
+        split_plan([_pairs(x)], out, 16, 16, tile=3)                  # a gather tile does not read pairs
+    with pytest.raises(OkpError, match="patch-resident"):
+        split_plan([x], out, 16, 16, out_pairs=True)                   # the heuristic's tile for one frame is not 13
+    assert not out.pairs
+    with pytest.raises(OkpError, match="split-product"):
+        exact_plan([_pairs(x)], out, 16, 16)
+    with pytest.raises(OkpError, match="residual stays float32"):
+        split_plan([x], out, 16, 16, res=_pairs(out), tile=13)
+    with pytest.raises(OkpError, match="pair format"):
+        ops.cast(_pairs(x), torch.float16)
+    with pytest.raises(OkpError, match="pair format"):
+        _pairs(x).view()
+    with pytest.raises(OkpError, match="8-channel groups"):
+        _pairs(x).slice(4, 8)
+    assert _pairs(x).slice(8, 16).pairs
+
+
+@pytest.mark.parametrize("n", [16, 5])
+def test_network_with_pair_tensors_is_bit_identical(n):
+    """The float32x3 network with backbone.PAIR_TENSORS on / off: same bits out.  At 16 frames the 64 x 64 convolutions fill the chip with
+    patch-kernel tiles and the pair format is in use (counted); at 5 frames the heuristic keeps some of them on gather tiles and the
+    tensors around those stay fp32."""
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception import backbone
+    from object_keypoints_amd.perception.models import KeypointNet
+    net = KeypointNet(features=128, heatmaps_out=3, compute_dtype=ops.F32X3)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.fill_state_dict(shapes, seed=0).items()})
+    net.eval().cuda()
+    x = torch.from_numpy(synth.frames(n, seed=4)).cuda()
+    outs = {}
+    for on in (True, False):
+        backbone.PAIR_TENSORS = on
+        try:
+            before = ops.COUNTERS.get("pair_outputs", 0)
+            with torch.no_grad():
+                outs[on] = [o.clone() for o in net.deployed(x)]
+            used = ops.COUNTERS.get("pair_outputs", 0) - before
+        finally:
+            backbone.PAIR_TENSORS = True
+        if on and n >= 16:
+            assert used == 7        # the stem, conv1 and the result of pre[1], conv1 of pre[2], the two hourglasses' merged maps, conv1 of inters[0]
+        if not on:
+            assert used == 0
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     from object_keypoints_amd import _lib
     bound = {n for n, _, _ in _lib.SIGNATURES}
     assert declared == bound, f"ctypes binding and header disagree: {declared ^ bound}"
-    assert _lib.lib().okp_abi_version() == 5 == _lib.OKP_ABI
+    assert _lib.lib().okp_abi_version() == 6 == _lib.OKP_ABI
 
 
 def test_struct_layouts_match_the_header():
@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.okp_tap) == 24
     assert ctypes.sizeof(_lib.okp_camera) == 72 and _lib.okp_camera.model.offset == 64
     assert _lib.okp_conv_args.src.offset == 16 and _lib.okp_conv_args.out.offset == 80
-    assert _lib.okp_conv_args.res.offset == 128 and _lib.okp_conv_args.dw_out.offset == 184 and _lib.okp_conv_args.n_classes.offset == 248 and _lib.okp_conv_args.out16.offset == 256 and _lib.okp_conv_args.res_is_f16.offset == 288 and _lib.okp_conv_args.out_subsample.offset == 292 and ctypes.sizeof(_lib.okp_conv_args) == 296
+    assert _lib.okp_conv_args.res.offset == 128 and _lib.okp_conv_args.dw_out.offset == 184 and _lib.okp_conv_args.n_classes.offset == 248 and _lib.okp_conv_args.out16.offset == 256 and _lib.okp_conv_args.res_is_f16.offset == 288 and _lib.okp_conv_args.out_subsample.offset == 292 and _lib.okp_conv_args.src_pairs.offset == 296 and _lib.okp_conv_args.out_pairs.offset == 300 and ctypes.sizeof(_lib.okp_conv_args) == 304
 
 
 def test_no_cpu_fallback():
