@@ -285,7 +285,9 @@ int okp_head_out_forward(int dtype, const okp_head_out_args* args, void* stream)
 /* The three prediction heads of one stack in one launch (bf16, 128 features): l1 = the fused 256 -> 384 first layers
  * (BN folded, ReLU), l2 = the block-diagonal 384 -> 96 second layers, `args` as for okp_head_out_forward (its `src` is
  * ignored: the 96-channel tensor never exists), x = the 256-channel backbone output.  Replaces prediction_module x 3
- * (perception/models.py:13-18,21-53) and the deployed wrapper's sigmoid (scripts/package_model.py:28). */
+ * (perception/models.py:13-18,21-53) and the deployed wrapper's sigmoid (scripts/package_model.py:28).
+ * OKP_F32X3 plans (ABI 6): the split-product form of the same launch; x is then a PAIR-FORMAT tensor (okp_conv_args.out_pairs: written
+ * by the `cnvs` convolution in front of the heads), fp32 results. */
 int okp_heads_forward(const okp_conv* l1, const okp_conv* l2, const okp_head_out_args* args, const okp_tensor* x, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -62,25 +62,6 @@ __device__ __forceinline__ void okp_split8(const u32x4& r0, const u32x4& r1, u32
 #endif
 }
 
-// 4 fp32 held by a lane -> their fp16 hi / lo halves, two packed dwords each (same arithmetic as okp_split8)
-__device__ __forceinline__ void okp_split4(const f32x4& x, u32x2& hi, u32x2& lo) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float xa = x[2 * q], xb = x[2 * q + 1];
-    f16x2 h2; h2[0] = (_Float16)xa; h2[1] = (_Float16)xb;
-    const uint32_t hw = __builtin_bit_cast(uint32_t, h2);
-    float da, db;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(da) : "v"(hw), "v"(xa));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(db) : "v"(hw), "v"(xb));
-    f16x2 l2; l2[0] = (_Float16)da; l2[1] = (_Float16)db;
-    hi[q] = hw; lo[q] = __builtin_bit_cast(uint32_t, l2);
-  }
-#else
-  hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u};
-#endif
-}
-
 // the high halves alone (single-term slices)
 __device__ __forceinline__ u32x4 okp_hi8(const u32x4& r0, const u32x4& r1) {
   const f32x4 x0 = __builtin_bit_cast(f32x4, r0), x1 = __builtin_bit_cast(f32x4, r1);

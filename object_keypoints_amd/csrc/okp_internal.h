@@ -63,6 +63,27 @@ template <> struct H16<_Float16> {
   static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
   static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
 };
+
+// Split-product operands (OKP_F32X3; struct F32S in okp_igemm_kernel.h): 4 fp32 held by a lane -> their fp16 halves hi = fp16(x),
+// lo = fp16(x - hi), two packed dwords each (the arithmetic of okp_split8: cvt_pk, two exact v_fma_mix differences, cvt_pk)
+static __device__ __forceinline__ void okp_split4(const f32x4& x, u32x2& hi, u32x2& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float xa = x[2 * q], xb = x[2 * q + 1];
+    f16x2 h2; h2[0] = (_Float16)xa; h2[1] = (_Float16)xb;
+    const uint32_t hw = __builtin_bit_cast(uint32_t, h2);
+    float da, db;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(da) : "v"(hw), "v"(xa));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(db) : "v"(hw), "v"(xb));
+    f16x2 l2; l2[0] = (_Float16)da; l2[1] = (_Float16)db;
+    hi[q] = hw; lo[q] = __builtin_bit_cast(uint32_t, l2);
+  }
+#else
+  hi = u32x2{0u, 0u}; lo = u32x2{0u, 0u};
+#endif
+}
+
 template <typename T> __device__ __forceinline__ uint32_t okp_pack2(float a, float b) {     // two fp32 -> one packed dword (RNE)
   typename H16<T>::x2 v;
   v[0] = (T)a; v[1] = (T)b;

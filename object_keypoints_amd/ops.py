@@ -680,18 +680,21 @@ def head_out(src, outputs, w_dev, bias_dev):
 
 
 FUSE_HEADS = True    # 16-bit, 128 features: the three heads of a stack in one launch
+FUSE_HEADS_X3 = True # split-product configuration: the same with three-term products, on the pair-format output of the last `cnvs` convolution
 
 
 def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):
-    """The three prediction heads in one launch (okp_heads_forward): l1 256 -> 384, l2 block-diagonal 384 -> 96 plans."""
-    _refuse_pairs(x)
-    T = _lib.torch_ops()
+    """The three prediction heads in one launch (okp_heads_forward): l1 256 -> 384, l2 block-diagonal 384 -> 96 plans.
+    Split-product plans: x is a pair-format activation (Act.pairs; written by the 3x3 `cnvs` convolution in front of the heads)."""
+    if l1.split != bool(x.pairs):
+        raise OkpError("heads_fused: split-product plans read a pair-format activation, the 16-bit plans an ordinary one")
+    T = _lib.torch_ops() if not l1.split else None
     if T is not None:
         _dispatch(T.heads_forward, l1._h, l2._h, x.t, x.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
                   w_dev, bias_dev, stream_int())
     else:
         a = _head_out_args(x.n, x.h, x.w, outputs, w_dev, bias_dev)
-        xv = x.view()
+        xv = x.view(pairs_ok=True)
         _lib.check(_lib.lib().okp_heads_forward(l1._h, l2._h, ctypes.byref(a), ctypes.byref(xv), stream_handle()), "okp_heads_forward")
     COUNTERS["macs"] += x.n * x.h * x.w * (l1.cout * l1.alg_k + l2.cout * l2.alg_k + 32 * len(outputs))
     COUNTERS["launches"] += 1

@@ -166,8 +166,9 @@ class convolution(_HipModule):
             return out
         return self.forward(ops.pack_frames(frames, dtype), shadow=shadow, compact=compact)
 
-    def forward(self, x, shadow=False, compact=False):
-        """shadow / compact (split-product plans): also write the fp16 copy; keep the fp32 result at even rows / columns only."""
+    def forward(self, x, shadow=False, compact=False, out_pairs=False):
+        """shadow / compact (split-product plans): also write the fp16 copy; keep the fp32 result at even rows / columns only.
+        out_pairs: the result in pair format if this launch runs on the patch-resident split kernel (the caller looks at Act.pairs)."""
         plan = self._plan(("p", x.dtype), lambda: self._build(x.dtype))
         if self.inp_dim == 3:       # x is the packed frame tensor [N, H+6, Wp, 4]
             if x.orig_hw is None:
@@ -187,7 +188,8 @@ class convolution(_HipModule):
                     out = Act.empty(x.n, (ho + 1) // 2, (wo + 1) // 2, self.out_dim, x.dtype, x.t.device)
                     out.compact, sub = True, 2
                 out.shadow = sh
-            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0, out16=out.shadow, out_subsample=sub)
+            pairs = bool(out_pairs and self.takes_pairs(x.n, x.h, x.w, x.dtype) and not (shadow and plan.split))
+            plan([x], out, ho, wo, tile=STEM_TILE if self.inp_dim == 3 else 0, out16=out.shadow, out_subsample=sub, out_pairs=pairs)
         return out
 
 
@@ -606,9 +608,10 @@ class hg(_HipModule):
         taps = [(0, 0, 0, np.ascontiguousarray(wa[:, :, 0, 0])), (1, 0, 0, np.ascontiguousarray(wb[:, :, 0, 0]))]
         return ConvPlan(dtype, [256, 256], [1, 1], 256, taps, ba + bb, relu=True)
 
-    def forward(self, x, dtype=None):
+    def forward(self, x, dtype=None, cnv_pairs=False):
         """x: packed frames (ops.pack_frames), or raw fp32 NCHW frames with the compute dtype given (the stem then reads
-        them itself where it can).  Returns [cnv0, cnv1] as NHWC activations."""
+        them itself where it can).  Returns [cnv0, cnv1] as NHWC activations.  cnv_pairs (split-product configuration): the caller reads
+        the LAST stack's cnv in pair format if it comes that way (Act.pairs; models.KeypointNet: the fused heads)."""
         # mixed configuration with fp16 branches: producers write the fp16 copy their consumer's conv1 reads (stem -> pre.1, pre.1 -> pre.2)
         mix16 = ops.F32_MIX and ops.MIX_BRANCH_SINGLE and ops.MIX_BRANCH_FP16
         # ... and keep the fp32 stream at even pixels only where its single fp32 reader is the next block's stride-2 skip
@@ -666,7 +669,7 @@ class hg(_HipModule):
         last = len(self.hgs) - 1
         for i, (hg_, cnv_) in enumerate(zip(self.hgs, self.cnvs)):
             # (the hourglass's merged map has one reader, cnvs[i]: pair format where that 3x3 takes it)
-            cnv = cnv_(hg_(inter, out_pairs=cnv_.takes_pairs(inter.n, inter.h, inter.w, inter.dtype)))
+            cnv = cnv_(hg_(inter, out_pairs=cnv_.takes_pairs(inter.n, inter.h, inter.w, inter.dtype)), out_pairs=cnv_pairs and i == last)
             cnvs.append(cnv)
             if i < last:
                 merge = self._plan(("m", i, inter.dtype), lambda: self._build_merge(i, inter.dtype))

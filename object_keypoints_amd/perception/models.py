@@ -136,6 +136,8 @@ class KeypointNet(_HipModule):
         outs += [(64, ops.ACT_NONE, centers, k) for k in range(2 * (K - 1))]
         if ops.FUSE_HEADS and cnv.dtype in ops.HALF_DTYPES and self.features == 128:
             ops.heads_fused(l1, l2, cnv, outs, w3, b3)           # one launch, the 384- and 96-channel tensors stay in LDS
+        elif cnv.pairs:                                          # (split-product configuration: requested from the backbone by fused_heads_x3)
+            ops.heads_fused(l1, l2, cnv, outs, w3, b3)
         else:
             a1 = Act.empty(n, h, w, 3 * self.features, cnv.dtype, cnv.t.device)
             l1([cnv], a1, h, w)
@@ -152,11 +154,14 @@ class KeypointNet(_HipModule):
         ops.require_cuda(x, "frames")
         if self.training:
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
+        # split-product configuration: the last stack's `cnv` has one reader, the heads - in pair format where its 3x3 convolution can write
+        # that, the three heads are one launch (ops.heads_fused; _run_heads_ looks at Act.pairs)
+        cnv_pairs = bool(ops.FUSE_HEADS_X3 and self.mfma_split and not self.mixed and self.features == 128)
         if x.dtype == torch.uint8:      # raw RGB [N,H,W,3]: normalisation (and resize + centre crop) fused into the packing kernel
             if self.raw_frame_size is not None and tuple(x.shape[1:3]) != (self.raw_frame_size, self.raw_frame_size):
-                return self.backbone(ops.preprocess_u8(x, self.compute_dtype, size=self.raw_frame_size))
-            return self.backbone(ops.pack_frames_u8(x, self.compute_dtype))
-        return self.backbone(x.float(), self.compute_dtype)
+                return self.backbone(ops.preprocess_u8(x, self.compute_dtype, size=self.raw_frame_size), cnv_pairs=cnv_pairs)
+            return self.backbone(ops.pack_frames_u8(x, self.compute_dtype), cnv_pairs=cnv_pairs)
+        return self.backbone(x.float(), self.compute_dtype, cnv_pairs=cnv_pairs)
 
     def max_frames_per_pass(self, h, w):
         """Frames per network pass such that the largest activation behind the two high-resolution layers (pre[1]'s output, 256

@@ -154,6 +154,54 @@ def test_pair_format_is_refused_everywhere_else():
     assert _pairs(x).slice(8, 16).pairs
 
 
+def _x3_net(k=3, seed=3):
+    from object_keypoints_amd import ops, synth
+    from object_keypoints_amd.perception.models import KeypointNet
+    net = KeypointNet(features=128, heatmaps_out=k, compute_dtype=ops.F32X3)
+    shapes = {kk: tuple(v.shape) for kk, v in net.state_dict().items()}
+    net.load_state_dict({kk: torch.from_numpy(np.array(v)) for kk, v in synth.fill_state_dict(shapes, seed=seed).items()})
+    return net.eval().cuda()
+
+
+@pytest.mark.parametrize("n,h,w,k", [(2, 64, 64, 3), (1, 13, 9, 4), (3, 8, 8, 3), (64, 64, 64, 3)])
+def test_split_product_heads_in_one_launch(n, h, w, k):
+    """okp_heads_forward on split-product plans (okp_heads_x3_kernel: pair-format x, three-term products, h1 / h2 in LDS) against the
+    three-launch path of the same plans on the same values (256 -> 384, 384 -> 96, pointwise output), and - the first frame - against
+    the oracle's prediction modules on the CPU."""
+    from object_keypoints_amd import ops
+    from oracle import net as onet
+    net = _x3_net(k)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    cnv = ops.Act(torch.randn((n, h, w, 256), generator=gen, device="cuda") * 0.7)
+    l0 = ops.COUNTERS["launches"]
+    fused = net._run_heads(1, _pairs(cnv), sigmoid=True)
+    assert ops.COUNTERS["launches"] - l0 == 1
+    ref = net._run_heads(1, cnv, sigmoid=True)
+    assert ops.COUNTERS["launches"] - l0 == 1 + 3                       # 256 -> 384, 384 -> 96, the pointwise output kernel
+    for a, b in zip(fused, ref):
+        assert a.shape == b.shape and a.dtype == torch.float32
+        assert float((a - b).abs().max()) <= 2e-5 * (1.0 + float(b.abs().max()))
+    oracle = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=k), seed=3)
+    x = cnv.t[:1].permute(0, 3, 1, 2).cpu()
+    with torch.no_grad():
+        rh = torch.sigmoid(oracle.heatmap_head.output_head2(x)); rd = oracle.depth_head.output_head2(x); rc = oracle.center_head.output_head2(x)
+    assert float((fused[0][:1].cpu() - rh).abs().max()) <= 2e-5
+    assert float((fused[1][:1].cpu() - rd).abs().max()) <= 2e-5 * (1.0 + float(rd.abs().max()))
+    assert float((fused[2][:1].cpu().reshape(rc.shape) - rc).abs().max()) <= 2e-5 * (1.0 + float(rc.abs().max()))
+
+
+def test_split_product_heads_refuse_an_fp32_activation_and_16_bit_heads_a_pair_one():
+    from object_keypoints_amd import ops
+    from object_keypoints_amd._lib import OkpError
+    net = _x3_net()
+    cnv = ops.Act(torch.randn((1, 8, 8, 256), device="cuda"))
+    with ops.f32_split():
+        l1, l2, w3, b3 = net._build_heads(1, torch.float32, cnv.t.device)
+    out = torch.empty((1, 3, 8, 8), device="cuda")
+    with pytest.raises(OkpError, match="pair-format"):
+        ops.heads_fused(l1, l2, cnv, [(0, ops.ACT_NONE, out, 0)], w3, b3)
+
+
 @pytest.mark.parametrize("n", [16, 5])
 def test_network_with_pair_tensors_is_bit_identical(n):
     """The float32x3 network with backbone.PAIR_TENSORS on / off: same bits out.  At 16 frames the 64 x 64 convolutions fill the chip with
@@ -168,18 +216,43 @@ def test_network_with_pair_tensors_is_bit_identical(n):
     net.eval().cuda()
     x = torch.from_numpy(synth.frames(n, seed=4)).cuda()
     outs = {}
-    for on in (True, False):
-        backbone.PAIR_TENSORS = on
-        try:
+    keep_heads = ops.FUSE_HEADS_X3
+    ops.FUSE_HEADS_X3 = False           # (the one-launch heads sum in another order: compared in test_network_with_fused_split_heads)
+    try:
+        for on in (True, False):
+            backbone.PAIR_TENSORS = on
             before = ops.COUNTERS.get("pair_outputs", 0)
             with torch.no_grad():
                 outs[on] = [o.clone() for o in net.deployed(x)]
             used = ops.COUNTERS.get("pair_outputs", 0) - before
-        finally:
-            backbone.PAIR_TENSORS = True
-        if on and n >= 16:
-            assert used == 7        # the stem, conv1 and the result of pre[1], conv1 of pre[2], the two hourglasses' merged maps, conv1 of inters[0]
-        if not on:
-            assert used == 0
+            if on and n >= 16:
+                assert used == 7        # the stem, conv1 and the result of pre[1], conv1 of pre[2], the two hourglasses' merged maps, conv1 of inters[0]
+            if not on:
+                assert used == 0
+    finally:
+        backbone.PAIR_TENSORS = True
+        ops.FUSE_HEADS_X3 = keep_heads
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+def test_network_with_fused_split_heads():
+    """float32x3 network at 16 frames: the last `cnvs` convolution writes pairs and the heads are one launch; outputs within the
+    split-product tolerance of the three-launch heads (same products, sums in another order)."""
+    from object_keypoints_amd import ops, synth
+    net = _x3_net(seed=0)
+    x = torch.from_numpy(synth.frames(16, seed=4)).cuda()
+    outs = {}
+    keep = ops.FUSE_HEADS_X3
+    try:
+        for on in (True, False):
+            ops.FUSE_HEADS_X3 = on
+            l0 = ops.COUNTERS["launches"]
+            with torch.no_grad():
+                outs[on] = [o.clone() for o in net.deployed(x)]
+            outs[on, "launches"] = ops.COUNTERS["launches"] - l0
+    finally:
+        ops.FUSE_HEADS_X3 = keep
+    assert outs[False, "launches"] - outs[True, "launches"] == 2
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) <= 2e-5 * (1.0 + float(b.abs().max()))
