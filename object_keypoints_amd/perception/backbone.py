@@ -126,7 +126,7 @@ class convolution(_HipModule):
     def takes_pairs(self, n, h, w, dtype):
         """This 3x3 convolution reads a pair-format input of n x h x w pixels (PAIR_TENSORS): a pure split-product plan whose launch runs
         on the patch-resident kernel."""
-        if not (PAIR_TENSORS and dtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX and self.inp_dim != 3 and self.k > 1):
+        if not (PAIR_TENSORS and dtype == torch.float32 and ops.F32_SPLIT and self.inp_dim != 3 and self.k > 1):     # (also the mixed configuration's `cnvs`)
             return False
         plan = self._plan(("p", dtype), lambda: self._build(dtype))
         return bool(getattr(plan, "split", False)) and plan.picks_patch(n, conv_out_size(h, self.k, self.stride, self.pad),
@@ -393,7 +393,7 @@ class unpool_merge(_HipModule):
         if up1.h != 2 * low.h or up1.w != 2 * low.w:
             raise OkpError("unpool_merge: up1 must be twice the size of low")
         out = Act.empty(low.n, 2 * low.h, 2 * low.w, self.dim, low.dtype, low.t.device)
-        out_pairs = bool(out_pairs and PAIR_TENSORS and plan.split and not ops.F32_MIX
+        out_pairs = bool(out_pairs and PAIR_TENSORS and plan.split
                          and plan.picks_patch(low.n, low.h, low.w, [low.t.shape[3]], out_step=2, n_classes=4, tile=UNPOOL_TILE))
         plan([low], out, low.h, low.w, res=up1, out_step=2, n_classes=4, tile=UNPOOL_TILE, out_pairs=out_pairs)     # four output parities, one launch
         return out

@@ -156,7 +156,7 @@ class KeypointNet(_HipModule):
             raise OkpError("the HIP path implements eval-mode inference only; call .eval()")
         # split-product configuration: the last stack's `cnv` has one reader, the heads - in pair format where its 3x3 convolution can write
         # that, the three heads are one launch (ops.heads_fused; _run_heads_ looks at Act.pairs)
-        cnv_pairs = bool(ops.FUSE_HEADS_X3 and self.mfma_split and not self.mixed and self.features == 128)
+        cnv_pairs = bool(ops.FUSE_HEADS_X3 and self.mfma_split and self.features == 128)      # (the mixed configuration's heads are three-term plans too)
         if x.dtype == torch.uint8:      # raw RGB [N,H,W,3]: normalisation (and resize + centre crop) fused into the packing kernel
             if self.raw_frame_size is not None and tuple(x.shape[1:3]) != (self.raw_frame_size, self.raw_frame_size):
                 return self.backbone(ops.preprocess_u8(x, self.compute_dtype, size=self.raw_frame_size), cnv_pairs=cnv_pairs)
