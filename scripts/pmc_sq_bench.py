@@ -14,7 +14,8 @@ import collections, csv, glob, json, re, sys
 
 
 def short(n):
-    return re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", n)[:96]
+    n = re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", n)[:96]
+    return re.sub(r"(okp_igemm_patch_x3_kernel|okp_stem_x3_kernel)(<(true|false)>|ILb[01]E)", r"\1", n)    # instantiations that differ in the output format only: one population
 
 
 def per_kernel(d):
@@ -30,9 +31,10 @@ def per_kernel(d):
 
 a, b = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 traffic = json.load(open(sys.argv[3]))
-dur = {}
-for r in csv.DictReader(open(sys.argv[4])):
-    dur[short(r["Name"])] = float(r["AverageNs"])
+dur_tot, dur_n = collections.Counter(), collections.Counter()
+for r in csv.DictReader(open(sys.argv[4])):          # (instantiations merged by short(): average over all their calls)
+    dur_tot[short(r["Name"])] += float(r["TotalDurationNs"]); dur_n[short(r["Name"])] += float(r["Calls"])
+dur = {k: dur_tot[k] / dur_n[k] for k in dur_tot if dur_n[k]}
 out = {}
 for k in sorted(set(a) | set(b)):
     if "okp_" not in k:

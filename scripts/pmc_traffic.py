@@ -15,6 +15,7 @@ def per_kernel(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", r["Kernel_Name"])[:96]
+            k = re.sub(r"(okp_igemm_patch_x3_kernel|okp_stem_x3_kernel)(<(true|false)>|ILb[01]E)", r"\1", k)    # instantiations that differ in the output format only: one population
             tot[k] += float(r["Counter_Value"])
             cnt[k] += 1
     return tot, cnt

@@ -25,7 +25,7 @@ def short(n):
     if "okp_igemm_kernelI" in n:
         m = re.search(r"okp_igemm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
         return f"igemm<{ 'bf16' if 'DF16b' in m.group(1) else 'f32'},{m.group(2)}x{m.group(3)},ring{m.group(4)}x{m.group(5)}B,mfma{m.group(6)},src{m.group(7)}>"
-    for k in ("okp_stem_x3_kernel", "okp_fire_x3_kernel", "okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_heads_kernel", "okp_peak_nms", "okp_stem_kernel", "okp_fire_chain_kernel", "okp_fire2_kernel", "okp_group_objects", "okp_lift_peaks"):
+    for k in ("okp_stem_x3_kernel", "okp_fire_x3_kernel", "okp_dwconv3x3", "okp_pack_frames", "okp_head_out", "okp_heads_x3_kernel", "okp_heads_kernel", "okp_peak_nms", "okp_stem_kernel", "okp_fire_chain_kernel", "okp_fire2_kernel", "okp_group_objects", "okp_lift_peaks"):
         if k in n: return k
     return n[:40]
 t0 = int(sel[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in sel)
