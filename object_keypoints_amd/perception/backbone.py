@@ -33,6 +33,7 @@ PAIR_TENSORS = True      # split-product configuration: a tensor whose only read
                          # in pair format ([hi | lo] fp16 per 8 channels, okp_conv_args.out_pairs) by its producer, so that its consumers do
                          # not split every landed patch between their K-steps: conv1 -> conv2 of the residual blocks, pre[1] -> pre[2],
                          # hourglass -> cnvs.  Bit-identical results (the same split, done once per element in the producer's epilogue)
+STEM_PAIRS = True        # ... and the split-product stem kernel writes pairs for pre[1] (okp_stem_forward_nchw_pairs)
 UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
 SQUEEZE_TILE = 0         # tile code of the squeeze launch of a fire module that has no one-launch kernel (0 = heuristic)
 STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
@@ -629,7 +630,7 @@ class hg(_HipModule):
         want_shadow = mix16 and sdtype == torch.float32
         chunk = self.front_chunk(n, fh, fw, sdtype, compact=want_shadow and cp[0])
         # pair format between the stem and pre[1] (both of its launches read the stem's map): every frame chunk's launches on the patch kernel
-        stem_pairs = all(self.pre[1].takes_pairs(min(n, q + chunk) - q, conv_out_size(fh, 7, 2, 3), conv_out_size(fw, 7, 2, 3), sdtype)
+        stem_pairs = STEM_PAIRS and all(self.pre[1].takes_pairs(min(n, q + chunk) - q, conv_out_size(fh, 7, 2, 3), conv_out_size(fw, 7, 2, 3), sdtype)
                          for q in range(0, n, chunk))
         if chunk < n:
             # fp32 tensors: the stem output (128 channels at half resolution, 33.5 MB per frame) of a whole batch would pass the 2 GiB
