@@ -19,9 +19,8 @@
 //    16 bytes.  The squeeze result goes to LDS with one ds_write_b128 per 16 pixels, the skip values come and the expand
 //    result goes straight to HBM with one 16-byte access per 16 pixels - no transposition (with the pixels as rows a lane
 //    held channel PAIRS of four pixels: four times the memory instructions, measured 2-3 us of a 16 us tile).
-//  * CIN = 256: squeeze weights stay in registers for the whole kernel (64 VGPRs per lane, gathered once from the
-//    packed [slice][cout][128 B] plan layout).  Wider inputs stream them from L2 two k-steps ahead (three rotating
-//    fragment sets; the counted waits of the x ring include them).  Expand weights are re-fetched per tile.
+//  * Squeeze weights stream from L2 in fragment order two k-steps ahead (three rotating fragment sets; the counted waits of the
+//    x ring include them), or through a per-wave LDS ring where there is LDS to spare (MID >= 192).  Expand weights are re-fetched per tile.
 //  * x streams through a 4-stage LDS ring of 64-byte K-chunks (one MFMA k-step per stage) filled by LDS-DMA; the
 //    16-byte chunk position inside a row is rotated by 2*(row>>2) so that the 16x16 fragment reads are conflict-free.
 //  * The depth-wise branch reads its 3x3 neighbourhoods from the LDS squeeze tile (runs of 4 pixels share a
@@ -90,7 +89,18 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr int HALF = MID;
   constexpr int KS1 = CIN / 32;                    // squeeze k-steps
   constexpr int KS2 = MID / 32;                    // expand k-steps
-  constexpr bool RES = CIN <= 256;                 // squeeze weights resident in registers
+  // Squeeze weights: streamed from L2 in fragment order for every instance (three rotating register sets, or the LDS ring below).  The
+  // CIN = 256 instances kept them RESIDENT until round 5 (64 registers per lane for the whole kernel; -DOKP_F2_RESIDENT_W1 builds that
+  // form): streaming them frees 40 registers, which the depth-wise phase uses to keep DWB squeeze-row reads in flight before their
+  // FMAs - and the kernel no longer sits on 255 registers (the fp16 and stride-2 instances spilled two).  Same bits out; 64 x 64 alone
+  // 89 -> 87 us, 32 x 32 31.9 -> 30.9, bf16 step -0.6 % (profiles/r05u_ab_fire2_batch.txt).
+#ifdef OKP_F2_RESIDENT_W1
+  constexpr bool RES = CIN <= 256;
+  constexpr int DWB = 1;
+#else
+  constexpr bool RES = false;
+  constexpr int DWB = (CIN == 256 && MID == 128) ? 4 : 1;   // (the other instances have no registers to spare: batching spills there)
+#endif
   // Wider inputs stream the squeeze weights.  With >= 192 squeeze channels (one workgroup per CU, LDS to spare) they go through a
   // per-wave LDS ring of DW k-steps filled by LDS-DMA (fragment order: 1 KiB per instruction, read back by the lane that needs it -
   // no barrier, no registers): DW - 1 steps in flight cover the 2-3 us a weight load takes to return under load (hot or cold in L2
@@ -464,6 +474,41 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const f32x4 u0 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * HALF), u1 = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * HALF + 4);
             wt[dy][0] = f32x2{u0[0], u0[1]}; wt[dy][1] = f32x2{u0[2], u0[3]}; wt[dy][2] = f32x2{u1[0], u1[1]}; wt[dy][3] = f32x2{u1[2], u1[3]};
           }
+          if constexpr (DWB > 1) {
+          // the column's squeeze rows in batches of DWB reads, all of a batch in flight before its first FMA (rows beyond
+          // the tile's are read too - the accumulator rows they feed are never stored)
+          constexpr int NSR = STR * (MAXIH - 1) + 3, BT = DWB;
+#pragma unroll
+          for (int s0 = 0; s0 < NSR; s0 += BT) {
+            u32x4 svb[BT];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+              if (s0 + u < NSR) {
+                const int sp = min((s0 + u) * p.SW + STR * ixc + dx, SP - 1);
+                svb[u] = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cg ^ (sp & SWM)) << 4));
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+              const int sr = s0 + u;
+              if (sr < NSR) {
+                f32x2 s2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2[e] = f32x2{H16<T>::lo(svb[u][e]), H16<T>::hi(svb[u][e])};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                  const int iy = (sr - dy) / STR;
+                  if (sr - dy >= 0 && (sr - dy) % STR == 0 && iy < MAXIH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_elementwise_fma(s2[e], wt[dy][e], v[iy][e]);
+                  }
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          } else {
 #pragma unroll
           for (int sr = 0; sr < STR * (MAXIH - 1) + 3; ++sr) {   // squeeze row sr is tap row dy of output row (sr - dy) / STR
             if (sr < STR * (p.IH - 1) + 3) {
@@ -481,6 +526,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
                 }
               }
             }
+          }
           }
         }
 #pragma unroll
