@@ -328,6 +328,8 @@ class ConvPlan:
             raise OkpError("pair-format activations belong to split-product (ops.F32X3) plans")
         if (res is not None and res.pairs) or (dw is not None and (src_pairs or out_pairs)):
             raise OkpError("pair format: the residual stays float32, and the depth-wise branch does not take it")
+        if out_pairs and (out.c0 % 8 or out.t.shape[3] % 8):
+            raise OkpError("pair format: the output window starts on a whole 8-channel group of its tensor")
         extended = out16 is not None or res16 or bool(src_pairs) or bool(out_pairs)
         macs = out.n * ho * wo * self.cout * self.alg_k
         macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
