@@ -166,7 +166,7 @@ def _x3_net(k=3, seed=3):
 @pytest.mark.parametrize("n,h,w,k", [(2, 64, 64, 3), (1, 13, 9, 4), (3, 8, 8, 3), (64, 64, 64, 3)])
 def test_split_product_heads_in_one_launch(n, h, w, k):
     """okp_heads_forward on split-product plans (okp_heads_x3_kernel: pair-format x, three-term products, h1 / h2 in LDS) against the
-    three-launch path of the same plans on the same values (256 -> 384, 384 -> 96, pointwise output), and - the first frame - against
+    three-launch path of the same plans on the same values (256 -> 384, 384 -> 96, pointwise output), and - first, middle and last frame - against
     the oracle's prediction modules on the CPU."""
     from object_keypoints_amd import ops
     from oracle import net as onet
@@ -182,12 +182,13 @@ def test_split_product_heads_in_one_launch(n, h, w, k):
         assert a.shape == b.shape and a.dtype == torch.float32
         assert float((a - b).abs().max()) <= 2e-5 * (1.0 + float(b.abs().max()))
     oracle = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=k), seed=3)
-    x = cnv.t[:1].permute(0, 3, 1, 2).cpu()
-    with torch.no_grad():
-        rh = torch.sigmoid(oracle.heatmap_head.output_head2(x)); rd = oracle.depth_head.output_head2(x); rc = oracle.center_head.output_head2(x)
-    assert float((fused[0][:1].cpu() - rh).abs().max()) <= 2e-5
-    assert float((fused[1][:1].cpu() - rd).abs().max()) <= 2e-5 * (1.0 + float(rd.abs().max()))
-    assert float((fused[2][:1].cpu().reshape(rc.shape) - rc).abs().max()) <= 2e-5 * (1.0 + float(rc.abs().max()))
+    for i in sorted({0, n // 2 - 1 if n > 2 else 0, n - 1}):             # (64 frames: frames 0, 31 and 63)
+        x = cnv.t[i:i + 1].permute(0, 3, 1, 2).cpu()
+        with torch.no_grad():
+            rh = torch.sigmoid(oracle.heatmap_head.output_head2(x)); rd = oracle.depth_head.output_head2(x); rc = oracle.center_head.output_head2(x)
+        assert float((fused[0][i:i + 1].cpu() - rh).abs().max()) <= 2e-5
+        assert float((fused[1][i:i + 1].cpu() - rd).abs().max()) <= 2e-5 * (1.0 + float(rd.abs().max()))
+        assert float((fused[2][i:i + 1].cpu().reshape(rc.shape) - rc).abs().max()) <= 2e-5 * (1.0 + float(rc.abs().max()))
 
 
 def test_split_product_heads_refuse_an_fp32_activation_and_16_bit_heads_a_pair_one():
