@@ -500,7 +500,9 @@ def run_precision(name, ctx, steps, warmup, workload="batch64"):
                            "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f16"], name)}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
+        res["roofline"]["issued_frac"] = 3.0 * res["roofline"]["frac"] if res["roofline"].get("frac") is not None else None   # ... i.e. what the matrix pipe itself sees
     if name == "f32mix":
+        res["roofline_mfma"]["issued_frac"] = 3.0 * res["roofline_mfma"]["frac"] if res["roofline_mfma"].get("frac") is not None else None
         res["roofline_mfma"]["mfma_terms"] = 3       # (the single-term branches of this configuration run on the fp16 patch kernel: float16 plans, not in this population)
     res["collective"] = coll
     if power is not None and name in ("bf16", "f16"):
