@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define OKP_ABI_VERSION 6     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
+#define OKP_ABI_VERSION 7     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
                                  5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14
-                                 6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs */
+                                 6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs
+                                 7: okp_conv_patch_applies */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -150,6 +151,10 @@ typedef struct okp_conv_args {
 int okp_conv_forward(const okp_conv* plan, const okp_conv_args* args, void* stream);
 /* The tile code (1..8, 13; never 14) the launch heuristic picks for these args when args->tile == 0. */
 int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* args);
+/* 1 if the patch-resident kernel (tile 13: the one kernel that reads / writes pair-format tensors) applies to this plan and these args
+ * (only n, ho, wo, n_classes, the sources' pix_stride, dw_w_dev, out16 / res_is_f16 / out_subsample are read: a shape-only query needs no
+ * pointers), else 0 - what a caller that forces args->tile = 13 or requests src_pairs / out_pairs asks first instead of getting OKP_EINVAL. */
+int okp_conv_patch_applies(const okp_conv* plan, const okp_conv_args* args);
 /* Multiply-accumulates one okp_conv_forward performs for these args (algorithmic, unpadded). */
 int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* args);
 

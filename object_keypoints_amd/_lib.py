@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 LIB_PATH = os.environ.get("OKP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libokp_hip.so")   # OKP_LIB: A/B builds
 
 OKP_F32, OKP_BF16, OKP_F16, OKP_F32X3 = 0, 1, 2, 3
-OKP_ABI = 6
+OKP_ABI = 7
 CAM_EQUIDISTANT, CAM_RADTAN = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 HEAD_MAX_OUT = 32
@@ -69,6 +69,7 @@ SIGNATURES = [
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_conv_macs", c_int64, [c_void_p, POINTER(okp_conv_args)]),
+    ("okp_conv_patch_applies", c_int, [c_void_p, POINTER(okp_conv_args)]),
     ("okp_fire_forward", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(okp_fire_args), c_void_p]),
     ("okp_fire_chain_forward", c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int32,
                                        POINTER(okp_tensor), POINTER(okp_tensor), c_void_p]),

@@ -427,9 +427,12 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   }
   if (a->src_pairs || a->out_pairs) {
     bool ok = x3 && !a->out16.data && !a->res_is_f16 && !sub2 && !a->dw_w_dev && a->out.data && (a->src_pairs >> plan->n_src) == 0 && a->src_pairs >= 0 && plan->cout % 8 == 0;
-    for (int s = 0; s < plan->n_src; ++s) if ((a->src_pairs >> s) & 1) ok = ok && plan->cin[s] % 32 == 0 && a->src[s].pix_stride % 8 == 0;
+    for (int s = 0; s < plan->n_src; ++s)
+      if ((a->src_pairs >> s) & 1) ok = ok && plan->cin[s] % 32 == 0 && a->src[s].pix_stride % 8 == 0 && ((uintptr_t)a->src[s].data) % 32 == 0;
+    // (a pair group is 8 channels = 32 bytes of the tensor: a window starts on a group, pixels are whole groups apart)
+    if (a->out_pairs) ok = ok && a->out.pix_stride % 8 == 0 && ((uintptr_t)a->out.data) % 32 == 0;
     if (!ok) {
-      okp_set_error("okp_conv_forward: src_pairs / out_pairs (pair-format tensors) belong to OKP_F32X3 plans with an fp32-geometry out, whole 32-channel chunks per pair source, and no out16 / res_is_f16 / out_subsample / depth-wise branch");
+      okp_set_error("okp_conv_forward: src_pairs / out_pairs (pair-format tensors) belong to OKP_F32X3 plans with an fp32-geometry out, whole 32-channel chunks per pair source, views that start on a 32-byte pair group with pix_stride % 8 == 0, and no out16 / res_is_f16 / out_subsample / depth-wise branch");
       return OKP_EINVAL;
     }
   }
@@ -544,6 +547,19 @@ extern "C" int okp_conv_select_tile(const okp_conv* plan, const okp_conv_args* a
   if (!plan || !a) return 0;
   if (a->tile) return a->tile;
   return select_tile(plan, a);
+}
+
+// okp_patch_supported on the fields of the args it reads: what a caller that forces tile 13 (or wants pair-format tensors) asks first
+extern "C" int okp_conv_patch_applies(const okp_conv* plan, const okp_conv_args* a) {
+  if (!plan || !a) return 0;
+  OkpIgemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.n_classes = a->n_classes > 1 ? a->n_classes : 1;
+  p.dw_w = a->dw_w_dev; p.Ho = a->ho; p.Wo = a->wo;
+  p.out16 = a->out16.data; p.res16 = a->res_is_f16 ? 1 : 0; p.out_sub2 = a->out_subsample == 2 ? 1 : 0;
+  p.out = a->out.data ? a->out.data : (a->out16.data ? nullptr : (void*)1);      // (shape-only queries carry no pointers: "out is written")
+  for (int s = 0; s < plan->n_src; ++s) p.src_pix_stride[s] = a->src[s].pix_stride;
+  return okp_patch_supported(plan, p) ? 1 : 0;
 }
 
 extern "C" int64_t okp_conv_macs(const okp_conv* plan, const okp_conv_args* a) {

@@ -379,8 +379,8 @@ static int heads_forward_x3(const okp_conv* l1, const okp_conv* l2, const okp_he
   }
   if (a->n_out < 1 || a->n_out > OKP_HEAD_MAX_OUT) { okp_set_error("okp_heads_forward: n_out %d out of range", a->n_out); return OKP_EINVAL; }
   if (a->n < 1 || a->h < 1 || a->w < 1) return OKP_OK;
-  if (x->pix_stride < CIN || x->pix_stride % 8 || ((uintptr_t)x->data) % 16 || x->bytes <= 0 || x->bytes >= 0x7FFF0000ll) {
-    okp_set_error("okp_heads_forward: x must be a 16-byte aligned pair-format view of >= 256 channels in whole 8-channel groups, < 2 GiB"); return OKP_EINVAL;
+  if (x->pix_stride < CIN || x->pix_stride % 8 || ((uintptr_t)x->data) % 32 || x->bytes <= 0 || x->bytes >= 0x7FFF0000ll) {
+    okp_set_error("okp_heads_forward: x must be a 32-byte aligned (one pair group) pair-format view of >= 256 channels in whole 8-channel groups, < 2 GiB"); return OKP_EINVAL;
   }
   x3::Params p;
   std::memset(&p, 0, sizeof(p));

@@ -116,6 +116,18 @@ def _dispatch(fn, *args):
         raise OkpError(str(e).split("\n")[0]) from None
 
 
+def _ops():
+    """torch.ops.okp, or None with the ctypes call that follows counted (COUNTERS["ctypes_launches"])."""
+    T = _lib.torch_ops()
+    if T is None:
+        COUNTERS["ctypes_launches"] += 1
+    return T
+
+
+def _cam_list(cam):
+    return [cam.fx, cam.fy, cam.cx, cam.cy, cam.d[0], cam.d[1], cam.d[2], cam.d[3], float(cam.model)]
+
+
 def require_cuda(t, what):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise OkpError(f"{what} must be a device tensor: the HIP path has no CPU fallback")
@@ -222,7 +234,6 @@ class ConvPlan:
         self._strides = (list(strides) + [1])[:2]
         self._tap_srcs = [t[0] for t in taps]
         n_taps = len(taps)
-        arr_t = (_lib.okp_tap * n_taps)()
         keep = []
         k = 0
         for i, (src, dy, dx, w) in enumerate(taps):
@@ -230,7 +241,6 @@ class ConvPlan:
             if w.shape != (cout, cins[src]):
                 raise OkpError(f"tap {i}: weight shape {w.shape} != {(cout, cins[src])}")
             keep.append(w)
-            arr_t[i] = _lib.okp_tap(src, dy, dx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
             k += cins[src]
         self.alg_k = k if alg_k is None else alg_k      # algorithmic reduction length per output element
         b = None
@@ -238,17 +248,28 @@ class ConvPlan:
             b = np.ascontiguousarray(bias, dtype=np.float32)
             if b.shape != (cout,):
                 raise OkpError("bias shape")
+        if self.tap_terms is not None and len(self.tap_terms) != n_taps:
+            raise OkpError("tap_terms: one entry per tap")
+        code = OKP_F32X3 if self.split else okp_dtype(dtype)
+        act = ACT_RELU if relu else ACT_NONE
+        T = _ops()
+        if T is not None:       # torch.ops.okp.conv_create: host tensors in, opaque handle out
+            self._h = _dispatch(T.conv_create, code, list(cins), (list(strides) + [1] * len(cins))[:len(cins)], cout, [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps],
+                                [torch.from_numpy(w) for w in keep], torch.from_numpy(b) if b is not None else None, act, self.tap_terms or [])
+            self._via_torch = True
+            return
+        self._via_torch = False
+        arr_t = (_lib.okp_tap * n_taps)()
+        for i, (src, dy, dx, _) in enumerate(taps):
+            arr_t[i] = _lib.okp_tap(src, dy, dx, keep[i].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         cin_arr = (ctypes.c_int32 * 2)(*(list(cins) + [0])[:2])
         st_arr = (ctypes.c_int32 * 2)(*(list(strides) + [1])[:2])
         bp = b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if b is not None else None
         if self.tap_terms is not None:
-            if len(self.tap_terms) != n_taps:
-                raise OkpError("tap_terms: one entry per tap")
             terms = (ctypes.c_uint8 * n_taps)(*self.tap_terms)
-            self._h = L.okp_conv_create_x3(self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, terms, bp, ACT_RELU if relu else ACT_NONE)
+            self._h = L.okp_conv_create_x3(self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, terms, bp, act)
         else:
-            self._h = L.okp_conv_create(OKP_F32X3 if self.split else okp_dtype(dtype), self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, bp,
-                                        ACT_RELU if relu else ACT_NONE)
+            self._h = L.okp_conv_create(code, self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, bp, act)
         if not self._h:
             raise OkpError("okp_conv_create: " + L.okp_last_error().decode())
 
@@ -256,7 +277,7 @@ class ConvPlan:
         h, self._h = getattr(self, "_h", None), None
         try:
             if h and _lib is not None and _lib._lib is not None:
-                _lib._lib.okp_conv_destroy(h)
+                _lib._lib.okp_conv_destroy(h)       # (the same C symbol torch.ops.okp.conv_destroy calls; safe during interpreter shutdown)
         except Exception:       # interpreter shutdown: the process is going away with its HBM
             pass
 
@@ -265,14 +286,17 @@ class ConvPlan:
         on the patch-resident kernel (tile 13 of okp_conv_forward's heuristic, okp_conv_select_tile) - the one kernel that reads and
         writes pair-format activations."""
         tile = tile or FORCE_TILE
-        if tile:
-            return tile == 13
+        T = _ops()
+        if T is not None:
+            return bool(_dispatch(T.conv_picks_patch, self._h, n, ho, wo, list(src_pix_strides), self.cout, out_step, n_classes, tile))
         a = _lib.okp_conv_args()
         a.n, a.ho, a.wo = n, ho, wo
         for i, ps in enumerate(src_pix_strides):
             a.src[i] = _lib.okp_tensor(1, 1, 1, ps, 1)          # (the heuristic reads pixel strides and the output grid only)
         a.out = _lib.okp_tensor(1, ho * out_step, wo * out_step, self.cout, 1)
         a.out_step, a.n_classes = out_step, n_classes
+        if tile:                                                # a forced tile 13 on a shape the kernel refuses is not a "yes" (the launch would end in EINVAL)
+            return tile == 13 and bool(_lib.lib().okp_conv_patch_applies(self._h, ctypes.byref(a)))
         return _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a)) == 13
 
     def _algorithmic_bytes(self, srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample):
@@ -330,11 +354,12 @@ class ConvPlan:
             raise OkpError("pair format: the residual stays float32, and the depth-wise branch does not take it")
         if out_pairs and (out.c0 % 8 or out.t.shape[3] % 8):
             raise OkpError("pair format: the output window starts on a whole 8-channel group of its tensor")
-        extended = out16 is not None or res16 or bool(src_pairs) or bool(out_pairs)
+        extended = out16 is not None or res16 or out_subsample == 2 or not write_out      # (what keeps a split-product launch off the patch-resident kernel)
         macs = out.n * ho * wo * self.cout * self.alg_k
         macs_dw = out.n * ho * wo * self.cout * 9 if dw is not None else 0
         tile = tile or FORCE_TILE
-        T = _lib.torch_ops() if not extended else None       # (the dispatcher shim carries the common arguments; the ctypes binding all)
+        out.pairs = False                # whatever this Act held before, the launch overwrites it with ordinary values - or pairs, set below
+        T = _ops()
         hook = LAUNCH_HOOK
         if T is not None:
             s1 = srcs[1] if len(srcs) > 1 else None
@@ -342,15 +367,17 @@ class ConvPlan:
                 self.last_launch = (out.n, ho, wo, dw is not None, res is not None, n_classes)
                 self.last_bytes = self._algorithmic_bytes(srcs, out, ho, wo, res, out_step, n_classes, dw, out16, write_out, out_subsample)
                 tile = _dispatch(T.conv_select_tile, self._h, srcs[0].t, srcs[0].c0, s1.t if s1 else None, s1.c0 if s1 else 0, out.t, out.c0, ho, wo,
-                                 out_step, oy, ox, tile, n_classes, dw is not None)
+                                 out_step, oy, ox, tile, n_classes, dw is not None, extended)
                 token = hook.before(self, tile, macs)
             if dw is not None:
                 dw_w, dw_b, dw_out, dw_res = dw
+                dw_out.pairs = False
                 dwa = (dw_w, dw_b, dw_out.t, dw_out.c0, dw_res.t if dw_res is not None else None, dw_res.c0 if dw_res is not None else 0)
             else:
                 dwa = (None, None, None, 0, None, 0)
             _dispatch(T.conv_forward, self._h, srcs[0].t, srcs[0].c0, s1.t if s1 else None, s1.c0 if s1 else 0, out.t, out.c0, ho, wo,
-                      res.t if res is not None else None, res.c0 if res is not None else 0, out_step, oy, ox, tile, n_classes, *dwa, stream_int())
+                      res.t if res is not None else None, res.c0 if res is not None else 0, out_step, oy, ox, tile, n_classes, *dwa, stream_int(),
+                      out16.t if out16 is not None else None, out16.c0 if out16 is not None else 0, bool(write_out), out_subsample, src_pairs, bool(out_pairs))
             if hook is not None:
                 hook.after(token)
         else:
@@ -359,7 +386,6 @@ class ConvPlan:
             for i, s in enumerate(srcs):
                 a.src[i] = s.view(pairs_ok=True)
             a.src_pairs, a.out_pairs = src_pairs, 1 if out_pairs else 0
-            out.pairs = False
             a.out = out.view()
             if not write_out:
                 a.out.data = None
@@ -373,6 +399,7 @@ class ConvPlan:
             a.n_classes = n_classes
             if dw is not None:
                 dw_w, dw_b, dw_out, dw_res = dw
+                dw_out.pairs = False
                 a.dw_w_dev, a.dw_bias_dev = dw_w.data_ptr(), dw_b.data_ptr()
                 a.dw_out = dw_out.view()
                 a.dw_res = dw_res.view() if dw_res is not None else _NULL_TENSOR
@@ -382,15 +409,17 @@ class ConvPlan:
                 a.tile = _lib.lib().okp_conv_select_tile(self._h, ctypes.byref(a))
                 token = hook.before(self, a.tile, macs)
             _lib.check(_lib.lib().okp_conv_forward(self._h, ctypes.byref(a), stream_handle()), "okp_conv_forward")
-            out.pairs = bool(out_pairs)
-            COUNTERS["pair_outputs"] += 1 if out_pairs else 0
             if hook is not None:
                 hook.after(token)
+        out.pairs = bool(out_pairs)
+        COUNTERS["pair_outputs"] += 1 if out_pairs else 0
         COUNTERS["macs"] += macs + macs_dw
         COUNTERS["launches"] += 1
 
 
-COUNTERS = {"macs": 0, "launches": 0, "pair_outputs": 0}
+# "ctypes_launches": C-ABI calls (launches and plan creations) that went through the ctypes binding instead of torch.ops.okp - stays 0 while the
+# dispatcher shim is loaded (tests/test_gpu_torch_ops.py); the ctypes binding serves non-torch hosts and OKP_TORCH_OPS=0
+COUNTERS = {"macs": 0, "launches": 0, "pair_outputs": 0, "ctypes_launches": 0}
 LAUNCH_HOOK = None      # bench.py: object with before(plan, tile, macs) / after(token) bracketing conv launches
 FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256), 0 = heuristic
 
@@ -398,7 +427,8 @@ FORCE_TILE = 0          # tests: 1/2/3 pins the implicit-GEMM tile (64/128/256),
 def fire_fused(squeeze, expand, wd_dev, bd_dev, x, out, stride, skip):
     """One-launch fire module (16-bit plans: okp_fire2.hip; split-product plans: okp_fire_x3.hip): see okp_fire_forward in include/okp.h."""
     _refuse_pairs(x)
-    T = _lib.torch_ops()
+    out.pairs = False
+    T = _ops()
     if T is not None:
         _dispatch(T.fire_forward, squeeze._h, expand._h, wd_dev, bd_dev, x.t, x.c0, out.t, out.c0, stride, bool(skip), stream_int())
     else:
@@ -426,7 +456,8 @@ def fire_chain(modules, x, out):
     """modules: list of (squeeze plan, expand plan, dw weights, dw bias) of consecutive fire(512, 512) modules; x, out: Acts."""
     _refuse_pairs(x)
     n = len(modules)
-    T = _lib.torch_ops()
+    out.pairs = False
+    T = _ops()
     if T is not None:
         _dispatch(T.fire_chain_forward, [m[0]._h for m in modules], [m[1]._h for m in modules], [m[2] for m in modules], [m[3] for m in modules],
                   x.t, x.c0, out.t, out.c0, stream_int())
@@ -477,7 +508,11 @@ LIGHT_EVENTS = True     # forks / joins through okp_stream_wait_stream (events w
 def stream_wait(waiter, signaller):
     """`waiter` (torch.cuda.Stream) waits for the work enqueued on `signaller` so far."""
     if LIGHT_EVENTS:
-        _lib.check(_lib.lib().okp_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaller.cuda_stream)), "okp_stream_wait_stream")
+        T = _ops()
+        if T is not None:
+            _dispatch(T.stream_wait_stream, waiter.cuda_stream, signaller.cuda_stream)
+        else:
+            _lib.check(_lib.lib().okp_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaller.cuda_stream)), "okp_stream_wait_stream")
     else:
         waiter.wait_stream(signaller)
 
@@ -488,7 +523,12 @@ def cast(src, dtype):
     if src.c0 != 0 or src.c != src.t.shape[3]:
         raise OkpError("cast takes a whole tensor, not a channel window")
     out = Act(torch.empty(src.t.shape, dtype=dtype, device=src.t.device))
-    _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(), stream_handle()), "okp_cast")
+    okp_dtype(dtype)
+    T = _ops()
+    if T is not None:
+        _dispatch(T.cast, src.t, out.t, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(), stream_handle()), "okp_cast")
     COUNTERS["launches"] += 1
     return out
 
@@ -499,7 +539,11 @@ def add_f16_f32(a16, b32, relu=True):
     if a16.dtype != torch.float16 or b32.dtype != torch.float32 or a16.t.shape != b32.t.shape or a16.c0 or b32.c0 or a16.c != a16.t.shape[3] or b32.c != b32.t.shape[3]:
         raise OkpError("add_f16_f32 takes whole float16 / float32 tensors of one shape")
     out = Act(torch.empty_like(b32.t))
-    _lib.check(_lib.lib().okp_add_f16_f32(a16.t.data_ptr(), b32.t.data_ptr(), out.t.data_ptr(), out.t.numel(), ACT_RELU if relu else ACT_NONE, stream_handle()), "okp_add_f16_f32")
+    T = _ops()
+    if T is not None:
+        _dispatch(T.add_f16_f32, a16.t, b32.t, out.t, ACT_RELU if relu else ACT_NONE, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_add_f16_f32(a16.t.data_ptr(), b32.t.data_ptr(), out.t.data_ptr(), out.t.numel(), ACT_RELU if relu else ACT_NONE, stream_handle()), "okp_add_f16_f32")
     COUNTERS["launches"] += 1
     return out
 
@@ -507,6 +551,14 @@ def add_f16_f32(a16, b32, relu=True):
 def dwconv3x3(src, w_dev, bias_dev, out, stride, res=None, relu=True):
     _refuse_pairs(src, res)
     dt = okp_dtype(src.dtype)
+    out.pairs = False
+    T = _ops()
+    if T is not None:
+        _dispatch(T.dwconv3x3_forward, src.t, src.c0, src.c, stride, w_dev, bias_dev, res.t if res is not None else None, res.c0 if res is not None else 0,
+                  out.t, out.c0, ACT_RELU if relu else ACT_NONE, stream_int())
+        COUNTERS["macs"] += out.n * out.h * out.w * src.c * 9
+        COUNTERS["launches"] += 1
+        return
     sv, ov = src.view(), out.view()
     rv = res.view() if res is not None else None
     _lib.check(_lib.lib().okp_dwconv3x3_forward(dt, src.n, src.c, stride, ctypes.byref(sv), w_dev.data_ptr(), bias_dev.data_ptr(),
@@ -531,7 +583,12 @@ def pack_frames(frames, dtype):
     n, _, h, w = frames.shape
     wp = stem_packed_width(w)
     out = torch.empty((n, h + 6, wp, 4), dtype=dtype, device=frames.device)
-    _lib.check(_lib.lib().okp_pack_frames(okp_dtype(dtype), frames.data_ptr(), n, h, w, out.data_ptr(), wp, stream_handle()), "okp_pack_frames")
+    okp_dtype(dtype)
+    T = _ops()
+    if T is not None:
+        _dispatch(T.pack_frames, frames, out, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_pack_frames(okp_dtype(dtype), frames.data_ptr(), n, h, w, out.data_ptr(), wp, stream_handle()), "okp_pack_frames")
     COUNTERS["launches"] += 1
     act = Act(out)
     act.orig_hw = (h, w)
@@ -553,6 +610,10 @@ class StemPlan:
             raise OkpError("the stem kernel computes in bfloat16, float16 or (float32 inside ops.f32_split()) split products")
         self.dtype = dtype
         L = _lib.lib()
+        T = _ops()
+        if T is not None:
+            self._h = _dispatch(T.stem_create, OKP_F32X3 if self.split else okp_dtype(dtype), torch.from_numpy(w), torch.from_numpy(b))
+            return
         self._h = L.okp_stem_create_dtype(OKP_F32X3 if self.split else okp_dtype(dtype), w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         if not self._h:
             raise OkpError("okp_stem_create: " + L.okp_last_error().decode())
@@ -573,13 +634,16 @@ class StemPlan:
             raise OkpError("frames must be float32 [N,3,H,W] and the output of the plan's element type")
         frames = frames.contiguous()
         n, _, h, w = frames.shape
-        T = _lib.torch_ops()
+        T = _ops()
         out.pairs = False
         if out_pairs:
             if not self.split:
                 raise OkpError("pair-format output belongs to the split-product stem")
-            ov = out.view()
-            _lib.check(_lib.lib().okp_stem_forward_nchw_pairs(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw_pairs")
+            if T is not None:
+                _dispatch(T.stem_forward_nchw_pairs, self._h, frames, out.t, out.c0, stream_int())
+            else:
+                ov = out.view()
+                _lib.check(_lib.lib().okp_stem_forward_nchw_pairs(self._h, n, h, w, frames.data_ptr(), ctypes.byref(ov), stream_handle()), "okp_stem_forward_nchw_pairs")
             out.pairs = True
             COUNTERS["pair_outputs"] += 1
         elif T is not None:
@@ -594,8 +658,13 @@ class StemPlan:
         if packed.orig_hw is None or packed.dtype != self.dtype or out.dtype != self.dtype or self.split:
             raise OkpError("stem input must be the output of ops.pack_frames in the plan's 16-bit type (the split-product stem reads NCHW frames: from_nchw)")
         h, w = packed.orig_hw
-        pv, ov = packed.view(), out.view()
-        _lib.check(_lib.lib().okp_stem_forward(self._h, packed.n, h, w, ctypes.byref(pv), ctypes.byref(ov), stream_handle()), "okp_stem_forward")
+        out.pairs = False
+        T = _ops()
+        if T is not None:
+            _dispatch(T.stem_forward, self._h, packed.t, h, w, out.t, out.c0, stream_int())
+        else:
+            pv, ov = packed.view(), out.view()
+            _lib.check(_lib.lib().okp_stem_forward(self._h, packed.n, h, w, ctypes.byref(pv), ctypes.byref(ov), stream_handle()), "okp_stem_forward")
         COUNTERS["macs"] += out.n * out.h * out.w * 128 * 147
         COUNTERS["launches"] += 1
 
@@ -614,6 +683,14 @@ def pack_frames_u8(frames, dtype, mean=RGB_MEAN, std=RGB_STD):
     n, h, w, _ = frames.shape
     wp = stem_packed_width(w)
     out = torch.empty((n, h + 6, wp, 4), dtype=dtype, device=frames.device)
+    okp_dtype(dtype)
+    T = _ops()
+    if T is not None:
+        _dispatch(T.pack_frames_u8, frames, [float(np.float32(v)) for v in mean], [float(np.float32(v)) for v in std], out, stream_int())
+        COUNTERS["launches"] += 1
+        act = Act(out)
+        act.orig_hw = (h, w)
+        return act
     m = (ctypes.c_float * 3)(*mean)
     sd = (ctypes.c_float * 3)(*std)
     _lib.check(_lib.lib().okp_pack_frames_u8(okp_dtype(dtype), frames.data_ptr(), n, h, w, m, sd, out.data_ptr(), wp, stream_handle()), "okp_pack_frames_u8")
@@ -643,6 +720,14 @@ def preprocess_u8(frames, dtype, size=511, mean=RGB_MEAN, std=RGB_STD):
     cy, cx = (rh - size) // 2, (rw - size) // 2
     wp = stem_packed_width(size)
     out = torch.empty((n, size + 6, wp, 4), dtype=dtype, device=frames.device)
+    okp_dtype(dtype)
+    T = _ops()
+    if T is not None:
+        _dispatch(T.preprocess_u8, frames, rh, rw, cy, cx, size, size, [float(np.float32(v)) for v in mean], [float(np.float32(v)) for v in std], out, stream_int())
+        COUNTERS["launches"] += 1
+        act = Act(out)
+        act.orig_hw = (size, size)
+        return act
     m = (ctypes.c_float * 3)(*mean)
     sd = (ctypes.c_float * 3)(*std)
     _lib.check(_lib.lib().okp_preprocess_u8(okp_dtype(dtype), frames.data_ptr(), n, sh, sw, rh, rw, cy, cx, size, size, m, sd,
@@ -669,7 +754,7 @@ def _head_out_args(n, h, w, outputs, w_dev, bias_dev):
 def head_out(src, outputs, w_dev, bias_dev):
     """outputs: list of (in_c_off, act, out_tensor[N,Cx,H,W] fp32, channel index)."""
     _refuse_pairs(src)
-    T = _lib.torch_ops()
+    T = _ops()
     if T is not None:
         _dispatch(T.head_out_forward, src.t, src.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
                   w_dev, bias_dev, stream_int())
@@ -690,7 +775,7 @@ def heads_fused(l1, l2, x, outputs, w_dev, bias_dev):
     Split-product plans: x is a pair-format activation (Act.pairs; written by the 3x3 `cnvs` convolution in front of the heads)."""
     if l1.split != bool(x.pairs):
         raise OkpError("heads_fused: split-product plans read a pair-format activation, the 16-bit plans an ordinary one")
-    T = _lib.torch_ops() if not l1.split else None
+    T = _ops()
     if T is not None:
         _dispatch(T.heads_forward, l1._h, l2._h, x.t, x.c0, [o[0] for o in outputs], [o[1] for o in outputs], [o[2] for o in outputs], [o[3] for o in outputs],
                   w_dev, bias_dev, stream_int())
@@ -713,7 +798,7 @@ def peak_nms(heat, cap=64):
     count = torch.empty((n, k), dtype=torch.int32, device=heat.device)
     yx = torch.empty((n, k, cap, 2), dtype=torch.int32, device=heat.device)
     xyc = torch.empty((n, k, cap, 3), dtype=torch.float32, device=heat.device)
-    T = _lib.torch_ops()
+    T = _ops()
     if T is not None:
         _dispatch(T.peak_nms, heat, cap, count, yx, xyc, stream_int())
     else:
@@ -729,7 +814,11 @@ def nms_maxpool(x, size=5):
     x = x.contiguous()
     out = torch.empty_like(x)
     n, c, h, w = x.shape
-    _lib.check(_lib.lib().okp_nms_maxpool(x.data_ptr(), n * c, h, w, size, out.data_ptr(), stream_handle()), "okp_nms_maxpool")
+    T = _ops()
+    if T is not None:
+        _dispatch(T.nms_maxpool, x, size, out, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_nms_maxpool(x.data_ptr(), n * c, h, w, size, out.data_ptr(), stream_handle()), "okp_nms_maxpool")
     return out
 
 
@@ -750,7 +839,11 @@ def camera_undistort(cam, xy):
     require_cuda(xy, "xy")
     xy = xy.to(torch.float32).contiguous()
     out = torch.empty((xy.shape[0], 2), dtype=torch.float64, device=xy.device)
-    _lib.check(_lib.lib().okp_camera_undistort(ctypes.byref(cam), xy.data_ptr(), xy.shape[0], out.data_ptr(), stream_handle()), "okp_camera_undistort")
+    T = _ops()
+    if T is not None:
+        _dispatch(T.camera_undistort, _cam_list(cam), xy, out, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_camera_undistort(ctypes.byref(cam), xy.data_ptr(), xy.shape[0], out.data_ptr(), stream_handle()), "okp_camera_undistort")
     return out
 
 
@@ -766,8 +859,12 @@ def unproject_depth(cam, xy, map_id, depth, max_x, max_y):
     if depth.dtype != torch.float32 or depth.dim() != 3:
         raise OkpError("depth must be float32 [maps,H,W]")
     out = torch.empty((xy.shape[0], 3), dtype=torch.float64, device=xy.device)
-    _lib.check(_lib.lib().okp_unproject_depth(ctypes.byref(cam), xy.data_ptr(), map_id.data_ptr(), xy.shape[0], depth.data_ptr(),
-                                              depth.shape[1], depth.shape[2], max_x, max_y, out.data_ptr(), stream_handle()), "okp_unproject_depth")
+    T = _ops()
+    if T is not None:
+        _dispatch(T.unproject_depth, _cam_list(cam), xy, map_id, depth, max_x, max_y, out, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_unproject_depth(ctypes.byref(cam), xy.data_ptr(), map_id.data_ptr(), xy.shape[0], depth.data_ptr(),
+                                                  depth.shape[1], depth.shape[2], max_x, max_y, out.data_ptr(), stream_handle()), "okp_unproject_depth")
     return out
 
 
@@ -779,9 +876,9 @@ def lift_peaks(cam, count, xyc, depth, max_x, max_y):
     if depth.dtype != torch.float32 or depth.shape[:2] != (n, k):
         raise OkpError("depth must be float32 [N,K,H,W] matching the peak tensors")
     out = torch.empty((n, k, cap, 4), dtype=torch.float64, device=xyc.device)
-    T = _lib.torch_ops()
+    T = _ops()
     if T is not None:
-        _dispatch(T.lift_peaks, [cam.fx, cam.fy, cam.cx, cam.cy, cam.d[0], cam.d[1], cam.d[2], cam.d[3], float(cam.model)], count, xyc, depth, max_x, max_y, out, stream_int())
+        _dispatch(T.lift_peaks, _cam_list(cam), count, xyc, depth, max_x, max_y, out, stream_int())
     else:
         _lib.check(_lib.lib().okp_lift_peaks(ctypes.byref(cam), count.data_ptr(), xyc.data_ptr(), n * k, cap, depth.data_ptr(),
                                              depth.shape[2], depth.shape[3], max_x, max_y, out.data_ptr(), stream_handle()), "okp_lift_peaks")
@@ -803,7 +900,7 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
     votes = torch.empty((n, max_obj, k - 1), dtype=torch.int32, device=dev)
     assign = torch.empty((n, k, cap), dtype=torch.int32, device=dev)
     pred = torch.empty((n, k, cap, 2), dtype=torch.float64, device=dev)      # (the kernel zeroes the unused slots)
-    T = _lib.torch_ops()
+    T = _ops()
     if T is not None:
         _dispatch(T.group_objects, count, xyc, centers, [int(c) for c in type_count], float(max_dist), max_obj, max_sel, n_obj, sel, votes, assign, pred, stream_int())
     else:
@@ -820,7 +917,11 @@ def capacity_overflow(count, cap, max_obj):
     require_cuda(count, "count")
     flag = torch.empty((1,), dtype=torch.int32, device=count.device)
     n, k = count.shape
-    _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
+    T = _ops()
+    if T is not None:
+        _dispatch(T.capacity_overflow, count.contiguous(), k, cap, max_obj, flag, stream_int())
+    else:
+        _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
     return flag[0]
 
 
@@ -831,6 +932,12 @@ def triangulate_dlt(cam_l, cam_r, T_RL, left_xy, right_xy, F=None):
     if left_xy.shape != right_xy.shape:
         raise OkpError("left/right point counts differ")
     T = np.ascontiguousarray(np.asarray(T_RL, dtype=np.float64)[:3, :4])
+    TO = _ops()
+    if TO is not None:
+        out = torch.empty((left_xy.shape[0], 3), dtype=torch.float64, device=left_xy.device)
+        Fl = [] if F is None else [float(v) for v in np.asarray(F, dtype=np.float64).reshape(9)]
+        _dispatch(TO.triangulate_dlt, _cam_list(cam_l), _cam_list(cam_r), [float(v) for v in T.reshape(12)], Fl, left_xy, right_xy, out, stream_int())
+        return out
     Fp = None
     if F is not None:
         Fa = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(3, 3))

@@ -275,54 +275,70 @@ class KeypointExtractionComponent:
 
 
 class ObjectExtraction:
-    """Centre-vector voting (pipeline.py:93-153): every non-centre peak votes for the object whose centre is
-    nearest to `pixel centre + predicted offset`, votes further than 20 px are dropped, and surplus detections
-    of a type are reduced to the configured count (arg-max confidence, or k-means for multi-instance types)."""
+    """Centre-vector voting (interface and results of the reference's pipeline.py:93-153): the peaks of map 0 are object centres; every
+    other peak votes with `pixel centre + predicted offset` at its rounded position for the nearest centre, votes further than
+    VOTE_RADIUS pixels are dropped; per object and keypoint type the surplus over the configured count is reduced (most confident
+    detection for a single-instance type, k-means centres for a multi-instance one).  Returns one dict per centre peak:
+    {'center', 'heatmap_points': per type (n, 2) or empty, 'confidence': per type list, 'p_centers': the votes received}."""
+
+    VOTE_RADIUS = 20.0
 
     def __init__(self, keypoint_config, prediction_size):
         self.keypoint_config = keypoint_config['keypoint_config']
         self.prediction_size = prediction_size
-        self.max = np.array(self.prediction_size[::-1], dtype=np.int32) - 1
+        h, w = prediction_size
         self.min = np.zeros(2, dtype=np.int32)
-        h, w = self.prediction_size
-        self.image_indices = np.stack(np.meshgrid(np.arange(w) + 0.5, np.arange(h) + 0.5, indexing="xy"))   # (2,h,w) = (x,y)
+        self.max = np.array([w - 1, h - 1], dtype=np.int32)                      # (x, y) bounds of a rounded peak
+        cols, rows = np.arange(w) + 0.5, np.arange(h) + 0.5
+        self.image_indices = np.stack([np.broadcast_to(cols[None, :], (h, w)), np.broadcast_to(rows[:, None], (h, w))])   # (2, h, w): x, y of pixel centres
+
+    def _votes(self, keypoints, centers, center_points):
+        """All non-centre peaks of the frame at once -> (type index, index within its type, predicted centre (fp64), voted object or -1),
+        in the reference's visiting order (type by type, peak by peak)."""
+        types = [np.full(len(pts), i, dtype=np.int64) for i, pts in enumerate(keypoints[1:])]
+        flat = [p for pts in keypoints[1:] for p in pts]
+        if not flat:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 2)), np.zeros(0, np.int64)
+        type_of = np.concatenate(types)
+        within = np.concatenate([np.arange(len(pts)) for pts in keypoints[1:]])
+        pts = np.stack(flat)
+        cell = np.clip(np.round(pts).astype(np.int32), self.min, self.max)      # (x, y), half to even like ndarray.round
+        predicted = (self.image_indices[:, cell[:, 1], cell[:, 0]] + centers[type_of, :, cell[:, 1], cell[:, 0]].T).T          # (n, 2) fp64
+        delta = center_points[None, :, :] - predicted[:, None, :]
+        dist = np.sqrt(delta[..., 0] * delta[..., 0] + delta[..., 1] * delta[..., 1])                                            # (n, n_centres)
+        nearest = dist.argmin(axis=1)
+        voted = np.where(dist[np.arange(len(pts)), nearest] > self.VOTE_RADIUS, -1, nearest)
+        return type_of, within, predicted, voted
+
+    def _reduce(self, points, confidences, wanted):
+        if points.shape[0] <= wanted:
+            return points
+        if wanted == 1:
+            return points[np.argmax(confidences)][None]
+        from sklearn import cluster
+        # the reference passes no n_init (pipeline.py:146) under its pinned scikit-learn 0.24.1, whose default is 10 restarts; newer
+        # releases changed the default ('auto' -> 1 for init='random' from 1.4), so it is spelled out
+        return cluster.KMeans(init='random', n_clusters=wanted, n_init=10).fit(points).cluster_centers_
 
     def __call__(self, keypoints, confidence, centers):
         if len(keypoints[0]) == 0:
             return []
-        p_centers = self.image_indices + centers
         center_points = np.stack(keypoints[0])
         n_types = len(keypoints) - 1
-        objects = [{'center': c, 'heatmap_points': [[] for _ in range(n_types)], 'p_centers': [],
-                    'confidence': [[] for _ in range(n_types)]} for c in center_points]
-        for i, points in enumerate(keypoints[1:]):
-            for j, point in enumerate(points):
-                xy = np.clip(point.round().astype(np.int32), self.min, self.max)
-                predicted_center = p_centers[i, :, xy[1], xy[0]]
-                distances = np.linalg.norm(center_points - predicted_center[None], 2, axis=1)
-                if distances.min() > 20.0:
-                    continue
-                obj = objects[distances.argmin(axis=0)]
-                obj['p_centers'].append(predicted_center)
-                obj['heatmap_points'][i].append(point)
-                obj['confidence'][i].append(confidence[i + 1][j])
-        for obj in objects:
+        type_of, within, predicted, voted = self._votes(keypoints, np.asarray(centers), center_points)
+        objects = []
+        for o, c in enumerate(center_points):
+            mine = voted == o
+            obj = {'center': c, 'heatmap_points': [], 'p_centers': [p for p in predicted[mine]], 'confidence': []}
             for i in range(n_types):
-                if len(obj['heatmap_points'][i]) == 0:
-                    obj['heatmap_points'][i] = np.array([])
-                    continue
-                points = np.stack(obj['heatmap_points'][i])
-                confidences = np.stack(obj['confidence'][i])
-                if points.shape[0] > self.keypoint_config[i]:
-                    if self.keypoint_config[i] == 1:
-                        points = points[confidences.argmax(axis=0)][None]
-                    else:
-                        from sklearn import cluster
-                        # the reference passes no n_init (pipeline.py:146) under its pinned scikit-learn 0.24.1, whose default is
-                        # 10 restarts; newer releases changed the default ('auto' -> 1 for init='random' from 1.4), so it is spelled out
-                        clusterer = cluster.KMeans(init='random', n_clusters=self.keypoint_config[i], n_init=10)
-                        points = clusterer.fit(points).cluster_centers_
-                obj['heatmap_points'][i] = points
+                picked = within[mine & (type_of == i)]
+                conf = [confidence[i + 1][j] for j in picked]
+                obj['confidence'].append(conf)
+                if len(picked) == 0:
+                    obj['heatmap_points'].append(np.array([]))
+                else:
+                    obj['heatmap_points'].append(self._reduce(np.stack([keypoints[i + 1][j] for j in picked]), np.stack(conf), self.keypoint_config[i]))
+            objects.append(obj)
         return objects
 
 

@@ -23,32 +23,53 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _upper_triangular_inverse(K):
+    """Inverse of a camera matrix [[fx, s, cx], [0, fy, cy], [0, 0, 1]] in closed form; anything else goes to LAPACK."""
+    K = np.asarray(K, dtype=np.float64)
+    if K.shape != (3, 3) or K[1, 0] != 0.0 or K[2, 0] != 0.0 or K[2, 1] != 0.0 or K[2, 2] != 1.0:
+        return np.linalg.inv(K)
+    fx, s, cx, fy, cy = K[0, 0], K[0, 1], K[0, 2], K[1, 1], K[1, 2]
+    return np.array([[1.0 / fx, -s / (fx * fy), (s * cy - cx * fy) / (fx * fy)],
+                     [0.0, 1.0 / fy, -cy / fy],
+                     [0.0, 0.0, 1.0]])
+
+
 class PinholeCamera:
+    """Interface of the reference's PinholeCamera (camera_utils.py:7-43): attributes K, Kinv, D, image_size = (height, width)."""
+
+    PRINCIPAL_POINT_TOLERANCE = 0.05      # the principal point sits within 5 % of the image width from the centre column
+
     def __init__(self, K, D, image_size):
-        self.K = K
-        self.Kinv = np.linalg.inv(K)
-        self.D = D
-        self.image_size = np.array(image_size)     # height, width
-        assert np.abs(K[0, 2] * 2.0 - image_size[1]) < 0.05 * image_size[1]
+        self.K, self.D = K, D
+        self.Kinv = _upper_triangular_inverse(K)
+        self.image_size = np.asarray(image_size).copy()     # (height, width)
+        width = image_size[1]
+        off_centre = abs(2.0 * K[0, 2] - width)
+        assert off_centre < self.PRINCIPAL_POINT_TOLERANCE * width
 
     def scale(self, scale):
-        K = scale_camera_matrix(self.K, np.ones(2) * scale)
-        return FisheyeCamera(K, self.D, self.image_size * scale)
+        """The camera of the same view resampled by `scale` (a FisheyeCamera whatever the receiver is, as in the reference)."""
+        return FisheyeCamera(scale_camera_matrix(self.K, (scale, scale)), self.D, self.image_size * scale)
 
     def cut(self, offset):
-        K = self.K.copy()
-        K[0, 2] = self.K[0, 2] - offset[0]
-        K[1, 2] = self.K[1, 2] - offset[1]
-        return FisheyeCamera(K, self.D, self.image_size - 2.0 * offset[::-1])
+        """The camera of the view cropped by offset = (x, y) pixels on every side."""
+        shift = np.zeros_like(self.K)
+        shift[:2, 2] = offset[:2]
+        return FisheyeCamera(self.K - shift, self.D, self.image_size - 2.0 * np.asarray(offset)[::-1])
 
     def unproject(self, xys, zs):
-        xs = np.concatenate([xys, np.ones((xys.shape[0], 1))], axis=1)
-        return (self.Kinv @ xs[:, :, None])[:, :, 0] * zs[:, None]
+        """(n, 2) pixels and (n,) depths -> (n, 3): z * K^-1 [x, y, 1]^T."""
+        n = xys.shape[0]
+        homogeneous = np.empty((n, 3), dtype=np.result_type(xys, np.float64))
+        homogeneous[:, :2] = xys
+        homogeneous[:, 2] = 1.0
+        rays = np.einsum("ij,nj->ni", self.Kinv, homogeneous)
+        return rays * np.asarray(zs)[:, None]
 
     def in_frame(self, x):
-        under = (x <= 0.0).any(axis=1)
-        over = (x >= self.image_size).any(axis=1)
-        return np.bitwise_or(under, over) == False  # noqa: E712
+        """Row mask: no coordinate at or below 0, none at or beyond image_size."""
+        outside = np.logical_or(x <= 0.0, x >= self.image_size)
+        return np.logical_not(outside.any(axis=1))
 
     MODEL = 0          # okp_camera.model: 0 = equidistant (FisheyeCamera), 1 = radtan (RadTanPinholeCamera)
 
@@ -98,12 +119,12 @@ class FisheyeCamera(PinholeCamera):
 
 
 class StereoCamera:
+    """A calibrated pair: T_RL maps left-camera coordinates to the right camera's (reference camera_utils.py:83-117)."""
+
     def __init__(self, left_camera, right_camera, T_RL):
-        self.left_camera = left_camera
-        self.right_camera = right_camera
-        self.T_RL = T_RL
-        self.T_LR = linalg.inv_transform(T_RL)
-        self.F = fundamental_matrix(T_RL, self.left_camera.K, self.right_camera.K)
+        self.left_camera, self.right_camera = left_camera, right_camera
+        self.T_RL, self.T_LR = T_RL, linalg.inv_transform(T_RL)
+        self.F = fundamental_matrix(T_RL, left_camera.K, right_camera.K)
 
     def triangulate(self, left_keypoints, right_keypoints, correct_matches=True, per_camera_model=False):
         """Like the reference (camera_utils.py:92-110) the key points are undistorted with the FISHEYE (equidistant) model and the
@@ -122,56 +143,64 @@ class StereoCamera:
 
     @classmethod
     def from_file(cls, calibration_file):
-        camera = load_calibration_params(calibration_file)
-        left_camera = FisheyeCamera(camera['K'], camera['D'], camera['image_size'])
-        right_camera = FisheyeCamera(camera['Kp'], camera['Dp'], camera['image_size'])
-        return cls(left_camera, right_camera, camera['T_RL'])
+        """A Kalibr stereo calibration (cam0 = left, cam1 = right) as two FisheyeCameras."""
+        p = load_calibration_params(calibration_file)
+        cameras = [FisheyeCamera(p[k], p[d], p['image_size']) for k, d in (('K', 'D'), ('Kp', 'Dp'))]
+        return cls(cameras[0], cameras[1], p['T_RL'])
 
 
 def camera_matrix(intrinsics):
-    fx, fy, cx, cy = intrinsics
-    return np.array([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]])
+    """(fx, fy, cx, cy) -> 3 x 3."""
+    K = np.eye(3)
+    K[[0, 1], [0, 1]] = intrinsics[:2]
+    K[:2, 2] = intrinsics[2:4]
+    return K
 
 
 def projection_matrix(camera_matrix, T_CW):
-    return camera_matrix @ T_CW[:3, :]
+    return np.matmul(camera_matrix, np.asarray(T_CW)[:3])
+
+
+def _read_yaml(path):
+    with open(path, 'rt') as f:
+        return yaml.load(f.read(), Loader=yaml.SafeLoader)
+
+
+def _intrinsics_of(entry):
+    """(K, D, (height, width)) of one Kalibr camera entry (resolution is stored width first)."""
+    width, height = entry['resolution']
+    return camera_matrix(entry['intrinsics']), np.array(entry['distortion_coeffs']), [height, width]
+
+
+_CAMERA_CLASSES = {('pinhole', 'equidistant'): FisheyeCamera, ('pinhole', 'radtan'): RadTanPinholeCamera}
 
 
 def from_calibration(calibration_file):
-    with open(calibration_file, 'rt') as f:
-        camera = yaml.load(f.read(), Loader=yaml.SafeLoader)['cam0']
-    K = camera_matrix(camera['intrinsics'])
-    D = np.array(camera['distortion_coeffs'])
-    if camera['distortion_model'] == 'equidistant' and camera['camera_model'] == 'pinhole':
-        return FisheyeCamera(K, D, camera['resolution'][::-1])
-    if camera['distortion_model'] == 'radtan' and camera['camera_model'] == 'pinhole':
-        return RadTanPinholeCamera(K, D, camera['resolution'][::-1])
-    raise ValueError(f"Unrecognized calibration type {camera['distortion_model']}.")
+    entry = _read_yaml(calibration_file)['cam0']
+    camera_class = _CAMERA_CLASSES.get((entry['camera_model'], entry['distortion_model']))
+    if camera_class is None:
+        raise ValueError(f"Unrecognized calibration type {entry['distortion_model']}.")
+    return camera_class(*_intrinsics_of(entry))
 
 
 def load_calibration_params(calibration_file):
-    with open(calibration_file, 'rt') as f:
-        calibration = yaml.load(f.read(), Loader=yaml.SafeLoader)
-    left, right = calibration['cam0'], calibration['cam1']
-    T_RL = np.array(right['T_cn_cnm1'])
-    return {
-        'K': camera_matrix(left['intrinsics']), 'Kp': camera_matrix(right['intrinsics']),
-        'D': np.array(left['distortion_coeffs']), 'Dp': np.array(right['distortion_coeffs']),
-        'T_LR': linalg.inv_transform(T_RL), 'T_RL': T_RL, 'image_size': right['resolution'][::-1],
-    }
+    calibration = _read_yaml(calibration_file)
+    (K, D, _), (Kp, Dp, size) = _intrinsics_of(calibration['cam0']), _intrinsics_of(calibration['cam1'])
+    T_RL = np.array(calibration['cam1']['T_cn_cnm1'])
+    return dict(K=K, Kp=Kp, D=D, Dp=Dp, T_RL=T_RL, T_LR=linalg.inv_transform(T_RL), image_size=size)
 
 
 def scale_camera_matrix(K, scaling_factor):
-    out = K.copy()
-    out[0, 0] = K[0, 0] * scaling_factor[0]
-    out[1, 1] = K[1, 1] * scaling_factor[1]
-    out[0, 2] = K[0, 2] * scaling_factor[0]
-    out[1, 2] = K[1, 2] * scaling_factor[1]
-    return out
+    """Focal lengths and principal point scaled by (sx, sy); a skew entry is left as it is, as the reference does."""
+    sx, sy = scaling_factor[0], scaling_factor[1]
+    scaled = np.array(K, copy=True)
+    scaled[0, [0, 2]] = K[0, [0, 2]] * sx
+    scaled[1, [1, 2]] = K[1, [1, 2]] * sy
+    return scaled
 
 
 def fundamental_matrix(T_RL, K, Kp):
-    R = T_RL[:3, :3]
-    t = T_RL[:3, 3]
-    C = linalg.skew_matrix(K @ R.T @ t)
-    return np.linalg.inv(Kp).T @ R @ K.T @ C
+    """F with x_R^T F x_L = 0 for pixels of the same point: Kp^-T R K^T [K R^T t]_x (the reference's form, camera_utils.py:184-189)."""
+    R, t = T_RL[:3, :3], T_RL[:3, 3]
+    epipole = K @ (R.T @ t)
+    return np.linalg.inv(Kp).T @ (R @ K.T) @ linalg.skew_matrix(epipole)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     from object_keypoints_amd import _lib
     bound = {n for n, _, _ in _lib.SIGNATURES}
     assert declared == bound, f"ctypes binding and header disagree: {declared ^ bound}"
-    assert _lib.lib().okp_abi_version() == 6 == _lib.OKP_ABI
+    assert _lib.lib().okp_abi_version() == 7 == _lib.OKP_ABI
 
 
 def test_struct_layouts_match_the_header():
@@ -290,13 +290,37 @@ def test_torch_ops_are_registered_over_the_c_abi():
     T = _lib.torch_ops()
     assert T is not None, "libokp_torch.so is built by object_keypoints_amd.build alongside libokp_hip.so"
     names = ["conv_forward", "conv_select_tile", "fire_forward", "fire_chain_forward", "heads_forward", "head_out_forward",
-             "stem_forward_nchw", "peak_nms", "lift_peaks", "group_objects"]
+             "stem_forward_nchw", "peak_nms", "lift_peaks", "group_objects",
+             # round 6: the rest of include/okp.h - a torch-only caller builds and runs the whole path
+             "stem_forward_nchw_pairs", "stem_forward", "pack_frames", "pack_frames_u8", "preprocess_u8", "cast", "add_f16_f32", "dwconv3x3_forward",
+             "nms_maxpool", "capacity_overflow", "camera_undistort", "unproject_depth", "triangulate_dlt"]
     for n in names:
         op = getattr(T, n)
         schema = str(op.default._schema)
         assert schema.startswith(f"okp::{n}(")
         if n != "conv_select_tile":
             assert "(a!)" in schema, schema
+    for n in ("conv_create", "conv_bn_create", "fold_bn", "conv_destroy", "conv_macs", "conv_picks_patch", "stem_create", "stem_destroy", "stream_wait_stream"):
+        assert str(getattr(T, n).default._schema).startswith(f"okp::{n}(")
+    # the ABI-5/6 arguments of okp_conv_args are arguments of the op
+    schema = str(T.conv_forward.default._schema)
+    for arg in ("out16", "write_out", "out_subsample", "src_pairs", "out_pairs"):
+        assert arg in schema
+    # every launch / creation entry point the header declares has an op (by the C name without its okp_ prefix, or a listed alias)
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "okp.h")).read()
+    declared = set(re.findall(r"\b(okp_[a-z0-9_]+)\s*\(", header))
+    alias = {"okp_conv_create_x3": "conv_create", "okp_stem_create_dtype": "stem_create", "okp_stem_create": "stem_create", "okp_fisheye_undistort": "camera_undistort",
+             "okp_conv_patch_applies": "conv_picks_patch"}
+    not_ops = {"okp_last_error", "okp_abi_version", "okp_device_count", "okp_device_arch"}      # (errors surface as exceptions; devices are torch's business)
+    for c_name in sorted(declared - not_ops):
+        op_name = alias.get(c_name, c_name[len("okp_"):])
+        assert hasattr(T, op_name), f"{c_name} has no torch.ops.okp counterpart"
+    # plan creation needs no GPU call before the upload: the argument checks run first, on the host
+    with pytest.raises(RuntimeError, match="weight is"):
+        T.conv_create(0, [64], [1], 128, [0], [0], [0], [torch.zeros(128, 32)], None, 0, [])
+    fw, fb = T.fold_bn(torch.ones(4, 2, 1, 1), torch.full((4,), 2.0), torch.zeros(4), torch.ones(4), torch.full((4,), 4.0 - 1e-5), 1e-5, None)
+    assert torch.equal(fw, torch.ones(4, 2, 1, 1)) and torch.equal(fb, torch.full((4,), -1.0))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         T.peak_nms(torch.zeros(1, 1, 8, 8), 4, torch.zeros(1, dtype=torch.int32), torch.zeros(8, dtype=torch.int32), torch.zeros(12), 0)
     with pytest.raises(ops.OkpError):
@@ -520,3 +544,73 @@ def test_bench_parity_fields_report_point_error_quantiles(tmp_path):
     assert len(idx) >= 2
     assert abs(got["p_C_err_m"] - 1.5) < 1e-9 and st["max"] == got["p_C_err_m"] and st["n"] == len(idx)
     assert st["n_over_1e-4"] == 1 and (st["median"] < 1e-9 or len(idx) == 2) and got["meets"]["p_C_1e-4_m"] is False and got["meets"]["peaks_identical"]
+
+
+@pytest.mark.parametrize("config,n_objects", [([1, 1, 1], 4), ([1, 3], 2), ([1, 3], 1)])
+def test_vectorised_voting_equals_the_oracle_on_multi_object_scenes(config, n_objects):
+    """The product's ObjectExtraction votes for all peaks of a frame at once; the oracle walks them one by one as the reference does
+    (pipeline.py:104-133).  Same objects, same order of the received votes, identical numbers (no k-means branch in these scenes)."""
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception.pipeline import ObjectExtraction
+    from oracle import pipeline as op
+    cfg = {"keypoint_config": config}
+    for index in range(12):
+        s = synth.bump_scene(config, n_objects=n_objects, seed=91, index=index)
+        points, conf = op.KeypointExtractionComponent(cfg, [64, 64])(s["heat"][None])
+        got = ObjectExtraction(cfg, [64, 64])(points[0], conf[0], s["centers"])
+        want = op.ObjectExtraction(cfg, [64, 64])(points[0], conf[0], s["centers"])
+        assert len(got) == len(want) >= 1
+        for g, w_ in zip(got, want):
+            assert set(g) == set(w_) == {"center", "heatmap_points", "p_centers", "confidence"}
+            assert np.array_equal(g["center"], w_["center"])
+            assert len(g["p_centers"]) == len(w_["p_centers"])
+            for a, b in zip(g["p_centers"], w_["p_centers"]):
+                assert np.array_equal(a, b) and a.dtype == b.dtype
+            for a, b in zip(g["heatmap_points"], w_["heatmap_points"]):
+                multi = np.asarray(b).ndim == 2 and np.asarray(b).dtype == np.float64      # a k-means result is unordered and unseeded
+                if not multi:
+                    assert np.array_equal(np.asarray(a), np.asarray(b)) and np.asarray(a).dtype == np.asarray(b).dtype
+            for a, b in zip(g["confidence"], w_["confidence"]):
+                assert [float(v) for v in a] == [float(v) for v in b]
+    # no centre peak: no objects; centre peaks but no votes: empty groups
+    ex = ObjectExtraction(cfg, [64, 64])
+    assert ex([[]] + [[] for _ in config], [[]] + [[] for _ in config], np.zeros((len(config), 2, 64, 64), np.float32)) == []
+    lone = ex([[np.array([5.0, 6.0], np.float32)]] + [[] for _ in config], [[np.float32(3)]] + [[] for _ in config], np.zeros((len(config), 2, 64, 64), np.float32))
+    assert len(lone) == 1 and lone[0]["p_centers"] == [] and all(np.asarray(p).size == 0 for p in lone[0]["heatmap_points"])
+
+
+def test_camera_helpers_agree_with_the_oracle_restatement():
+    """camera_utils' host helpers (own formulation: closed-form K^-1, index-assigned matrices) against oracle/geometry.py, which follows the
+    reference line by line (camera_utils.py:7-43,119-189; linalg.py:4-20)."""
+    from object_keypoints_amd.perception.utils import camera_utils as cu, linalg
+    from oracle import geometry as og
+    rng = np.random.default_rng(4)
+    K = cu.camera_matrix([421.5, 418.25, 322.0, 238.5])
+    assert np.array_equal(K, og.camera_matrix([421.5, 418.25, 322.0, 238.5]))
+    D = np.array([-0.02, 0.01, -0.003, 0.0004])
+    mine, theirs = cu.FisheyeCamera(K, D, [480, 640]), og.FisheyeCamera(K, D, [480, 640])
+    np.testing.assert_allclose(mine.Kinv, theirs.Kinv, rtol=0, atol=1e-15)
+    skewed = K.copy(); skewed[0, 1] = 0.7
+    np.testing.assert_allclose(cu._upper_triangular_inverse(skewed), np.linalg.inv(skewed), rtol=0, atol=1e-15)
+    xy, z = rng.uniform(0, 600, (9, 2)), rng.uniform(0.3, 2.0, 9)
+    np.testing.assert_allclose(mine.unproject(xy, z), theirs.unproject(xy, z), rtol=0, atol=1e-13)
+    probe = np.array([[1.0, 1.0], [0.0, 5.0], [500.0, 100.0], [100.0, 500.0], [479.0, 639.0], [480.0, 10.0], [np.nan, 3.0]])
+    assert mine.in_frame(probe).tolist() == theirs.in_frame(probe).tolist()
+    for a, b in ((mine.scale(0.125), theirs.scale(0.125)), (mine.cut(np.array([12.0, 7.0])), theirs.cut(np.array([12.0, 7.0])))):
+        assert type(a) is cu.FisheyeCamera and np.array_equal(a.K, b.K) and np.array_equal(a.image_size, b.image_size)
+    assert np.array_equal(cu.scale_camera_matrix(skewed, (0.5, 0.25)), og.scale_camera_matrix(skewed, (0.5, 0.25)))
+    T = np.eye(4); T[:3, :3] = np.linalg.qr(rng.standard_normal((3, 3)))[0]; T[:3, 3] = [-0.11, 0.004, 0.002]
+    np.testing.assert_allclose(cu.fundamental_matrix(T, K, skewed), og.fundamental_matrix(T, K, skewed), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(cu.projection_matrix(K, T), og.projection_matrix(K, T), rtol=0, atol=1e-13)
+    v = rng.standard_normal(3)
+    assert np.array_equal(linalg.skew_matrix(v), og.skew_matrix(v))
+    np.testing.assert_allclose(linalg.inv_transform(T), og.inv_transform(T), rtol=0, atol=1e-15)
+    pts = rng.standard_normal((5, 3))
+    np.testing.assert_allclose(linalg.transform_points(T, pts), og.transform_points(T, pts), rtol=0, atol=1e-15)
+    calib = os.path.join(REPO, "config", "calibration.yaml")
+    p, q = cu.load_calibration_params(calib), og.load_calibration_params(calib)
+    assert set(p) == set(q)
+    for k in p:
+        np.testing.assert_allclose(np.asarray(p[k], dtype=np.float64), np.asarray(q[k], dtype=np.float64), rtol=0, atol=1e-15)
+    stereo = cu.StereoCamera.from_file(calib)
+    np.testing.assert_allclose(stereo.F, og.StereoCamera.from_file(calib).F, rtol=1e-12, atol=1e-18)
