@@ -156,3 +156,51 @@ def test_single_process_is_passthrough():
     x = torch.zeros(2, 3, 4, 4)
     assert d.all_gather_keypoints(x) is x
     assert d.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def _worker_world8(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from object_keypoints_amd import distributed as d
+    r, _, w = d.init(backend="gloo")
+    K, cap = 4, 16                                  # config/cups.json: K = 4 maps
+    start, count = d.shard(total, r, w)
+    pts = torch.full((count, K, cap, 4), float("nan"), dtype=torch.float64)
+    for i in range(count):
+        for k in range(K):
+            pts[i, k, :1 + (start + i + k) % 3, :] = float(1000 * (start + i) + k)
+    gathered = d.all_gather_keypoints(pts, total_frames=total)
+    slowest = d.max_over_ranks(float(10 + rank), torch.device("cpu"))
+    d.barrier()
+    q.put((rank, start, count, tuple(gathered.shape), gathered[:, :, 0, 0].numpy(), slowest))
+
+
+@pytest.mark.parametrize("total", [64, 61])        # 8 ranks x 8 frames, and an uneven total (blocks of 8, 8, 8, 8, 8, 7, 7, 7)
+def test_allgather_world8_gloo_cups_payload(total):
+    """The rehearsal of the driver's 8-GPU run (BASELINE configs[3]): world size 8, the cups payload [frames, 4, cap, 4] fp64,
+    every rank ends with all frames in global order; blocks that differ by a frame are padded for the collective and trimmed after it."""
+    from object_keypoints_amd import distributed as d
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_world8, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    covered = []
+    want = np.array([[1000.0 * f + k for k in range(4)] for f in range(total)])
+    for rank, start, count, shape, first, slowest in results:
+        covered += list(range(start, start + count))
+        assert (start, count) == d.shard(total, rank, world) and shape == (total, 4, 16, 4)
+        assert np.array_equal(first, want) and slowest == 17.0
+    assert covered == list(range(total))
+    sizes = [d.shard(61, r, 8)[1] for r in range(8)]
+    assert sizes == [8, 8, 8, 8, 8, 7, 7, 7] and max(sizes) - min(sizes) == 1

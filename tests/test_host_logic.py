@@ -250,6 +250,18 @@ def test_bench_launcher_starts_ranks_and_relays_one_json_line():
     seen.clear()
     assert bench.self_launch(args, argv, device_count=1, popen=FakeProc, out=io.StringIO(), err=err) == 2
     assert "needs 8 devices, 1 visible" in err.getvalue() and not seen
+    # the driver's configs[3] run: `python bench.py --gpus 8 --workload cups512` -> eight ranks, the workload flag handed on unchanged
+    argv3 = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--workload", "cups512"]
+    args3 = bench.parse(argv3)
+    assert args3.workload == "cups512" and bench.needs_launcher(args3, {})
+    cmd3 = bench.launcher_command(args3, argv3, 29512)
+    assert "--nproc-per-node=8" in cmd3 and cmd3[-8:] == argv3 and cmd3[cmd3.index("--master-addr") + 1] == "127.0.0.1"
+    assert "configs[3]" in bench.workload_string(args3.batch, args3.dtype, 8, "cups512") and "batch=64/GPU" in bench.workload_string(args3.batch, args3.dtype, 8, "cups512")
+    seen.clear(); seen["rc"] = 0
+    assert bench.self_launch(args3, argv3, device_count=8, popen=FakeProc, out=io.StringIO(), err=io.StringIO()) == 0 and seen["cmd"][-2:] == ["--workload", "cups512"]
+    seen.clear()
+    err = io.StringIO()
+    assert bench.self_launch(args3, argv3, device_count=7, popen=FakeProc, out=io.StringIO(), err=err) == 2 and "needs 8 devices, 7 visible" in err.getvalue() and not seen
 
 
 def test_launcher_counts_gpus_without_the_hip_runtime(tmp_path):
