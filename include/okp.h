@@ -30,7 +30,8 @@ extern "C" {
 #define OKP_ABI_VERSION 7     /* 2: okp_camera.model, OKP_F16, okp_stem_create_dtype, okp_radtan...  3: OKP_F32X3  4: okp_stream_wait_stream
                                  5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14
                                  6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs
-                                 7: okp_conv_patch_applies */
+                                 7: okp_conv_patch_applies; okp_group_objects: `reduced_dev` (device k-means reduction of surplus votes);
+                                    okp_conv_set_range_flag / okp_stem_set_range_flag (fp16-range guard of split-product plans), okp_capacity_overflow: `range_flag_dev` */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -90,6 +91,15 @@ okp_conv* okp_conv_create(int dtype, int n_src, const int32_t* cin, const int32_
  * weights.  tap_terms == NULL: all taps three terms (= okp_conv_create(OKP_F32X3, ...)). */
 okp_conv* okp_conv_create_x3(int n_src, const int32_t* cin, const int32_t* conv_stride, int32_t cout, int32_t n_taps,
                              const okp_tap* taps, const uint8_t* tap_terms, const float* bias, int act);
+/* OKP_F32X3 range guard (ABI 7).  A split-product plan halves its fp32 operands into fp16: a value beyond +-65504 (or a non-finite one)
+ * becomes (inf, -inf), its products NaN, and the next ReLU turns the NaN into 0 - silently, where the reference's fp32 arithmetic
+ * (py_utils/utils.py:143-156) returns numbers.  With a flag attached, every launch of the plan (okp_conv_forward on any tile, and
+ * okp_fire_forward / okp_heads_forward through their squeeze / first-layer plan) ORs 1 into *flag_dev when one of its RESULTS - a value
+ * the next split-product layer will halve, including the squeeze tile of the one-launch fire module and the hidden layer of the heads -
+ * is outside the fp16 range or not finite; okp_stem_set_range_flag does the same for the stem and also checks the frames it reads.  The
+ * flag is never cleared by the library: the caller zeroes it before a pass and reads it after (or hands it to okp_capacity_overflow).
+ * flag_dev: DEVICE int32, NULL = off (the default).  Set once, before the plan is used from several threads or captured in a graph. */
+int okp_conv_set_range_flag(okp_conv* plan, int32_t* flag_dev);
 void okp_conv_destroy(okp_conv* plan);
 
 typedef struct okp_tensor {        /* an NHWC view */
@@ -254,6 +264,7 @@ typedef struct okp_stem okp_stem;
 okp_stem* okp_stem_create(const float* w_host, const float* bias_host);                       /* bf16 */
 okp_stem* okp_stem_create_dtype(int dtype, const float* w_host, const float* bias_host);    /* OKP_BF16, OKP_F16, or OKP_F32X3: the split-product
                                                                                                form (fp32 NHWC output; okp_stem_forward_nchw only) */
+int okp_stem_set_range_flag(okp_stem* stem, int32_t* flag_dev);   /* OKP_F32X3 stems: see okp_conv_set_range_flag */
 void okp_stem_destroy(okp_stem* stem);
 int okp_stem_forward(const okp_stem* stem, int32_t n, int32_t h, int32_t w, const okp_tensor* packed, const okp_tensor* out, void* stream);
 /* Same layer straight from the reference's input layout, fp32 NCHW frames (n,3,h,w): the bf16 rounding and the zero
@@ -354,24 +365,31 @@ int okp_lift_peaks(const okp_camera* cam, const int32_t* count_dev, const float*
  * the peaks of map 0 are object centres; every peak of map k >= 1 votes for the centre nearest to
  * (pixel centre + centre-offset map value at its rounded position), votes farther than `max_dist` (20 px in the
  * reference) are dropped; per object and keypoint type at most `type_count[k-1]` peaks are kept: for a type with
- * count 1 the most confident one, otherwise the first `type_count` in peak order with `overflow` set so the caller
- * can run the reference's k-means on them (its unseeded KMeans is not reproducible bit for bit anyway).
+ * count 1 the most confident one; for a multi-instance type the first `max_sel` votes in peak order go to `sel`, and where an object
+ * received MORE votes than the type has instances the reference's k-means reduction (pipeline.py:143-148: unseeded sklearn KMeans,
+ * reproducible as a set only) is done here as a deterministic Lloyd iteration - one lane per vote (the object's first 64), fp64,
+ * farthest-point initialisation seeded by each of the four most confident votes in turn, least inertia wins - into `reduced`.
  *   count [n][K] int32, xyc [n][K][cap][3] fp32 (okp_peak_nms outputs), centers [n][K-1][2][h][w] fp32
  *   n_obj   [n] int32                         objects per frame (= min(count[n][0], max_obj)); max_obj <= 64
  *   sel     [n][max_obj][K-1][max_sel] int32  selected peak indices into map k, -1 = empty slot
  *   n_votes [n][max_obj][K-1] int32           votes the object received for that type (before the cut)
  *   assign  [n][K][cap] int32                 object index each peak voted for (-1: none / dropped / map 0)
  *   pred    [n][K][cap][2] fp64               the predicted centre (x, y) each peak voted with
- * One lane per frame; K <= 8, max_sel <= 8.
+ *   reduced [n][max_obj][K-1][max_sel][2] fp32 (ABI 7; may be NULL = no reduction): for a type with type_count > 1 (<= max_sel) and
+ *           n_votes > type_count the type_count cluster centres (x, y), NaN everywhere else
+ * One wave per frame; K <= 8, max_sel <= 8.
  * ---------------------------------------------------------------------------------- */
 int okp_group_objects(const int32_t* count_dev, const float* xyc_dev, const float* centers_dev, int32_t n, int32_t K,
                       int32_t cap, int32_t h, int32_t w, const int32_t* type_count /* HOST [K-1] */, float max_dist,
                       int32_t max_obj, int32_t max_sel, int32_t* n_obj_dev, int32_t* sel_dev, int32_t* n_votes_dev,
-                      int32_t* assign_dev, double* pred_dev, void* stream);
+                      int32_t* assign_dev, double* pred_dev, float* reduced_dev, void* stream);
 
-/* The fixed-capacity tensors can truncate where the reference (which keeps every peak, pipeline.py:73) cannot: flag[0] = 1 iff some
- * map has more than `cap` peaks or some centre map (map 0 of each frame of K maps) more than `max_obj`; else 0.  Device-side, no sync. */
-int okp_capacity_overflow(const int32_t* count_dev, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, int32_t* flag_dev, void* stream);
+/* The fixed-capacity tensors can truncate where the reference (which keeps every peak, pipeline.py:73) cannot: bit 0 of flag[0] is set iff
+ * some map has more than `cap` peaks or some centre map (map 0 of each frame of K maps) more than `max_obj`.  range_flag_dev (ABI 7, may be
+ * NULL): the fp16-range flag of the split-product network that made the maps (okp_conv_set_range_flag); bit 1 of flag[0] is set iff it is
+ * non-zero - one device-side word says whether a batch's results can be trusted.  No sync. */
+int okp_capacity_overflow(const int32_t* count_dev, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, const int32_t* range_flag_dev,
+                          int32_t* flag_dev, void* stream);
 
 /* Replaces StereoCamera.triangulate (utils/camera_utils.py:92-110) and the labelling tool's
  * 2-view DLT (scripts/label.py:285-305): undistort both views (P=K) -> optional Hartley-Sturm

@@ -62,6 +62,8 @@ SIGNATURES = [
     ("okp_device_arch", c_int, [c_int, c_char_p, c_int]),
     ("okp_conv_create", c_void_p, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(c_float), c_int]),
     ("okp_conv_create_x3", c_void_p, [c_int, POINTER(c_int32), POINTER(c_int32), c_int32, c_int32, POINTER(okp_tap), POINTER(ctypes.c_uint8), POINTER(c_float), c_int]),
+    ("okp_conv_set_range_flag", c_int, [c_void_p, c_void_p]),
+    ("okp_stem_set_range_flag", c_int, [c_void_p, c_void_p]),
     ("okp_conv_destroy", None, [c_void_p]),
     ("okp_cast", c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     ("okp_add_f16_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -90,8 +92,8 @@ SIGNATURES = [
     ("okp_nms_maxpool", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_unproject_depth", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     ("okp_lift_peaks", c_int, [POINTER(okp_camera), c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
-    ("okp_group_objects", c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    ("okp_capacity_overflow", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    ("okp_group_objects", c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("okp_capacity_overflow", c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     ("okp_triangulate_dlt", c_int, [POINTER(okp_camera), POINTER(okp_camera), POINTER(c_double), POINTER(c_double), c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_fisheye_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),
     ("okp_camera_undistort", c_int, [POINTER(okp_camera), c_void_p, c_int32, c_void_p, c_void_p]),

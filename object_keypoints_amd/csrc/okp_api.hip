@@ -375,6 +375,12 @@ static okp_conv* conv_create(int dtype, int n_src, const int32_t* cin, const int
   return plan;
 }
 
+extern "C" int okp_conv_set_range_flag(okp_conv* plan, int32_t* flag_dev) {
+  if (!plan || plan->dtype != OKP_F32X3) { okp_set_error("okp_conv_set_range_flag: a split-product (OKP_F32X3) plan"); return OKP_EINVAL; }
+  plan->range_flag = flag_dev;
+  return OKP_OK;
+}
+
 extern "C" void okp_conv_destroy(okp_conv* plan) {
   if (!plan) return;
   if (plan->weights_dev) (void)hipFree(plan->weights_dev);
@@ -490,6 +496,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   p.out16 = a->out16.data; p.out16_pix_stride = a->out16.pix_stride; p.res16 = a->res_is_f16 ? 1 : 0;
   if (sub2) { p.out_sub2 = 1; p.OH2 = a->out.h; p.OW2 = a->out.w; p.OH = a->out16.h; p.OW = a->out16.w; }
   p.src_pairs = a->src_pairs; p.out_pairs = a->out_pairs ? 1 : 0;
+  p.range_flag = plan->range_flag;
   if (a->dw_w_dev) {
     if (!a->dw_bias_dev) { okp_set_error("okp_conv_forward: dw_w_dev without dw_bias_dev"); return OKP_EINVAL; }
     if (plan->cin[0] != plan->cout || a->out_step != 1) { okp_set_error("okp_conv_forward: the fused depth-wise branch needs cin[0] == cout and out_step 1"); return OKP_EINVAL; }

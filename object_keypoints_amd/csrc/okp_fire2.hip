@@ -658,7 +658,7 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.N = a->n; q.skip = a->skip;
     q.w1 = squeeze->fragT_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev; q.s1 = squeeze->oscale_dev;
     q.wa = expand->fragT_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev; q.sa = expand->oscale_dev;
-    q.wd = dw_w_dev; q.bd = dw_bias_dev;
+    q.wd = dw_w_dev; q.bd = dw_bias_dev; q.range_flag = squeeze->range_flag;
     return okp_launch_fire_x3(q, (hipStream_t)stream);
   }
   if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, q = lane >> 4;
+  bool range_bad = false;                                     // a squeeze value or a result outside the fp16 range (okp_unsplittable)
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
         const int row = 16 * pb + l16t;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ok ? __builtin_fmaf(acc[pb][e], s1v[e], b1v[e]) : 0.f;
+        for (int e = 0; e < 4; ++e) { v[e] = ok ? __builtin_fmaf(acc[pb][e], s1v[e], b1v[e]) : 0.f; range_bad |= okp_unsplittable(v[e]); }
         *reinterpret_cast<f32x4*>(smem + OFF_S32 + row * 512 + ((((uint32_t)(4 * w + qt)) ^ (uint32_t)(row & 15)) << 4)) = v;
         u32x2 hi, lo;
         okp_split4(v, hi, lo);
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
         const f32x4 r = __builtin_bit_cast(f32x4, r_raw);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(ac2[e], sav[e], bav[e]) + r[e], 0.f);
+        for (int e = 0; e < 4; ++e) { const float u = __builtin_fmaf(ac2[e], sav[e], bav[e]) + r[e]; range_bad |= okp_unsplittable(u); v[e] = fmaxf(u, 0.f); }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, (int)o_off, 0, 0);
       }
     }
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
           const f32x4 r = __builtin_bit_cast(f32x4, rr[iy]);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[iy][e] + r[e], 0.f);
+          for (int e = 0; e < 4; ++e) { const float u = v[iy][e] + r[e]; range_bad |= okp_unsplittable(u); o[e] = fmaxf(u, 0.f); }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, (int)oo[iy], 0, 0);
         }
       }
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
     FX3_STAMP(6);
     // no barrier here: the next tile's phase 1 starts with one (behind its vmcnt(0)), and nothing of this phase is overwritten before it
   }
+  okp_raise_range_flag(p.range_flag, range_bad);
 }
 
 }  // namespace

@@ -122,7 +122,90 @@ struct GroupParams {
   int type_count[8];
   float max_dist;
   int* n_obj; int* sel; int* n_votes; int* assign; double* pred;
+  float* reduced;          // [n][max_obj][K-1][max_sel][2] (x, y) or NULL: the k-means reduction of surplus votes (reduce_surplus below)
 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);        // butterfly: every lane ends with the same bits
+  return v;
+}
+
+// Surplus votes of a multi-instance type -> `want` cluster centres (ObjectExtraction, perception/pipeline.py:135-148: the reference runs an
+// unseeded sklearn KMeans(init='random', n_init = 10 restarts) and keeps the run of least inertia; its result is reproducible only as a
+// set).  Device form: Lloyd's algorithm, one lane per vote (the first 64 votes of the object, in peak order), distances and means in fp64,
+// farthest-point initialisation (the start that separates well-separated groups at once) seeded in turn by each of the up to KM_RESTARTS most
+// confident votes; the run of least inertia wins, earlier seeds win ties.  Deterministic: same votes, same centres, on every launch.
+constexpr int KM_RESTARTS = 4, KM_ITERS = 32, KM_MAXK = 8;
+__device__ void reduce_surplus(int np, double px, double py, float conf, int want, int lane, float* out /* [max_sel][2] */) {
+  const bool live = lane < np;
+  // rank of this vote by (confidence descending, peak order ascending)
+  int rank = 0;
+  for (int i = 0; i < np; ++i) {
+    const float ci = __shfl(conf, i);
+    rank += (ci > conf || (ci == conf && i < lane)) ? 1 : 0;
+  }
+  double best_inertia = 1e300, bx[KM_MAXK], by[KM_MAXK];
+#pragma unroll
+  for (int t = 0; t < KM_MAXK; ++t) { bx[t] = 0.0; by[t] = 0.0; }
+  const int restarts = np < KM_RESTARTS ? np : KM_RESTARTS;
+  for (int r = 0; r < restarts; ++r) {
+    double cx[KM_MAXK], cy[KM_MAXK];
+#pragma unroll
+    for (int t = 0; t < KM_MAXK; ++t) { cx[t] = 0.0; cy[t] = 0.0; }
+    const int seed = __ffsll((long long)__ballot(live && rank == r)) - 1;
+    cx[0] = __shfl(px, seed); cy[0] = __shfl(py, seed);
+    double dmin = live ? (px - cx[0]) * (px - cx[0]) + (py - cy[0]) * (py - cy[0]) : -1.0;
+#pragma unroll
+    for (int t = 1; t < KM_MAXK; ++t) {
+      if (t < want) {                                     // the vote farthest from the centres chosen so far (lowest lane wins ties)
+        double d = dmin; int l = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double d2 = __shfl_xor(d, off); const int l2 = __shfl_xor(l, off);
+          if (d2 > d || (d2 == d && l2 < l)) { d = d2; l = l2; }
+        }
+        cx[t] = __shfl(px, l); cy[t] = __shfl(py, l);
+        const double dn = (px - cx[t]) * (px - cx[t]) + (py - cy[t]) * (py - cy[t]);
+        if (live && dn < dmin) dmin = dn;
+      }
+    }
+    double inertia = 0.0;
+    for (int it = 0; it < KM_ITERS; ++it) {
+      int a = 0; double da = 1e300;
+#pragma unroll
+      for (int t = 0; t < KM_MAXK; ++t) {
+        if (t < want) {
+          const double d = (px - cx[t]) * (px - cx[t]) + (py - cy[t]) * (py - cy[t]);
+          if (d < da) { da = d; a = t; }
+        }
+      }
+      inertia = wave_sum(live ? da : 0.0);
+      bool moved = false;
+#pragma unroll
+      for (int t = 0; t < KM_MAXK; ++t) {
+        if (t < want) {
+          const bool in = live && a == t;
+          const double cnt = wave_sum(in ? 1.0 : 0.0);
+          if (cnt > 0.0) {                                // an empty cluster keeps its centre
+            const double nx = wave_sum(in ? px : 0.0) / cnt, ny = wave_sum(in ? py : 0.0) / cnt;
+            moved = moved || nx != cx[t] || ny != cy[t];
+            cx[t] = nx; cy[t] = ny;
+          }
+        }
+      }
+      if (!moved) break;                                  // (wave-uniform: every lane holds the same centres)
+    }
+    if (inertia < best_inertia) {
+      best_inertia = inertia;
+#pragma unroll
+      for (int t = 0; t < KM_MAXK; ++t) { bx[t] = cx[t]; by[t] = cy[t]; }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KM_MAXK; ++t)
+    if (t < want && lane == t) { out[2 * t] = (float)bx[t]; out[2 * t + 1] = (float)by[t]; }
+}
 
 // One wave per frame, one lane per peak.  The reference walks the peaks of a keypoint type in order and lets each
 // vote for the nearest object centre (pipeline.py:121-133); here the votes of up to 64 peaks are taken at once and
@@ -144,6 +227,9 @@ __global__ __launch_bounds__(64) void okp_group_objects_kernel(const GroupParams
   int* assign = p.assign + (size_t)f * p.K * p.cap;
   double* pred = p.pred + (size_t)f * p.K * p.cap * 2;
   for (int i = lane; i < p.K * p.cap; i += 64) { assign[i] = -1; pred[2 * i] = 0.0; pred[2 * i + 1] = 0.0; }   // unused slots are defined output (callers hand over uninitialised buffers)
+  float* reduced = p.reduced ? p.reduced + (size_t)f * p.max_obj * (p.K - 1) * p.max_sel * 2 : nullptr;
+  if (reduced)
+    for (int i = lane; i < p.max_obj * (p.K - 1) * p.max_sel * 2; i += 64) reduced[i] = __builtin_nanf("");
   if (nobj == 0) return;
   if (lane < nobj) { oc[2 * lane] = pk[lane * 3 + 0]; oc[2 * lane + 1] = pk[lane * 3 + 1]; }
   __syncthreads();
@@ -206,6 +292,34 @@ __global__ __launch_bounds__(64) void okp_group_objects_kernel(const GroupParams
     if (lane < nobj) {
       votes[lane * (p.K - 1) + (k - 1)] = my_votes;
       if (want == 1 && my_votes > 0) sel[((size_t)lane * (p.K - 1) + (k - 1)) * p.max_sel] = my_best_j;
+    }
+    // multi-instance type with more votes than instances: the reference's k-means reduction, on the device (wave-uniform loop over the objects)
+    if (reduced && want > 1 && want <= p.max_sel) {
+      const unsigned long long surplus = __ballot(lane < nobj && my_votes > want);
+      if (surplus) {
+        __syncthreads();                                  // the `assign` entries of this type, written by other lanes, are visible
+        for (unsigned long long rest = surplus; rest; rest &= rest - 1ull) {
+          const int o = __ffsll((long long)rest) - 1;
+          int np = 0;
+          double px = 0.0, py = 0.0; float cf = 0.f;
+          for (int base = 0; base < npk && np < 64; base += 64) {        // the object's votes in peak order, compacted onto lanes 0 .. np - 1
+            const int j = base + lane;
+            const bool mine = j < npk && assign[k * p.cap + j] == o;
+            const unsigned long long m = __ballot(mine);
+            float x = 0.f, y = 0.f, c = 0.f;
+            if (mine) { const float* q = pk + ((size_t)k * p.cap + j) * 3; x = q[0]; y = q[1]; c = q[2]; }
+            for (unsigned long long mm = m; mm; mm &= mm - 1ull) {
+              const int src = __ffsll((long long)mm) - 1;
+              const int dst = np + __popcll(m & ((1ull << src) - 1ull));
+              const float sx = __shfl(x, src), sy = __shfl(y, src), sc = __shfl(c, src);
+              if (lane == dst) { px = (double)sx; py = (double)sy; cf = sc; }
+            }
+            np += __popcll(m);
+          }
+          np = np < 64 ? np : 64;
+          reduce_surplus(np, px, py, cf, want, lane, reduced + ((size_t)o * (p.K - 1) + (k - 1)) * p.max_sel * 2);
+        }
+      }
     }
   }
 }
@@ -716,7 +830,7 @@ extern "C" int okp_lift_peaks(const okp_camera* cam, const int32_t* count, const
   return okp_check_hip(hipGetLastError(), "okp_lift_peaks launch");
 }
 
-__global__ void okp_capacity_overflow_kernel(const int* __restrict__ count, int n_maps, int K, int cap, int max_obj, int* __restrict__ flag) {
+__global__ void okp_capacity_overflow_kernel(const int* __restrict__ count, int n_maps, int K, int cap, int max_obj, const int* __restrict__ range_flag, int* __restrict__ flag) {
   // one workgroup: any map with more peaks than `cap`, or any centre map (map 0 of a frame) with more than `max_obj`
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
@@ -728,24 +842,24 @@ __global__ void okp_capacity_overflow_kernel(const int* __restrict__ count, int 
   }
   if (bad) atomicOr(&any, 1);
   __syncthreads();
-  if (threadIdx.x == 0) *flag = any;
+  if (threadIdx.x == 0) *flag = any | ((range_flag && *range_flag) ? 2 : 0);      // bit 1: the network's fp16-range flag (okp_conv_set_range_flag)
 }
 
-extern "C" int okp_capacity_overflow(const int32_t* count, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, int32_t* flag, void* stream) {
+extern "C" int okp_capacity_overflow(const int32_t* count, int32_t n_maps, int32_t K, int32_t cap, int32_t max_obj, const int32_t* range_flag, int32_t* flag, void* stream) {
   if (!count || !flag || K < 1) { okp_set_error("okp_capacity_overflow: bad argument"); return OKP_EINVAL; }
-  hipLaunchKernelGGL(okp_capacity_overflow_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, count, n_maps, K, cap, max_obj, flag);
+  hipLaunchKernelGGL(okp_capacity_overflow_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, count, n_maps, K, cap, max_obj, range_flag, flag);
   return okp_check_hip(hipGetLastError(), "okp_capacity_overflow launch");
 }
 
 extern "C" int okp_group_objects(const int32_t* count, const float* xyc, const float* centers, int32_t n, int32_t K, int32_t cap,
                                  int32_t h, int32_t w, const int32_t* type_count, float max_dist, int32_t max_obj, int32_t max_sel,
-                                 int32_t* n_obj, int32_t* sel, int32_t* n_votes, int32_t* assign, double* pred, void* stream) {
+                                 int32_t* n_obj, int32_t* sel, int32_t* n_votes, int32_t* assign, double* pred, float* reduced, void* stream) {
   if (!count || !xyc || !centers || !type_count || !n_obj || !sel || !n_votes || !assign || !pred) { okp_set_error("okp_group_objects: null argument"); return OKP_EINVAL; }
   if (K < 2 || K > 8 || max_sel < 1 || max_sel > 8 || max_obj < 1 || max_obj > 64 || cap < 1) { okp_set_error("okp_group_objects: K in [2,8], max_sel in [1,8], max_obj in [1,64] required"); return OKP_EINVAL; }
   if (n <= 0) return OKP_OK;
   GroupParams p;
   p.count = count; p.xyc = xyc; p.centers = centers; p.n = n; p.K = K; p.cap = cap; p.H = h; p.W = w;
-  p.max_obj = max_obj; p.max_sel = max_sel; p.max_dist = max_dist; p.n_obj = n_obj; p.sel = sel; p.n_votes = n_votes; p.assign = assign; p.pred = pred;
+  p.max_obj = max_obj; p.max_sel = max_sel; p.max_dist = max_dist; p.n_obj = n_obj; p.sel = sel; p.n_votes = n_votes; p.assign = assign; p.pred = pred; p.reduced = reduced;
   for (int k = 0; k < 8; ++k) p.type_count[k] = k < K - 1 ? type_count[k] : 0;
   hipLaunchKernelGGL(okp_group_objects_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, p);
   return okp_check_hip(hipGetLastError(), "okp_group_objects launch");

@@ -212,6 +212,7 @@ struct Params {
   float* out_ptr[OKP_HEAD_MAX_OUT];
   int64_t out_n_stride[OKP_HEAD_MAX_OUT];
   int32_t n_tiles;
+  int32_t* range_flag;         // plan l1's range flag (okp_conv_set_range_flag) or NULL: raised when a hidden value of layer 1 leaves the fp16 range
 };
 
 __device__ __forceinline__ uint32_t row_key(int row) { return (uint32_t)(((row & 1) << 3) | ((row & 2) << 1) | ((row >> 2) & 1)); }
@@ -310,13 +311,15 @@ __global__ __launch_bounds__(256, 2) void okp_heads_x3_kernel(const Params p) {
           for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = H16<_Float16>::mfma16(w1h[cb][ks], xh[ks & 1][pb], acc[cb][pb]);
       }
       // h1 as pairs: channels 32 w + 16 cb + 4 q .. + 3 of the head = half (q & 1) of pair 4 w + 2 cb + (q >> 1) of pixel 16 pb + l16
+      bool range_bad = false;                              // a hidden value (split for the second layer) outside the fp16 range: local to this block,
+                                                           // so that nothing of the guard is live across the GEMMs
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[cb][pb][e], s1v[cb][e], b1v[cb][e]), 0.f);
+          for (int e = 0; e < 4; ++e) { v[e] = fmaxf(__builtin_fmaf(acc[cb][pb][e], s1v[cb][e], b1v[cb][e]), 0.f); range_bad |= okp_unsplittable(v[e]); }   // (x's producer has checked x)
           u32x2 hi, lo;
           okp_split4(v, hi, lo);
           const int px = 16 * pb + l16;
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void okp_heads_x3_kernel(const Params p) {
           *reinterpret_cast<u32x2*>(row + pos) = hi;
           *reinterpret_cast<u32x2*>(row + (pos ^ 16u)) = lo;
         }
+      okp_raise_range_flag(p.range_flag, range_bad);
     }
     __syncthreads();
     // x is free (every wave has read its fragments): the next tile streams in under GEMM 2 and the last layer
@@ -387,7 +391,7 @@ static int heads_forward_x3(const okp_conv* l1, const okp_conv* l2, const okp_he
   p.x = x->data; p.x_bytes = (uint32_t)x->bytes; p.x_ps = x->pix_stride;
   p.HW = a->h * a->w; p.n_pix = (long)a->n * p.HW;
   p.w1 = l1->fragT_dev; p.b1 = l1->bias_dev; p.s1 = l1->oscale_dev; p.w2 = l2->fragT_dev; p.b2 = l2->bias_dev; p.s2 = l2->oscale_dev;
-  p.w3 = a->w_dev; p.b3 = a->bias_dev; p.n_out = a->n_out;
+  p.w3 = a->w_dev; p.b3 = a->bias_dev; p.n_out = a->n_out; p.range_flag = l1->range_flag;
   for (int o = 0; o < a->n_out; ++o) {
     if (a->in_c_off[o] % F2 || a->in_c_off[o] < 0 || a->in_c_off[o] >= 3 * F2 || !a->out_ptr[o]) { okp_set_error("okp_heads_forward: output %d: bad channel offset or null pointer", o); return OKP_EINVAL; }
     p.head_of[o] = a->in_c_off[o] / F2; p.act[o] = a->act[o]; p.out_ptr[o] = a->out_ptr[o]; p.out_n_stride[o] = a->out_n_stride[o];

@@ -620,6 +620,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
     // Residual vectors: requested UH items at a time (the accumulators are dead - they were staged above - so registers
     // are available), instead of one exposed memory round trip per batch of two items.
     constexpr int UH = U >= 16 ? U / 4 : (U >= 8 ? U / 2 : U);
+    bool range_bad = false;                        // split-product plans: a result of this pass leaves the fp16 range (okp_unsplittable); local to
+                                                   // the epilogue, so that nothing of it is live across the K loop
 #pragma unroll 1
     for (int ub = 0; ub < U; ub += UH) {
     u32x4 rres[UH][CH8];
@@ -725,6 +727,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
                 for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb[e]; }
               }
             }
+            if constexpr (X3) {            // before the ReLU: fmaxf would turn the NaN of an out-of-range operand upstream into 0
+#pragma unroll
+              for (int e = 0; e < 8; ++e) range_bad |= okp_unsplittable(v[e]);
+            }
             if (p.act == OKP_ACT_RELU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -743,6 +749,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
       }
     }
     }  // ub
+    if constexpr (X3) okp_raise_range_flag(p.range_flag, range_bad);
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
   }
@@ -762,6 +769,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
     static_assert(NT % CG == 0 && BPX % PSEG == 0 && SEG % G == 0, "depth-wise work split");
     const int cq = tid % CG, pl = tid / CG;
     const int ch = co0 + cq * VN;
+    bool dw_range_bad = false;
     if (ch < p.cout) {
       float wreg[9][VN], breg[VN];
 #pragma unroll
@@ -794,6 +802,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
           to_f(*reinterpret_cast<const u32x4*>(static_cast<const char*>(p.dw_res) + (opix * p.dw_res_pix_stride + ch) * ESZ), r);
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] += r[e];
+        }
+        if constexpr (X3) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) dw_range_bad |= okp_unsplittable(v[e]);
         }
         if (p.act == OKP_ACT_RELU) {
 #pragma unroll
@@ -868,6 +880,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
         }
       }
     }
+    if constexpr (X3) okp_raise_range_flag(p.range_flag, dw_range_bad);
   }
   }  // tile loop
 }

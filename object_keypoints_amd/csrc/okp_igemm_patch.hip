@@ -468,6 +468,7 @@ int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatc
   p.out = q.out; p.out_bytes = q.out_bytes; p.out_pix_stride = q.out_pix_stride;
   p.res = q.res; p.res_bytes = q.res_bytes; p.res_pix_stride = q.res_pix_stride; p.act = q.act;
   p.pairs = ((uint32_t)q.src_pairs & 3u) | (q.out_pairs ? 4u : 0u);
+  p.range_flag = q.range_flag;
   p.n_co_tiles = q.cout_pad / 256;
   p.tiles_per_class = p.n_co_tiles * p.N * p.tiles_y * p.tiles_x;
   p.n_tiles = p.tiles_per_class * p.n_classes;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave >> 1, wpx = wave & 1;
   const int fr = lane & 15, fh = lane >> 4;
+  bool range_bad = false;                          // some result of this launch leaves the fp16 range (okp_unsplittable)
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
@@ -336,6 +337,8 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
 #pragma unroll
               for (int e = 0; e < 4; ++e) { va[e] += ra[e]; vb[e] += rb[e]; }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) range_bad |= okp_unsplittable(va[e]) || okp_unsplittable(vb[e]);      // (before the ReLU: fmaxf turns a NaN into 0)
             if (relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], 0.f); vb[e] = fmaxf(vb[e], 0.f); }
@@ -382,6 +385,8 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += r[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) range_bad |= okp_unsplittable(v[e]);
             if (relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -393,6 +398,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
       __syncthreads();                               // staging is free again: the next pass / the next tile's LDS-DMA may overwrite it
     }
   }
+  okp_raise_range_flag(p.range_flag, range_bad);
 }
 
 }  // namespace

@@ -84,6 +84,17 @@ static __device__ __forceinline__ void okp_split4(const f32x4& x, u32x2& hi, u32
 #endif
 }
 
+// OKP_F32X3 range guard: a value that a split-product consumer will halve (hi = fp16(x)) must fit fp16, |x| <= 65504 - beyond it hi is
+// inf, lo = fp16(x - hi) is -inf and the three-term product is NaN, which the next ReLU (fmaxf) silently turns into 0.  Every kernel that
+// PRODUCES such a value (an output tensor of a split-product plan, the squeeze tile of the one-launch fire module, the hidden layer of the
+// heads, the frames the stem reads) accumulates `bad` per lane and raises the plan's flag (okp_conv_set_range_flag) at its end.
+static __device__ __forceinline__ bool okp_unsplittable(float v) { return !(__builtin_fabsf(v) <= 65504.f); }     // (true for NaN)
+static __device__ __forceinline__ void okp_raise_range_flag(int32_t* flag, bool bad) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (flag != nullptr && bad) atomicOr(flag, 1);     // (no lane takes this branch in a healthy launch)
+#endif
+}
+
 template <typename T> __device__ __forceinline__ uint32_t okp_pack2(float a, float b) {     // two fp32 -> one packed dword (RNE)
   typename H16<T>::x2 v;
   v[0] = (T)a; v[1] = (T)b;
@@ -153,6 +164,7 @@ struct OkpIgemmParams {
   int32_t src_pairs, out_pairs;      // OKP_F32X3 on the patch-resident kernel: sources (bit s) / output in pair format (okp_conv_args.src_pairs / out_pairs)
   int32_t out_sub2, OH2, OW2;        // OKP_F32X3: the fp32 output keeps even rows / columns only (tensor of OH2 x OW2 pixels); out16 is full size
   int32_t mfma32;                    // tile 14: the patch-resident 16-bit kernel on 32x32x16 MFMAs (experiment)
+  int32_t* range_flag;               // OKP_F32X3: the plan's range flag (okp_conv_set_range_flag) or NULL
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 
@@ -194,6 +206,7 @@ struct OkpPatchParams {
   const void* res; uint32_t res_bytes; int32_t res_pix_stride;
   int32_t act, n_co_tiles, n_tiles;
   uint32_t pairs;              // okp_igemm_patch_x3.hip: bit s = source s arrives in pair format (its patches are not split), bit 2 = out is written in pair format
+  int32_t* range_flag;         // okp_igemm_patch_x3.hip: the plan's range flag or NULL
 #ifdef OKP_PATCH_STAMPS
   uint32_t* dbg;
 #endif
@@ -207,6 +220,7 @@ struct OkpFire2Params {       // okp_fire2.hip: streaming fire module, 256 -> 12
   const void* wa; int32_t wa_cout_pad; const float* ba;     // expand plan
   const float* wd; const float* bd;                         // depth-wise [9][128] fp32, bias [128]
   const float* s1; const float* sa;                         // okp_fire_x3.hip (split-product plans): output scales of the squeeze / expand plan
+  int32_t* range_flag;                                      // okp_fire_x3.hip: the squeeze plan's range flag or NULL
   int32_t SH, SW, IH, IW, IP, RPR, tiles_y, tiles_x, n_tiles;
   OkpFastDiv div_tiles_frame, div_tiles_x, div_sw, div_iw, div_rpr;
 #ifdef OKP_FIRE_STAMPS
@@ -246,6 +260,7 @@ struct okp_conv {
   int32_t patch_n_geom;
   int32_t patch_src[OKP_PATCH_MAX_GEOM], patch_PW[OKP_PATCH_MAX_GEOM], patch_PH[OKP_PATCH_MAX_GEOM], patch_oy[OKP_PATCH_MAX_GEOM], patch_ox[OKP_PATCH_MAX_GEOM], patch_step[OKP_PATCH_MAX_GEOM];
   void* frag_dev;          // single-tap 16-bit plans: weights re-laid in MFMA-fragment order (built by okp_conv_create; NULL otherwise)
+  int32_t* range_flag;     // OKP_F32X3 plans: device flag raised by this plan's launches when a result leaves the fp16 range (okp_conv_set_range_flag); NULL = off
   void* fragT_dev;         // the same with the channel-as-ROW order of okp_fire2 (row i of block b = channel 32 w + 8 (i >> 2) + 4 b + (i & 3));
                            // single-tap OKP_F32X3 plans: [cout / 16][hi | lo][cin / 32][lane][8 fp16], row i of wave w = channel 16 w + i (okp_fire_x3.hip)
 };

@@ -53,6 +53,7 @@ struct StemParams {
   int32_t N, Ho, Wo, out_pix_stride;
   int32_t tiles_x, tiles_y, n_tiles;
   OkpFastDiv div_tiles_frame, div_tiles_x;
+  int32_t* range_flag;      // split-product plan: raised when a frame value or a result leaves the fp16 range (okp_stem_set_range_flag), or NULL
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
+  bool range_bad = false;                    // a frame value or a result outside the fp16 range (okp_unsplittable)
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   u32x4 wh[KSTEPS], wl[KSTEPS];              // B-operand fragments of this wave's 32 channels: [wave][hi | lo][k-step][lane]
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
       if (idx < PATCH_BYTES / 8) {
         f16x4 hi, lo;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { hi[c] = (_Float16)pv[i][c]; lo[c] = (_Float16)(pv[i][c] - (float)hi[c]); }
+        for (int c = 0; c < 3; ++c) { hi[c] = (_Float16)pv[i][c]; lo[c] = (_Float16)(pv[i][c] - (float)hi[c]); range_bad |= okp_unsplittable(pv[i][c]); }
         hi[3] = (_Float16)0.f; lo[3] = (_Float16)0.f;
         *reinterpret_cast<f16x4*>(smem + (2 * buf) * PATCH_BYTES + idx * 8) = hi;
         *reinterpret_cast<f16x4*>(smem + (2 * buf + 1) * PATCH_BYTES + idx * 8) = lo;
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
+            range_bad |= okp_unsplittable(acc[r][e] * osc);
             const float v = fmaxf(acc[r][e] * osc, 0.f);
             uint32_t word = __builtin_bit_cast(uint32_t, v);
             if constexpr (PAIRS) {
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
     __syncthreads();            // every thread's part of the next patch is in LDS; this patch is free
     buf ^= 1;
   }
+  okp_raise_range_flag(p.range_flag, range_bad);
 }
 
 }  // namespace
@@ -369,6 +373,7 @@ struct okp_stem {
   float* bias_dev;
   int dtype;
   float* oscale_dev;        // OKP_F32X3 only
+  int32_t* range_flag;      // OKP_F32X3 only: okp_stem_set_range_flag
 };
 
 
@@ -401,7 +406,7 @@ static okp_stem* stem_create_x3(const float* w, const float* bias) {
         }
       }
   }
-  okp_stem* st = new okp_stem{nullptr, nullptr, OKP_F32X3, nullptr};
+  okp_stem* st = new okp_stem{nullptr, nullptr, OKP_F32X3, nullptr, nullptr};
   if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMalloc((void**)&st->oscale_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
@@ -435,7 +440,7 @@ extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const floa
             dst[e] = (kx < 7 && c < 3) ? okp_f32_to_16(dtype, w[((co * 3 + c) * 7 + ky) * 7 + kx]) : 0;
           }
         }
-  okp_stem* st = new okp_stem{nullptr, nullptr, dtype, nullptr};
+  okp_stem* st = new okp_stem{nullptr, nullptr, dtype, nullptr, nullptr};
   if (okp_check_hip(hipMalloc(&st->wfrag_dev, frag.size() * 2), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMalloc((void**)&st->bias_dev, kCout * 4), "okp_stem_create: hipMalloc") ||
       okp_check_hip(hipMemcpy(st->wfrag_dev, frag.data(), frag.size() * 2, hipMemcpyHostToDevice), "okp_stem_create: copy") ||
@@ -446,6 +451,12 @@ extern "C" okp_stem* okp_stem_create_dtype(int dtype, const float* w, const floa
     return nullptr;
   }
   return st;
+}
+
+extern "C" int okp_stem_set_range_flag(okp_stem* st, int32_t* flag_dev) {
+  if (!st || st->dtype != OKP_F32X3) { okp_set_error("okp_stem_set_range_flag: a split-product (OKP_F32X3) stem"); return OKP_EINVAL; }
+  st->range_flag = flag_dev;
+  return OKP_OK;
 }
 
 extern "C" void okp_stem_destroy(okp_stem* st) {
@@ -506,7 +517,7 @@ static int stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w
   StemParams p;
   std::memset(&p, 0, sizeof(p));
   p.src = frames_nchw_dev; p.src_bytes = (uint32_t)src_bytes; p.H = h; p.W = w;
-  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev; p.oscale = st->oscale_dev;
+  p.wfrag = st->wfrag_dev; p.bias = st->bias_dev; p.oscale = st->oscale_dev; p.range_flag = st->range_flag;
   p.out = out->data; p.out_bytes = (uint32_t)out->bytes; p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
   p.tiles_x = (wo + TW - 1) / TW; p.tiles_y = (ho + TH - 1) / TH;
   const long tiles = (long)n * p.tiles_x * p.tiles_y;

@@ -400,10 +400,22 @@ void nms_maxpool(const Tensor& x, int64_t size, const Tensor& out, int64_t strea
            "okp_nms_maxpool");
 }
 
-void capacity_overflow(const Tensor& count, int64_t K, int64_t cap, int64_t max_obj, const Tensor& flag, int64_t stream) {
+void capacity_overflow(const Tensor& count, int64_t K, int64_t cap, int64_t max_obj, const Tensor& flag, int64_t stream, const optional<Tensor>& range_flag) {
   check_dev(count, at::kInt, "count"); check_dev(flag, at::kInt, "flag");
-  check_rc(okp_capacity_overflow(count.data_ptr<int32_t>(), (int32_t)count.numel(), (int32_t)K, (int32_t)cap, (int32_t)max_obj, flag.data_ptr<int32_t>(), sp(stream)),
-           "okp_capacity_overflow");
+  if (range_flag.has_value()) check_dev(*range_flag, at::kInt, "range_flag");
+  check_rc(okp_capacity_overflow(count.data_ptr<int32_t>(), (int32_t)count.numel(), (int32_t)K, (int32_t)cap, (int32_t)max_obj,
+                                 range_flag.has_value() ? range_flag->data_ptr<int32_t>() : nullptr, flag.data_ptr<int32_t>(), sp(stream)), "okp_capacity_overflow");
+}
+
+// fp16-range guard of split-product plans: the plan's launches OR 1 into flag[0] when a result leaves the fp16 range (include/okp.h).  The
+// caller keeps `flag` alive as long as the plan is used.
+void conv_set_range_flag(int64_t plan, const optional<Tensor>& flag) {
+  if (flag.has_value()) check_dev(*flag, at::kInt, "flag");
+  check_rc(okp_conv_set_range_flag(reinterpret_cast<okp_conv*>(plan), flag.has_value() ? flag->data_ptr<int32_t>() : nullptr), "okp_conv_set_range_flag");
+}
+void stem_set_range_flag(int64_t stem, const optional<Tensor>& flag) {
+  if (flag.has_value()) check_dev(*flag, at::kInt, "flag");
+  check_rc(okp_stem_set_range_flag(reinterpret_cast<okp_stem*>(stem), flag.has_value() ? flag->data_ptr<int32_t>() : nullptr), "okp_stem_set_range_flag");
 }
 
 void stream_wait_stream(int64_t waiter, int64_t signaller) { check_rc(okp_stream_wait_stream(sp(waiter), sp(signaller)), "okp_stream_wait_stream"); }
@@ -450,16 +462,22 @@ void lift_peaks(at::ArrayRef<double> camera, const Tensor& count, const Tensor& 
 }
 
 void group_objects(const Tensor& count, const Tensor& xyc, const Tensor& centers, at::IntArrayRef type_count, double max_dist, int64_t max_obj, int64_t max_sel,
-                   const Tensor& n_obj, const Tensor& sel, const Tensor& votes, const Tensor& assign, const Tensor& pred, int64_t stream) {
+                   const Tensor& n_obj, const Tensor& sel, const Tensor& votes, const Tensor& assign, const Tensor& pred, int64_t stream, const optional<Tensor>& reduced) {
   TORCH_CHECK(xyc.is_cuda() && xyc.dim() == 4 && centers.is_cuda() && centers.dim() == 5 && centers.is_contiguous() && centers.scalar_type() == at::kFloat, "okp: group_objects inputs");
   const int64_t n = xyc.size(0), K = xyc.size(1), cap = xyc.size(2);
   TORCH_CHECK((int64_t)type_count.size() == K - 1 && K <= 8, "okp: type_count has K-1 entries, K <= 8");
   int32_t tc[8];
   for (int64_t i = 0; i < K - 1; ++i) tc[i] = (int32_t)type_count[i];
+  float* red = nullptr;
+  if (reduced.has_value()) {
+    TORCH_CHECK(reduced->is_cuda() && reduced->scalar_type() == at::kFloat && reduced->is_contiguous() && reduced->numel() == n * max_obj * (K - 1) * max_sel * 2,
+                "okp: reduced is a contiguous float32 [N, max_obj, K-1, max_sel, 2] device tensor");
+    red = reduced->data_ptr<float>();
+  }
   check_rc(okp_group_objects(count.data_ptr<int32_t>(), xyc.data_ptr<float>(), centers.data_ptr<float>(), (int32_t)n, (int32_t)K, (int32_t)cap,
                              (int32_t)centers.size(3), (int32_t)centers.size(4), tc, (float)max_dist, (int32_t)max_obj, (int32_t)max_sel,
                              n_obj.data_ptr<int32_t>(), sel.data_ptr<int32_t>(), votes.data_ptr<int32_t>(), assign.data_ptr<int32_t>(), pred.data_ptr<double>(),
-                             reinterpret_cast<void*>(stream)), "okp_group_objects");
+                             red, reinterpret_cast<void*>(stream)), "okp_group_objects");
 }
 
 }  // namespace
@@ -478,7 +496,7 @@ TORCH_LIBRARY(okp, m) {
   m.def("peak_nms(Tensor heat, int cap, Tensor(a!) count, Tensor(b!) yx, Tensor(c!) xyc, int stream) -> ()", peak_nms);
   m.def("lift_peaks(float[] camera, Tensor count, Tensor xyc, Tensor depth, int max_x, int max_y, Tensor(a!) out, int stream) -> ()", lift_peaks);
   m.def("group_objects(Tensor count, Tensor xyc, Tensor centers, int[] type_count, float max_dist, int max_obj, int max_sel, Tensor(a!) n_obj, Tensor(b!) sel, Tensor(c!) votes, "
-        "Tensor(d!) assign, Tensor(e!) pred, int stream) -> ()", group_objects);
+        "Tensor(d!) assign, Tensor(e!) pred, int stream, Tensor(f!)? reduced=None) -> ()", group_objects);
   // plan creation (host tensors in, opaque handle out)
   m.def("conv_create(int dtype, int[] cin, int[] conv_stride, int cout, int[] tap_src, int[] tap_dy, int[] tap_dx, Tensor[] tap_w, Tensor? bias, int act, int[] tap_terms) -> int", conv_create);
   m.def("fold_bn(Tensor weight, Tensor? bn_weight, Tensor? bn_bias, Tensor? bn_mean, Tensor? bn_var, float eps, Tensor? conv_bias) -> (Tensor, Tensor)", fold_bn);
@@ -498,7 +516,9 @@ TORCH_LIBRARY(okp, m) {
   m.def("add_f16_f32(Tensor a, Tensor b, Tensor(a!) out, int act, int stream) -> ()", add_f16_f32);
   m.def("dwconv3x3_forward(Tensor src, int src_c0, int c, int conv_stride, Tensor w, Tensor bias, Tensor? res, int res_c0, Tensor(a!) out, int out_c0, int act, int stream) -> ()", dwconv3x3_forward);
   m.def("nms_maxpool(Tensor x, int size, Tensor(a!) out, int stream) -> ()", nms_maxpool);
-  m.def("capacity_overflow(Tensor count, int K, int cap, int max_obj, Tensor(a!) flag, int stream) -> ()", capacity_overflow);
+  m.def("capacity_overflow(Tensor count, int K, int cap, int max_obj, Tensor(a!) flag, int stream, Tensor? range_flag=None) -> ()", capacity_overflow);
+  m.def("conv_set_range_flag(int plan, Tensor? flag) -> ()", conv_set_range_flag);
+  m.def("stem_set_range_flag(int stem, Tensor? flag) -> ()", stem_set_range_flag);
   m.def("stream_wait_stream(int waiter, int signaller) -> ()", stream_wait_stream);
   m.def("camera_undistort(float[] camera, Tensor xy, Tensor(a!) out, int stream) -> ()", camera_undistort);
   m.def("unproject_depth(float[] camera, Tensor xy, Tensor map_id, Tensor depth, int max_x, int max_y, Tensor(a!) out, int stream) -> ()", unproject_depth);

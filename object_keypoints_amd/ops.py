@@ -60,17 +60,37 @@ MIX_STEM_FP16 = True
 
 class f32_split:
     """Context manager: convolution plans built inside are split-product plans (KeypointNet(compute_dtype=ops.F32X3 / ops.F32MIX) wraps
-    its passes in it)."""
+    its passes in it).  range_flag (int32 device tensor of one element, optional): every split-product plan and stem BUILT inside gets it as
+    its fp16-range flag (okp_conv_set_range_flag: a launch ORs 1 into it when one of its results would not survive the next layer's split
+    into fp16 halves - |x| > 65504 or not finite)."""
 
-    def __init__(self, enabled=True, mixed=False):
+    def __init__(self, enabled=True, mixed=False, range_flag=None):
         self.enabled, self.mixed = bool(enabled), bool(enabled and mixed)
+        self.range_flag = range_flag if self.enabled else None
 
     def __enter__(self):
-        self.prev = (getattr(_MODE, "split", False), getattr(_MODE, "mix", False))
-        _MODE.split, _MODE.mix = self.enabled, self.mixed
+        self.prev = (getattr(_MODE, "split", False), getattr(_MODE, "mix", False), getattr(_MODE, "range_flag", None))
+        _MODE.split, _MODE.mix, _MODE.range_flag = self.enabled, self.mixed, self.range_flag
 
     def __exit__(self, *exc):
-        _MODE.split, _MODE.mix = self.prev
+        _MODE.split, _MODE.mix, _MODE.range_flag = self.prev
+
+
+def _attach_range_flag(plan, setter_name):
+    """Give a freshly built split-product plan the range flag of the enclosing f32_split context, if there is one."""
+    flag = getattr(_MODE, "range_flag", None)
+    plan._range_flag = None
+    if flag is None or not plan.split:
+        return
+    require_cuda(flag, "range_flag")
+    if flag.dtype != torch.int32 or flag.numel() != 1:
+        raise OkpError("range_flag is an int32 device tensor of one element")
+    T = _ops()
+    if T is not None:
+        _dispatch(getattr(T, setter_name), plan._h, flag)
+    else:
+        _lib.check(getattr(_lib.lib(), "okp_" + setter_name)(plan._h, flag.data_ptr()), "okp_" + setter_name)
+    plan._range_flag = flag              # (the plan's launches write through this pointer: keep the tensor alive with the plan)
 
 
 def parse_compute_dtype(compute_dtype):
@@ -256,9 +276,8 @@ class ConvPlan:
         if T is not None:       # torch.ops.okp.conv_create: host tensors in, opaque handle out
             self._h = _dispatch(T.conv_create, code, list(cins), (list(strides) + [1] * len(cins))[:len(cins)], cout, [t[0] for t in taps], [t[1] for t in taps], [t[2] for t in taps],
                                 [torch.from_numpy(w) for w in keep], torch.from_numpy(b) if b is not None else None, act, self.tap_terms or [])
-            self._via_torch = True
+            _attach_range_flag(self, "conv_set_range_flag")
             return
-        self._via_torch = False
         arr_t = (_lib.okp_tap * n_taps)()
         for i, (src, dy, dx, _) in enumerate(taps):
             arr_t[i] = _lib.okp_tap(src, dy, dx, keep[i].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
@@ -272,6 +291,7 @@ class ConvPlan:
             self._h = L.okp_conv_create(code, self.n_src, cin_arr, st_arr, cout, n_taps, arr_t, bp, act)
         if not self._h:
             raise OkpError("okp_conv_create: " + L.okp_last_error().decode())
+        _attach_range_flag(self, "conv_set_range_flag")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -613,10 +633,12 @@ class StemPlan:
         T = _ops()
         if T is not None:
             self._h = _dispatch(T.stem_create, OKP_F32X3 if self.split else okp_dtype(dtype), torch.from_numpy(w), torch.from_numpy(b))
+            _attach_range_flag(self, "stem_set_range_flag")
             return
         self._h = L.okp_stem_create_dtype(OKP_F32X3 if self.split else okp_dtype(dtype), w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         if not self._h:
             raise OkpError("okp_stem_create: " + L.okp_last_error().decode())
+        _attach_range_flag(self, "stem_set_range_flag")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -888,7 +910,8 @@ def lift_peaks(cam, count, xyc, depth, max_x, max_y):
 def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_dist=20.0):
     """Device-side object grouping (okp_group_objects).  count [N,K] int32, xyc [N,K,cap,3] fp32, centers
     [N,K-1,2,H,W] fp32 -> dict of device tensors: n_obj [N], sel [N,max_obj,K-1,max_sel], n_votes [N,max_obj,K-1],
-    assign [N,K,cap] (int32) and pred [N,K,cap,2] (fp64 predicted centres)."""
+    assign [N,K,cap] (int32), pred [N,K,cap,2] (fp64 predicted centres) and reduced [N,max_obj,K-1,max_sel,2] (fp32: the cluster centres of
+    a multi-instance type that received more votes than it has instances - the reference's k-means branch, pipeline.py:143-148 - NaN elsewhere)."""
     require_cuda(xyc, "xyc")
     n, k, cap, _ = xyc.shape
     centers = centers.contiguous()
@@ -900,28 +923,34 @@ def group_objects(count, xyc, centers, type_count, max_obj=16, max_sel=4, max_di
     votes = torch.empty((n, max_obj, k - 1), dtype=torch.int32, device=dev)
     assign = torch.empty((n, k, cap), dtype=torch.int32, device=dev)
     pred = torch.empty((n, k, cap, 2), dtype=torch.float64, device=dev)      # (the kernel zeroes the unused slots)
+    reduced = torch.empty((n, max_obj, k - 1, max_sel, 2), dtype=torch.float32, device=dev)     # (NaN where no reduction took place)
     T = _ops()
     if T is not None:
-        _dispatch(T.group_objects, count, xyc, centers, [int(c) for c in type_count], float(max_dist), max_obj, max_sel, n_obj, sel, votes, assign, pred, stream_int())
+        _dispatch(T.group_objects, count, xyc, centers, [int(c) for c in type_count], float(max_dist), max_obj, max_sel, n_obj, sel, votes, assign, pred, stream_int(), reduced)
     else:
         tc = (ctypes.c_int32 * (k - 1))(*[int(c) for c in type_count])
         _lib.check(_lib.lib().okp_group_objects(count.data_ptr(), xyc.data_ptr(), centers.data_ptr(), n, k, cap, centers.shape[3], centers.shape[4],
                                                 tc, float(max_dist), max_obj, max_sel, n_obj.data_ptr(), sel.data_ptr(), votes.data_ptr(),
-                                                assign.data_ptr(), pred.data_ptr(), stream_handle()), "okp_group_objects")
-    return {"n_obj": n_obj, "sel": sel, "n_votes": votes, "assign": assign, "pred": pred}
+                                                assign.data_ptr(), pred.data_ptr(), reduced.data_ptr(), stream_handle()), "okp_group_objects")
+    return {"n_obj": n_obj, "sel": sel, "n_votes": votes, "assign": assign, "pred": pred, "reduced": reduced}
 
 
-def capacity_overflow(count, cap, max_obj):
+RANGE_OVERFLOW = 2       # bit of capacity_overflow()'s word: the split-product network's fp16-range flag was raised
+
+
+def capacity_overflow(count, cap, max_obj, range_flag=None):
     """count [N,K] int32 (device) -> 0-d int32 tensor (device), non-zero when some map holds more than `cap` peaks or some frame more
-    than `max_obj` centre peaks (`bool(flag)` on the host).  One small launch, no host sync, no torch kernel."""
+    than `max_obj` centre peaks (bit 0), or - with `range_flag`, the fp16-range flag of the split-product network that made the maps -
+    when that flag is raised (bit 1, RANGE_OVERFLOW).  `bool(flag)` on the host.  One small launch, no host sync, no torch kernel."""
     require_cuda(count, "count")
     flag = torch.empty((1,), dtype=torch.int32, device=count.device)
     n, k = count.shape
     T = _ops()
     if T is not None:
-        _dispatch(T.capacity_overflow, count.contiguous(), k, cap, max_obj, flag, stream_int())
+        _dispatch(T.capacity_overflow, count.contiguous(), k, cap, max_obj, flag, stream_int(), range_flag)
     else:
-        _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
+        _lib.check(_lib.lib().okp_capacity_overflow(count.data_ptr(), n * k, k, cap, max_obj, range_flag.data_ptr() if range_flag is not None else None,
+                                                    flag.data_ptr(), stream_handle()), "okp_capacity_overflow")
     return flag[0]
 
 

@@ -102,6 +102,16 @@ class KeypointNet(_HipModule):
         # uint8 frames of any other size are resized (shortest side) and centre-cropped to this size on the device, as the
         # reference's data path does (perception/datasets/video.py:63-69,95-96); None = uint8 frames are taken as they are
         self.raw_frame_size = 511
+        # Split-product configurations halve fp32 values into fp16: a value beyond +-65504 has no halves (inf, -inf -> NaN products, which the
+        # next ReLU turns into 0 without a trace), where the reference's fp32 arithmetic returns numbers.  The kernels raise a device flag
+        # (okp_conv_set_range_flag) whenever a value they hand on leaves that range; what a pass does about it:
+        #   "raise"   (default) deployed() / forward() read the flag behind the pass (one device -> host word) and raise OkpError
+        #   "float32" ... and run the pass again with the exact fp32 kernels (slow, always right), with a RuntimeWarning the first time
+        #   "defer"   nothing is read: the caller asks range_overflow() or folds range_flag() into okp_capacity_overflow's word
+        #             (BatchedKeypointPipeline.forward_device does; captured graphs cannot branch on the host anyway)
+        self.on_overflow = "raise"
+        self._range_flag = None
+        self._warned_overflow = False
 
     # ---- fused three-head plan for one stack ------------------------------------------------
     def _build_heads(self, stack, dtype, device):
@@ -120,9 +130,55 @@ class KeypointNet(_HipModule):
         b3 = np.concatenate([_np(pm[2].bias) for pm in heads], 0)
         return l1, l2, torch.from_numpy(w3).to(device), torch.from_numpy(b3).to(device)
 
+    def range_flag(self, device=None):
+        """The network's fp16-range flag (int32 device tensor of one element; split-product configurations only, else None).  Every
+        split-product plan built by this network's passes raises it; the passes zero it when they start."""
+        if not self.mfma_split:
+            return None
+        if self._range_flag is None or (device is not None and self._range_flag.device != torch.device(device)):
+            dev = device if device is not None else next(self.parameters()).device
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._drop_all_plans()               # plans hold the old flag's address
+        return self._range_flag
+
+    def _drop_all_plans(self):
+        for m in self.modules():
+            if hasattr(m, "_drop_plans"):
+                m._drop_plans()
+
+    def range_overflow(self):
+        """True if a value left the fp16 range in a split-product pass since the last pass started (reads one word from the device)."""
+        return bool(self.mfma_split and self._range_flag is not None and int(self._range_flag) != 0)
+
+    def _guarded(self, x, run, check):
+        """One pass under the range guard: zero the flag, run, then act on `on_overflow` (see __init__).  check=False: never read the flag."""
+        if not self.mfma_split:
+            return run()
+        if self.on_overflow not in ("raise", "float32", "defer"):
+            raise OkpError("on_overflow is 'raise', 'float32' or 'defer'")
+        self.range_flag(x.device).zero_()
+        out = run()
+        if not check or self.on_overflow == "defer" or torch.cuda.is_current_stream_capturing():
+            return out
+        if int(self._range_flag) == 0:
+            return out
+        if self.on_overflow == "raise":
+            raise OkpError(f"{self.configuration()}: an activation left the fp16 range (|x| > 65504 or not finite); the split products of this pass are "
+                           "not fp32-grade.  Run these weights with compute_dtype=torch.float32, or load with on_overflow='float32'")
+        if not self._warned_overflow:
+            import warnings
+            warnings.warn(f"{self.configuration()}: an activation left the fp16 range; passes that do are re-run with the exact float32 kernels", RuntimeWarning, stacklevel=3)
+            self._warned_overflow = True
+        mine = (self.compute_dtype, self.mfma_split, self.mixed)
+        try:
+            self.compute_dtype, self.mfma_split, self.mixed = torch.float32, False, False
+            return run()
+        finally:
+            self.compute_dtype, self.mfma_split, self.mixed = mine
+
     def _run_heads(self, stack, cnv, sigmoid):
-        with ops.f32_split(self.mfma_split, self.mixed):
-            return self._run_heads_(stack, cnv, sigmoid)
+        with ops.f32_split(self.mfma_split, self.mixed, self.range_flag(cnv.t.device)):      # (allocated here if no guarded pass has run yet: a plan
+            return self._run_heads_(stack, cnv, sigmoid)                                     #  built without the flag would be cached without it)
 
     def _run_heads_(self, stack, cnv, sigmoid):
         l1, l2, w3, b3 = self._plan(("heads", stack, cnv.dtype), lambda: self._build_heads(stack, cnv.dtype, cnv.t.device))
@@ -147,7 +203,7 @@ class KeypointNet(_HipModule):
         return heat, depth, centers.reshape(n, K - 1, 2, h, w)
 
     def _features(self, x):
-        with ops.f32_split(self.mfma_split, self.mixed):
+        with ops.f32_split(self.mfma_split, self.mixed, self.range_flag(x.device) if isinstance(x, torch.Tensor) and x.is_cuda else None):
             return self._features_(x)
 
     def _features_(self, x):
@@ -180,8 +236,11 @@ class KeypointNet(_HipModule):
         step = self.max_frames_per_pass(h, w)
         return [x[i:i + step] for i in range(0, x.shape[0], step)]
 
-    def forward(self, x):
+    def forward(self, x, check_range=True):
         """frames [N,3,H,W] fp32 -> ((hm1,hm2),(d1,d2),(c1,c2)), raw logits for the heat maps."""
+        return self._guarded(x, lambda: self._forward(x), check_range)
+
+    def _forward(self, x):
         outs = []
         for xc in self._chunks(x):
             feats = self._features(xc)
@@ -202,6 +261,10 @@ class KeypointNet(_HipModule):
         self.compute_dtype, self.mfma_split, self.mixed = ops.parse_compute_dtype(compute_dtype)
         return self
 
+    def _apply(self, fn, *a, **k):          # .to() / .cuda(): the range flag lives on the old device
+        self._range_flag = None
+        return super()._apply(fn, *a, **k)
+
     def precision_audit(self, x, against=ops.F32X3):
         """Run the deployed outputs of frames `x` in this network's compute precision AND in `against` (default: the split-product
         configuration, fp32-grade: 2e-6 on the test networks) on the same weights, both on the HIP path, and return the absolute
@@ -210,10 +273,12 @@ class KeypointNet(_HipModule):
         frames, two passes, no CPU reference involved."""
         mine = (self.compute_dtype, self.mfma_split, self.mixed)
         with torch.no_grad():
-            got = [t.float().clone() for t in self.deployed(x)]
+            got = [t.float().clone() for t in self.deployed(x, check_range=False)]
+            mine_over = self.range_overflow()
             try:
                 self.compute_dtype, self.mfma_split, self.mixed = ops.parse_compute_dtype(against)
-                ref = [t.float() for t in self.deployed(x)]
+                ref = [t.float() for t in self.deployed(x, check_range=False)]
+                ref_over = self.range_overflow()
             finally:
                 self.compute_dtype, self.mfma_split, self.mixed = mine
         report = {}
@@ -221,12 +286,18 @@ class KeypointNet(_HipModule):
             d = (g - r).abs().flatten()
             k = max(1, int(round(0.99 * d.numel())))
             report[name] = {"max": float(d.max()), "mean": float(d.mean()), "p99": float(d.kthvalue(k).values),
-                            "finite": bool(torch.isfinite(g).all()) and bool(torch.isfinite(r).all())}      # (fp16 operands overflow above 65504)
+                            # (fp16 operands overflow above 65504: the outputs may still look finite - a ReLU swallows the NaN - so the range flags count)
+                            "finite": bool(torch.isfinite(g).all()) and bool(torch.isfinite(r).all()) and not mine_over and not ref_over}
         return report
 
-    def deployed(self, x):
+    def deployed(self, x, check_range=True):
         """What the packaged model returns (scripts/package_model.py:26-28):
-        sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed."""
+        sigmoid(heat[-1]), depth[-1], centers[-1]; the dead stack-1 heads are not executed.
+        Split-product configurations: the pass runs under the fp16-range guard (on_overflow, see __init__); check_range=False leaves the
+        flag unread (the caller folds range_flag() into its own overflow word)."""
+        return self._guarded(x, lambda: self._deployed(x), check_range)
+
+    def _deployed(self, x):
         chunks = self._chunks(x)
         outs = []
         for xc in chunks:

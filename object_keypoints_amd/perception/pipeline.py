@@ -127,53 +127,79 @@ HEAT_BAR = 1e-3          # north_star: heat maps within 1e-3 of the fp32 referen
 AUDIT_AUTO = "auto"      # load_keypoint_net(audit_frames=...): audit a mixed plan on two synthetic frames when the caller gives none
 
 
-def _audited(net, audit_frames, heat_bar):
+AUDIT_BATCH = 16         # the synthetic audit runs at a batch that takes the kernels a deployment takes (patch-resident kernel, pair tensors, fused heads)
+
+
+def _audited(net, audit_frames, heat_bar, _source=None):
     """float32mix is a plan derived on ONE weight family: its single-term fp16 branches are cheap because BatchNorm
     gains attenuate them there.  With `audit_frames` the loaded network is priced on the device against float32x3 (fp32-grade, 2e-6)
     on the caller's frames (KeypointNet.precision_audit: two passes, no CPU reference) and, where the heat maps are further than
-    `heat_bar` apart - or not finite: fp16 operands overflow above 65504 - the network falls back to float32x3 with a warning.
-    The default (AUDIT_AUTO) audits a MIXED configuration on two synthetic frames, so that no mixed plan ships unverified on the
-    weights it was loaded with; 16-bit configurations are the caller's explicit choice of a precision outside the bar and are audited
-    only on request.  audit_frames=None skips the audit; for a mixed configuration that is said with a RuntimeWarning."""
+    `heat_bar` apart - or a value left the fp16 range: fp16 operands overflow above 65504 - the network falls back to float32x3 with a
+    warning.  float32x3 itself is audited for that range (its one failure mode, KeypointNet.on_overflow): where the audit frames leave
+    it, the network falls back to exact float32, again with a warning.
+    The default (AUDIT_AUTO) audits a split-product configuration on synthetic frames - two N(0,1) frames repeated to a batch of
+    AUDIT_BATCH, so that the launch heuristics pick the kernels a deployment runs - so that no such plan ships unverified on the weights it
+    was loaded with; `net.audit` records the source of the frames and the batch.  Synthetic frames say nothing about activations on REAL
+    frames: the per-pass guard (on_overflow) stays on.  16-bit configurations are the caller's explicit choice of a precision outside the
+    bar and are audited only on request.  audit_frames=None skips the audit; for a mixed configuration that is said with a RuntimeWarning."""
+    import warnings
     if audit_frames is None:
         if getattr(net, "mixed", False):
-            import warnings
             warnings.warn(f"{net.configuration()}: loaded without an audit - this mixed-precision plan was derived on one weight family and is "
                           "UNVERIFIED on these weights (pass audit_frames, or leave the default, to price it against float32x3)", RuntimeWarning, stacklevel=3)
         return net
+    source = _source or "caller"
     if isinstance(audit_frames, str):
         if audit_frames != AUDIT_AUTO:
             raise OkpError(f"audit_frames: a [n,3,H,W] tensor, None or '{AUDIT_AUTO}'")
-        if not net.mixed:
+        if not net.mfma_split:
             return net
         from .. import synth
-        audit_frames = torch.from_numpy(synth.frames(2, seed=20251))
-    if not (net.mixed or net.compute_dtype in ops.HALF_DTYPES):
-        net.audit = {"configuration": net.configuration(), "checked": False, "reason": "fp32-grade configuration: nothing to audit"}
+        audit_frames = torch.from_numpy(synth.frames(2, seed=20251)).repeat(AUDIT_BATCH // 2, 1, 1, 1)
+        source = "synthetic"
+    if not (net.mfma_split or net.compute_dtype in ops.HALF_DTYPES):
+        net.audit = {"configuration": net.configuration(), "checked": False, "reason": "exact float32: nothing to audit"}
         return net
     frames = audit_frames.to(next(net.parameters()).device, torch.float32)
+    requested = net.configuration()
+    base = {"configuration": requested, "checked": True, "frames": int(frames.shape[0]), "batch": int(frames.shape[0]), "frames_source": source, "heat_bar": heat_bar}
+    if net.mfma_split and not net.mixed:
+        # float32x3: one pass; its only failure mode is the fp16 range of its operands
+        with torch.no_grad():
+            outs = net.deployed(frames, check_range=False)
+        ok = not net.range_overflow() and all(bool(torch.isfinite(t).all()) for t in outs)
+        net.audit = dict(base, report={"range_ok": ok}, fell_back=not ok, fell_back_to=None if ok else "float32")
+        if not ok:
+            warnings.warn(f"{requested}: an activation leaves the fp16 range on the audit frames ({source}); falling back to exact float32", RuntimeWarning, stacklevel=3)
+            net.set_compute_dtype(torch.float32)
+        return net
     report = net.precision_audit(frames)
     ok = report["heat"]["finite"] and report["heat"]["max"] <= heat_bar
-    net.audit = {"configuration": net.configuration(), "checked": True, "frames": int(frames.shape[0]), "heat_bar": heat_bar, "report": report,
-                 "fell_back": not ok}
+    net.audit = dict(base, report=report, fell_back=not ok, fell_back_to=None if ok else ops.F32X3)
     if not ok:
-        import warnings
-        warnings.warn(f"{net.configuration()}: heat maps differ from float32x3 by {report['heat']['max']:.2e} on the audit frames "
-                      f"(bar {heat_bar:.0e}, finite: {report['heat']['finite']}); falling back to float32x3", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"{requested}: heat maps differ from float32x3 by {report['heat']['max']:.2e} on the audit frames ({source}, batch {frames.shape[0]}; "
+                      f"bar {heat_bar:.0e}, in range and finite: {report['heat']['finite']}); falling back to float32x3", RuntimeWarning, stacklevel=3)
         net.set_compute_dtype(ops.F32X3)
+        if net.mixed is False and not report["heat"]["finite"]:
+            return _audited(net, audit_frames, heat_bar, _source=source)          # the range may be the reason: float32x3 is audited for it in turn
     return net
 
 
-def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_frames=AUDIT_AUTO, heat_bar=HEAT_BAR):
+def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_frames=AUDIT_AUTO, heat_bar=HEAT_BAR, on_overflow="raise"):
     """Accepts a KeypointNet, a state_dict, or a path to a torch.save'd state_dict / Lightning checkpoint /
     TorchScript file produced by the reference's scripts/package_model.py, and returns an eval KeypointNet.
     Entries of the file that are not KeypointNet parameters (loss buffers, metrics of the Lightning module) are ignored;
     a missing network tensor is an error.
     audit_frames ([n,3,H,W] float32, a handful of representative frames): price a mixed / 16-bit `compute_dtype` on these weights and
-    fall back to float32x3 when it misses `heat_bar` (see _audited; the result is in `net.audit`).  Default: a mixed configuration
-    ("float32mix") is audited on two synthetic frames; None skips the audit (with a RuntimeWarning for a mixed configuration)."""
+    fall back to float32x3 when it misses `heat_bar` (see _audited; the result is in `net.audit`).  Default: a split-product configuration
+    ("float32x3", "float32mix") is audited on synthetic frames; None skips the audit (with a RuntimeWarning for a mixed configuration).
+    on_overflow ("raise" | "float32" | "defer"): what a pass of a split-product configuration does when an activation leaves the fp16
+    range (KeypointNet.on_overflow): raise OkpError, re-run the pass with the exact float32 kernels, or leave the flag to the caller."""
     device = device or _device()
+    if on_overflow not in ("raise", "float32", "defer"):
+        raise OkpError("on_overflow is 'raise', 'float32' or 'defer'")
     if isinstance(model, models.KeypointNet):
+        model.on_overflow = on_overflow
         return _audited(model.to(device).eval(), audit_frames, heat_bar)
     if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
         clean = read_checkpoint_state_dict(model)
@@ -192,6 +218,7 @@ def load_keypoint_net(model, compute_dtype=torch.float32, device=None, audit_fra
     if missing:
         raise OkpError(f"model file lacks {len(missing)} KeypointNet tensors, e.g. '{missing[0]}'")
     net.load_state_dict({k: clean[k] for k in own})
+    net.on_overflow = on_overflow
     return _audited(net.to(device).eval(), audit_frames, heat_bar)
 
 
@@ -534,7 +561,8 @@ class BatchedKeypointPipeline:
         count [N,K] int32, xyc [N,K,cap,3] fp32 (x, y, confidence), points [N,K,cap,4] fp64 (X, Y, Z, confidence),
         overflow (0-d int32, non-zero: some map exceeded `capacity` peaks or `max_objects` centres - results are truncated)
     `points` is the fixed-capacity payload that is all-gathered across ranks (object_keypoints_amd.distributed).
-    objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points.
+    objects(...) groups one frame's peaks exactly as ObjectKeypointPipeline does, reusing the lifted points (surplus votes of a
+    multi-instance type reduced by the device k-means of okp_group_objects).
     """
 
     def __init__(self, net, keypoint_config, camera, prediction_size=(64, 64), capacity=DEFAULT_PEAK_CAPACITY,
@@ -551,8 +579,12 @@ class BatchedKeypointPipeline:
         self.max_index = camera.image_size.astype(int) - 1
 
     def forward_device(self, frames):
-        heat, depth, centers = self.net.deployed(frames)
-        return self.postprocess_device(heat, depth, centers)
+        """Split-product configurations: the network's fp16-range flag is not read here (no host sync in the batch loop) but folded into
+        `overflow` on the device (bit ops.RANGE_OVERFLOW), which objects() checks - except with on_overflow = "float32", where the pass has
+        to be judged on the host before it can be re-run."""
+        defer = getattr(self.net, "on_overflow", "raise") != "float32"
+        heat, depth, centers = self.net.deployed(frames, check_range=not defer)
+        return self.postprocess_device(heat, depth, centers, range_flag=self.net.range_flag(frames.device) if defer else None)
 
     def capture(self, frames):
         """Capture forward_device for this frame shape into a hipGraph (HIP stream capture through torch): the ~75
@@ -572,7 +604,7 @@ class BatchedKeypointPipeline:
             ops.SIDE_STREAMS = keep
         return CapturedStep(self.net, graph, static_in, static_out)
 
-    def postprocess_device(self, heat, depth, centers):
+    def postprocess_device(self, heat, depth, centers, range_flag=None):
         """Peaks, per-peak 3D points and the object grouping from (post-sigmoid) heat, depth and centre maps, all on
         the device: three small launches, nothing crosses PCIe."""
         count, yx, xyc = ops.peak_nms(heat, cap=self.capacity)
@@ -583,14 +615,15 @@ class BatchedKeypointPipeline:
         # The reference has no capacity (pipeline.py:73 keeps every peak); the fixed-capacity tensors do.  `overflow` is a
         # device-side flag (no sync here): a map with more peaks than `capacity`, or more centre peaks than `max_objects`,
         # means `points` / the grouping are truncated - callers check it (objects() raises, bench.py asserts).
-        out["overflow"] = ops.capacity_overflow(count, self.capacity, self.max_objects)
+        out["overflow"] = ops.capacity_overflow(count, self.capacity, self.max_objects, range_flag=range_flag)
         return out
 
     def objects(self, out, n):
         """Frame n of a forward_device() result as the reference's list of object dicts
-        ({'p_centers', 'keypoints', 'p_C'}, pipeline.py:190-200), assembled from the device-side grouping.  Falls back
-        to the host ObjectExtraction for the k-means branch (more detections of a multi-instance type than configured)
-        or when a capacity was exceeded."""
+        ({'p_centers', 'keypoints', 'p_C'}, pipeline.py:190-200), assembled from the device-side grouping.  A multi-instance type that
+        received more votes than it has instances comes back as the cluster centres of the device k-means reduction (`reduced`,
+        okp_group_objects; the reference: an unseeded sklearn KMeans, pipeline.py:143-148), lifted to 3D by one okp_unproject_depth
+        launch for the frame - no scikit-learn, no host clustering."""
         cfg = self.config['keypoint_config']
         count = out["count"][n].cpu().numpy()
         xyc = out["xyc"][n].cpu().numpy()
@@ -599,18 +632,38 @@ class BatchedKeypointPipeline:
         votes = out["n_votes"][n].cpu().numpy()
         if int(count.max(initial=0)) > self.capacity or int(count[0]) > self.max_objects:
             raise OkpError("peak / object capacity exceeded; raise `capacity` / `max_objects`")
-        overflow = any(votes[o, i] > cfg[i] and cfg[i] > 1 for o in range(n_obj) for i in range(len(cfg))) or \
-            any(votes[o, i] > self.max_per_type and cfg[i] > 1 for o in range(n_obj) for i in range(len(cfg)))
-        if overflow:
-            return self._objects_host(out, n, count, xyc, pts3)
+        if int(out["overflow"]) & ops.RANGE_OVERFLOW:
+            raise OkpError("an activation of the split-product network left the fp16 range in this batch: its maps are not fp32-grade "
+                           "(load the network with on_overflow='float32', or run it in torch.float32)")
+        if any(c > self.max_per_type for c in cfg):
+            raise OkpError(f"a keypoint type has {max(cfg)} instances, above max_per_type = {self.max_per_type}")
         sel = out["sel"][n].cpu().numpy()
         assign = out["assign"][n].cpu().numpy()
         pred = out["pred"][n].cpu().numpy()
+        surplus = [(o, i) for o in range(n_obj) for i in range(len(cfg)) if cfg[i] > 1 and votes[o, i] > cfg[i]]
+        centres, lifted = {}, {}
+        if surplus:
+            reduced = out["reduced"][n].cpu().numpy()
+            for o, i in surplus:
+                centres[(o, i)] = reduced[o, i, :cfg[i]].copy()
+            xy = np.concatenate([centres[key] for key in surplus])
+            ids = np.concatenate([np.full(cfg[i], i + 1, dtype=np.int32) for _, i in surplus])
+            dev = out["depth"].device
+            world = ops.unproject_depth(self.cam, torch.from_numpy(xy).to(dev), torch.from_numpy(ids).to(dev), out["depth"][n],
+                                        int(self.max_index[0]), int(self.max_index[1])).cpu().numpy()
+            at = 0
+            for o, i in surplus:
+                lifted[(o, i)] = world[at:at + cfg[i]]
+                at += cfg[i]
         objects = []
         for o in range(n_obj):
             keypoints = [xyc[0, o, :2].copy()[None]]
             world = [pts3[0, o, :3][None]]
             for i in range(len(cfg)):
+                if (o, i) in centres:
+                    keypoints.append(centres[(o, i)])
+                    world.append(lifted[(o, i)])
+                    continue
                 idx = [int(j) for j in sel[o, i] if j >= 0][:max(cfg[i], 1)]
                 if idx:
                     keypoints.append(xyc[i + 1, idx, :2].copy())
@@ -621,6 +674,11 @@ class BatchedKeypointPipeline:
             p_centers = [pred[k, j] for k in range(1, count.shape[0]) for j in range(int(count[k])) if assign[k, j] == o]
             objects.append({'p_centers': p_centers, 'keypoints': keypoints, 'p_C': world})
         return objects
+
+    def objects_reference(self, out, n):
+        """The same frame through the host ObjectExtraction (the reference's loop with scikit-learn's k-means): for comparisons only -
+        objects() never comes here."""
+        return self._objects_host(out, n, out["count"][n].cpu().numpy(), out["xyc"][n].cpu().numpy(), out["points"][n].cpu().numpy())
 
     def _objects_host(self, out, n, count, xyc, pts3):
         centers = out["centers"][n].cpu().numpy()
@@ -654,6 +712,49 @@ class BatchedKeypointPipeline:
         return objects
 
 
+class HostFrameFeed:
+    """Host -> HBM upload of camera frames on a COPY stream, double-buffered, so that the frames of tick t + 1 cross PCIe while tick t is
+    computed (the reference feeds its model from a DataLoader on the host, one frame per call: scripts/eval_model.py:274-293; raw frames
+    are 1280 x 720 uint8, perception/datasets/video.py:83-100).  Frames come as a pinned host tensor of the shape / dtype given at
+    construction (pin_memory() once, reuse it: the copy is only asynchronous from pinned memory).
+
+        feed = HostFrameFeed(host.shape, host.dtype)
+        slot = feed.submit(host)                 # async H2D on the copy stream into the next free device buffer
+        frames = feed.acquire(slot)              # the compute stream waits for that copy (device-side wait, no host sync)
+        ...                                      # launches that read `frames`
+        feed.release(slot)                       # the buffer may be overwritten once the work enqueued so far has run
+    """
+
+    def __init__(self, shape, dtype=torch.uint8, device=None, depth=2):
+        self.device = device or _device()
+        self.buffers = [torch.empty(tuple(shape), dtype=dtype, device=self.device) for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.done = [None] * depth
+        self.next = 0
+
+    def submit(self, host_frames):
+        if host_frames.is_cuda or tuple(host_frames.shape) != tuple(self.buffers[0].shape) or host_frames.dtype != self.buffers[0].dtype:
+            raise OkpError("HostFrameFeed.submit: a host tensor of the shape / dtype the feed was built for")
+        slot = self.next
+        self.next = (self.next + 1) % len(self.buffers)
+        with torch.cuda.stream(self.copy_stream):
+            if self.done[slot] is not None:
+                self.copy_stream.wait_event(self.done[slot])          # the buffer's previous tick has been consumed
+            self.buffers[slot].copy_(host_frames, non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        return slot
+
+    def acquire(self, slot):
+        torch.cuda.current_stream().wait_event(self.ready[slot])
+        return self.buffers[slot]
+
+    def release(self, slot):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.done[slot] = ev
+
+
 class StereoStreamPipeline:
     """BASELINE configs[4] / SURVEY 8(d) config 5: a rig of stereo cameras streamed frame-synchronously.  One TICK takes the 2P
     frames of P stereo pairs (left frame of pair p at index 2p, right at 2p + 1) through the network as ONE batch, finds the heat-map
@@ -664,7 +765,10 @@ class StereoStreamPipeline:
     compute dtype.
 
     tick(frames) -> list over pairs of {type k: (n_k, 3) float64 points in the left camera frame}, plus timing-free device work:
-    three small device -> host copies per tick (peaks, undistorted peaks, 3D points)."""
+    three small device -> host copies per tick (peaks, undistorted peaks, 3D points).
+    `frames`: fp32 NCHW crops [2P, 3, 511, 511] in HBM, or raw camera frames uint8 [2P, H, W, 3] (resized, cropped and normalised on the
+    device, okp_preprocess_u8).  Host-fed operation: stream(host_ticks) uploads the raw frames of tick t + 1 on a copy stream while tick t
+    is computed (HostFrameFeed) and yields the same results, bit for bit, as tick() on resident frames."""
 
     def __init__(self, net, stereo_camera, keypoint_config, capacity=16, max_distance=3.0):
         self.net = net
@@ -692,6 +796,25 @@ class StereoStreamPipeline:
             ops.SIDE_STREAMS = keep
         self._graph = CapturedStep(self.net, graph, static_in, static_out)
         return self._graph
+
+    def stream(self, host_ticks, heat_override=None, use_graph=False):
+        """host_ticks: an iterable of pinned host tensors, one per tick (all of one shape / dtype: raw uint8 [2P, H, W, 3] frames or fp32
+        [2P, 3, 511, 511] crops).  Generator of tick() results; the upload of the next tick overlaps the current one."""
+        it = iter(host_ticks)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        feed = HostFrameFeed(first.shape, first.dtype, device=next(self.net.parameters()).device)
+        slot = feed.submit(first)
+        while slot is not None:
+            frames = feed.acquire(slot)
+            upcoming = next(it, None)
+            nxt = feed.submit(upcoming) if upcoming is not None else None      # crosses PCIe under this tick's kernels
+            result = self.tick(frames, heat_override=heat_override, use_graph=use_graph)
+            feed.release(slot)
+            yield result
+            slot = nxt
 
     def tick(self, frames, heat_override=None, use_graph=False):
         if frames.shape[0] % 2:

@@ -123,7 +123,7 @@ def frames(n, seed=1, start=0, size=511):
 # ----------------------------------------------------------------------------
 
 def bump_scene(keypoint_config, n_objects=1, seed=0, index=0, size=64, length_scale=2.0,
-               margin=6.0):
+               margin=6.0, max_radius=9.0):
     """One frame of post-network maps for `n_objects` objects.
 
     Returns dict with heat (K,size,size), depth (K,size,size), centers (K-1,2,size,size),
@@ -147,7 +147,7 @@ def bump_scene(keypoint_config, n_objects=1, seed=0, index=0, size=64, length_sc
         cx = margin + (gx + 0.3 + 0.4 * j[0]) * cell
         cy = margin + (gy + 0.3 + 0.4 * j[1]) * cell
         obj = {"center": np.array([cx, cy], dtype=np.float32), "points": [], "depths": []}
-        radius = min(0.35 * cell, 9.0)
+        radius = min(0.35 * cell, max_radius)
         for k, count in enumerate(config):
             pts = []
             for i in range(count):
@@ -173,3 +173,24 @@ def bump_scene(keypoint_config, n_objects=1, seed=0, index=0, size=64, length_sc
         objects.append(obj)
     heat = np.clip(heat, 0.0, 1.0).astype(np.float32)
     return {"heat": heat, "depth": depth, "centers": centers, "objects": objects}
+
+
+def add_double_detections(scene, k, offset=(4.0, 3.0), size=64, length_scale=2.0):
+    """Every keypoint of map `k` (>= 1) of a bump_scene gets a second bump at `offset` pixels from it, with the same depth and a centre
+    vector that points at the same object: each instance is detected twice, so the object receives twice as many votes for that type as it
+    has instances - the case the reference reduces with k-means (perception/pipeline.py:143-148).  Returns a new scene dict."""
+    heat, depth, centers = scene["heat"].copy(), scene["depth"].copy(), scene["centers"].copy()
+    ys, xs = np.meshgrid(np.arange(size, dtype=np.float32), np.arange(size, dtype=np.float32), indexing="ij")
+    extra = np.zeros((size, size), dtype=np.float32)
+    for obj in scene["objects"]:
+        cx, cy = obj["center"]
+        for p, z in zip(obj["points"][k], obj["depths"][k]):
+            q = np.clip(p + np.array(offset, dtype=np.float32), 2.0, size - 3.0).astype(np.float32)
+            d2 = (xs - q[0]) ** 2 + (ys - q[1]) ** 2
+            extra += np.exp(-d2 / np.float32(length_scale ** 2)).astype(np.float32)
+            near = d2 < np.float32(16.0)
+            depth[k][near] = z
+            centers[k - 1, 0][near] = (cx - (xs + 0.5))[near]
+            centers[k - 1, 1][near] = (cy - (ys + 0.5))[near]
+    heat[k] = np.clip(heat[k] + extra, 0.0, 1.0).astype(np.float32)
+    return {"heat": heat, "depth": depth, "centers": centers, "objects": scene["objects"]}

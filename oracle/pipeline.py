@@ -104,20 +104,33 @@ class KeypointExtractionComponent:
         return keypoints, confidence
 
 
-def _kmeans(points, k, iters=50):
-    """Lloyd's algorithm with farthest-point init (deterministic stand-in for sklearn KMeans)."""
-    centers = [points[0]]
-    for _ in range(1, k):
-        d = np.min([np.linalg.norm(points - c, axis=1) for c in centers], axis=0)
-        centers.append(points[int(d.argmax())])
-    centers = np.stack(centers).astype(np.float64)
+def _lloyd(points, centers, iters=50):
     for _ in range(iters):
         assign = np.argmin(np.linalg.norm(points[:, None] - centers[None], axis=2), axis=1)
-        new = np.stack([points[assign == j].mean(axis=0) if (assign == j).any() else centers[j] for j in range(k)])
+        new = np.stack([points[assign == j].mean(axis=0) if (assign == j).any() else centers[j] for j in range(len(centers))])
         if np.allclose(new, centers):
             break
         centers = new
-    return centers
+    assign = np.argmin(np.linalg.norm(points[:, None] - centers[None], axis=2), axis=1)
+    return centers, float(((points - centers[assign]) ** 2).sum())
+
+
+def _kmeans(points, k, iters=50):
+    """Deterministic stand-in for the reference's sklearn KMeans(init='random', n_clusters=k) (perception/pipeline.py:146), which under its
+    pinned scikit-learn 0.24.1 runs n_init = 10 random starts and keeps the run of least inertia: Lloyd's algorithm from a farthest-point
+    start seeded by EVERY point in turn, least inertia kept (earlier seeds win ties).  On the handful of votes an object receives this finds
+    the optimum the reference's ten restarts find (tests/test_oracle_pipeline.py checks it against the exhaustive minimum)."""
+    points = np.asarray(points)
+    best = None
+    for seed in range(len(points)):
+        centers = [points[seed]]
+        for _ in range(1, k):
+            d = np.min([np.linalg.norm(points - c, axis=1) for c in centers], axis=0)
+            centers.append(points[int(d.argmax())])
+        centers, inertia = _lloyd(points.astype(np.float64), np.stack(centers).astype(np.float64), iters)
+        if best is None or inertia < best[1] - 1e-12:
+            best = (centers, inertia)
+    return best[0]
 
 
 class ObjectExtraction:

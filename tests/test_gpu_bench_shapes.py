@@ -478,3 +478,53 @@ def test_stream_wait_stream_orders_work_across_streams():
     torch.cuda.synchronize()
     assert bad == 0
     assert ops.LIGHT_EVENTS
+
+
+def test_host_fed_stream_equals_the_resident_tick():
+    """configs[4] as a STREAM (reference harness: scripts/eval_model.py:274-293 feeds the model from the host; raw frames are 1280 x 720 uint8,
+    perception/datasets/video.py:83-100): raw camera frames start in pinned host memory, cross PCIe on a copy stream under the previous
+    tick (HostFrameFeed), are resized / cropped / normalised on the device, and the tick's results - the network's maps AND the triangulated
+    points - equal, bit for bit, those of the resident tick on the fp32 crops the ORACLE's pre-processing makes of the same frames; several
+    ticks in flight (different frames per tick) come out in order."""
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    from oracle import geometry as og
+    from oracle import pipeline as op
+    from oracle import preprocess as opre
+    p = og.load_calibration_params(CALIB)
+    offset = np.array([(511 / 720 * 1280 - 511.0) / 2.0, 0.0])
+    mk = lambda K, D: cu.FisheyeCamera(K, D, p["image_size"]).scale(511 / 720).cut(offset).scale(64 / 511)
+    stereo = cu.StereoCamera(mk(p["K"], p["D"]), mk(p["Kp"], p["Dp"]), p["T_RL"])
+    net = _net(torch.float16)
+    pipe = pp.StereoStreamPipeline(net, stereo, {"keypoint_config": [1, 3]}, capacity=4096, max_distance=1.5)
+    rng = np.random.default_rng(12)
+    ticks_u8 = [rng.integers(0, 256, (2, 720, 1280, 3), dtype=np.uint8) for _ in range(3)]
+    hosts = [torch.from_numpy(t).pin_memory() for t in ticks_u8]
+    # resident reference: the oracle's resize + centre crop + normalisation (fp32 NCHW 511 x 511), uploaded beforehand
+    crops = [torch.from_numpy(op.normalize_frames(np.stack([opre.resize_center_crop(f, 511) for f in t]))).cuda() for t in ticks_u8]
+    with torch.no_grad():
+        want_maps = [[m.clone() for m in net.deployed(c)] for c in crops]
+        want_ticks = [pipe.tick(c) for c in crops]
+        # maps: host-fed through the feed, tick by tick
+        feed = pp.HostFrameFeed(hosts[0].shape, hosts[0].dtype)
+        slot = feed.submit(hosts[0])
+        for i in range(3):
+            frames = feed.acquire(slot)
+            nxt = feed.submit(hosts[i + 1]) if i + 1 < 3 else None
+            got = net.deployed(frames)
+            feed.release(slot)
+            for g, w_ in zip(got, want_maps[i]):
+                assert torch.equal(g, w_), f"tick {i}: host-fed maps differ from the resident tick's"
+            slot = nxt
+        # the whole tick, streamed: results in order, equal to the resident ticks
+        got_ticks = list(pipe.stream(iter(hosts)))
+    assert len(got_ticks) == 3
+    for got, want in zip(got_ticks, want_ticks):
+        assert len(got) == len(want) == 1
+        for k in want[0]:
+            assert np.array_equal(got[0][k], want[0][k])
+    # a tensor of another shape, or one that already lives on the device, is refused by the feed
+    with pytest.raises(pp.OkpError):
+        feed.submit(hosts[0][:1])
+    with pytest.raises(pp.OkpError):
+        feed.submit(hosts[0].cuda())

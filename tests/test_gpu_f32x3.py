@@ -475,7 +475,9 @@ def test_audit_frames_falls_back_to_float32x3_on_unit_gain_weights():
     # a 16-bit configuration trips it as well; an fp32-grade one is not audited at all
     with pytest.warns(RuntimeWarning):
         assert pp.load_keypoint_net(sd, compute_dtype=torch.bfloat16, audit_frames=frames).configuration() == ops.F32X3
-    assert pp.load_keypoint_net(sd, compute_dtype=ops.F32X3, audit_frames=frames).audit["checked"] is False
+    x3 = pp.load_keypoint_net(sd, compute_dtype=ops.F32X3, audit_frames=frames)
+    assert x3.audit["checked"] and x3.audit["report"] == {"range_ok": True} and not x3.audit["fell_back"] and x3.audit["frames_source"] == "caller"
+    assert pp.load_keypoint_net(sd, compute_dtype=torch.float32, audit_frames=frames).audit["checked"] is False
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 33, 33), (2, 64, 96), (1, 511, 511), (3, 47, 130)])
@@ -554,7 +556,8 @@ def test_float32mix_is_audited_by_default_when_loaded():
     sd = {k: v.clone() for k, v in onet.state_dict().items()}
     with pytest.warns(RuntimeWarning, match="falling back to float32x3"):
         net = pp.load_keypoint_net(sd, compute_dtype=ops.F32MIX)
-    assert net.configuration() == ops.F32X3 and net.audit["checked"] and net.audit["fell_back"] and net.audit["frames"] == 2
+    assert net.configuration() == ops.F32X3 and net.audit["checked"] and net.audit["fell_back"]
+    assert net.audit["frames"] == net.audit["batch"] == pp.AUDIT_BATCH and net.audit["frames_source"] == "synthetic"      # (two synthetic frames at the deployment's kernels' batch)
     case = cases.NET_CASES["valve_k3"]
     vals = synth.fill_state_dict({k: tuple(v.shape) for k, v in onet.state_dict().items()}, seed=case["weight_seed"])
     own = {k: torch.from_numpy(np.array(v)) for k, v in vals.items()}

@@ -290,7 +290,7 @@ def test_batch64_properties():
 
 def test_device_grouping_matches_oracle_on_a_batch():
     """okp_group_objects on 64 multi-object frames vs the oracle's ObjectExtraction, frame by frame; the k-means
-    branch (more votes than configured for a multi-instance type) falls back to the host and is compared as a set."""
+    branch (more votes than configured for a multi-instance type) is the device reduction and is compared as a set."""
     from object_keypoints_amd import synth
     from object_keypoints_amd.perception import pipeline as pp
     from object_keypoints_amd.perception.utils import camera_utils as cu
@@ -322,6 +322,66 @@ def test_device_grouping_matches_oracle_on_a_batch():
                     assert np.abs(np.sort(a, axis=0) - np.sort(b, axis=0)).max() < 1e-4
             checked += 1
     assert checked > 64
+
+
+def test_device_kmeans_reduction_on_double_detections():
+    """64 valve frames ([1, 3]) in which every instance of the three-instance type is detected TWICE: the object receives six votes for
+    three instances, the case the reference reduces with an unseeded sklearn KMeans (pipeline.py:143-148).  okp_group_objects reduces
+    them on the device (deterministic Lloyd iteration); BatchedKeypointPipeline.objects() never reaches scikit-learn, and the centres are
+    the oracle's k-means centres as a set, their 3D points the oracle's (DetectionToPoint on the centres), launch after launch the same bits."""
+    import sys
+    from object_keypoints_amd import synth
+    from object_keypoints_amd.perception import pipeline as pp
+    from object_keypoints_amd.perception.utils import camera_utils as cu
+    cfg = {"keypoint_config": [1, 3]}
+    scenes = [synth.add_double_detections(synth.bump_scene([1, 3], n_objects=1 + (i % 8 == 7), seed=47, index=i, max_radius=18.0 if i % 8 != 7 else 9.0), 2,
+                                          offset=(5.0, 3.0)) for i in range(64)]
+    to = lambda key: torch.from_numpy(np.stack([s[key] for s in scenes])).cuda()
+    cam_o = op.eval_camera(CALIB)
+    batched = pp.BatchedKeypointPipeline(None, cfg, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size))
+    out = batched.postprocess_device(to("heat"), to("depth"), to("centers"))
+    again = batched.postprocess_device(to("heat"), to("depth"), to("centers"))
+    assert torch.equal(torch.nan_to_num(out["reduced"], nan=-1.0), torch.nan_to_num(again["reduced"], nan=-1.0))
+    assert not bool(out["overflow"])
+    opipe = op.ObjectKeypointPipeline([64, 64], None, cfg)
+    opipe.reset(cam_o)
+    votes = out["n_votes"].cpu().numpy()
+    reduced = out["reduced"].cpu().numpy()
+    banned = sys.modules.get("sklearn")
+    sys.modules["sklearn"] = None                       # importing scikit-learn inside objects() would now raise ImportError
+    try:
+        got_all = [batched.objects(out, n) for n in range(64)]
+    finally:
+        if banned is not None:
+            sys.modules["sklearn"] = banned
+        else:
+            del sys.modules["sklearn"]
+    n_reduced = 0
+    for n in range(64):
+        want = opipe(scenes[n]["heat"][None], scenes[n]["depth"][None], scenes[n]["centers"][None])
+        got = got_all[n]
+        assert len(got) == len(want)
+        for o, (g, w_) in enumerate(zip(got, want)):
+            # the reduction ran exactly where an object has more votes than instances, and nowhere else
+            for i, c in enumerate(cfg["keypoint_config"]):
+                ran = not np.isnan(reduced[n, o, i, 0, 0])
+                assert ran == (c > 1 and votes[n, o, i] > c)
+                n_reduced += ran
+            for a, b in zip(g["keypoints"], w_["keypoints"]):
+                a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+                assert a.shape == b.shape
+                if a.size:
+                    d = np.linalg.norm(a[:, None, :] - b[None, :, :], axis=2)
+                    assert d.min(axis=1).max() < 1e-4 and d.min(axis=0).max() < 1e-4
+            for a, b in zip(g["p_C"], w_["p_C"]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert np.abs(np.sort(a, axis=0) - np.sort(b, axis=0)).max() < 1e-4
+    assert n_reduced >= 40
+    # a type with more instances than max_per_type cannot be represented: refused, not truncated
+    small = pp.BatchedKeypointPipeline(None, cfg, cu.FisheyeCamera(cam_o.K, cam_o.D, cam_o.image_size), max_per_type=2)
+    with pytest.raises(pp.OkpError):
+        small.objects(small.postprocess_device(to("heat")[:1], to("depth")[:1], to("centers")[:1]), 0)
 
 
 def test_association_component_matches_oracle_and_reference_contract(known):

@@ -514,21 +514,24 @@ def test_mixed_plan_loaded_without_an_audit_says_so():
     from object_keypoints_amd.perception import pipeline as pp
 
     class Stub:
-        def __init__(self, mixed):
-            self.mixed = mixed
+        def __init__(self, mixed, split=True):
+            self.mixed, self.mfma_split = mixed, split
 
         def configuration(self):
-            return "float32mix" if self.mixed else "float32x3"
+            return "float32mix" if self.mixed else ("float32x3" if self.mfma_split else "float32")
 
     with pytest.warns(RuntimeWarning, match="UNVERIFIED on these weights"):
         assert pp._audited(Stub(True), None, pp.HEAT_BAR).mixed
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)
         pp._audited(Stub(False), None, pp.HEAT_BAR)
-        pp._audited(Stub(False), pp.AUDIT_AUTO, pp.HEAT_BAR)          # nothing mixed: nothing to audit, no device touched
+        pp._audited(Stub(False, split=False), pp.AUDIT_AUTO, pp.HEAT_BAR)          # no split products: nothing to audit, no device touched
     with pytest.raises(pp.OkpError):
         pp._audited(Stub(True), "sometimes", pp.HEAT_BAR)
     assert inspect.signature(pp.load_keypoint_net).parameters["audit_frames"].default == pp.AUDIT_AUTO
+    assert inspect.signature(pp.load_keypoint_net).parameters["on_overflow"].default == "raise"
+    with pytest.raises(pp.OkpError):
+        pp.load_keypoint_net({}, on_overflow="sometimes", device="cpu")
 
 
 def test_bench_parity_fields_report_point_error_quantiles(tmp_path):
@@ -556,6 +559,11 @@ def test_bench_parity_fields_report_point_error_quantiles(tmp_path):
     assert len(idx) >= 2
     assert abs(got["p_C_err_m"] - 1.5) < 1e-9 and st["max"] == got["p_C_err_m"] and st["n"] == len(idx)
     assert st["n_over_1e-4"] == 1 and (st["median"] < 1e-9 or len(idx) == 2) and got["meets"]["p_C_1e-4_m"] is False and got["meets"]["peaks_identical"]
+    # no peak matched: nothing was compared - zero points, null statistics, and the 3D bar is not "met" on a made-up sample
+    empty = dict(sample, count=np.array([[0]]))
+    got0 = bench.parity_fields(empty, {"heat": heat, "depth": depth}, cal)
+    assert got0["p_C_points"] == 0 and got0["p_C_err_m"] is None and got0["p_C_err_m_stats"]["n"] == 0 and got0["p_C_err_m_stats"]["median"] is None
+    assert got0["meets"]["p_C_1e-4_m"] is False and not got0["meets"]["peaks_identical"]
 
 
 @pytest.mark.parametrize("config,n_objects", [([1, 1, 1], 4), ([1, 3], 2), ([1, 3], 1)])

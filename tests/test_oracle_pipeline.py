@@ -205,3 +205,38 @@ def test_radtan_undistort_inverts_projection():
     flat = og.RadTanPinholeCamera(K, np.zeros(4), [480, 640])
     assert np.abs(flat.undistort(px) - px).max() < 1e-12
     assert cam.undistort(px.astype(np.float32)).dtype == np.float32
+
+
+def test_oracle_kmeans_finds_the_exhaustive_minimum_on_double_detections():
+    """The k-means branch (reference pipeline.py:143-148: unseeded sklearn KMeans, ten restarts, least inertia) is reproducible as an
+    optimum only: on scenes where every instance of the three-instance type is detected twice, the oracle's deterministic stand-in reaches
+    the inertia of the exhaustive minimum over all assignments, and sklearn's own result is the same set of centres."""
+    import itertools
+    from object_keypoints_amd import synth
+    from oracle import pipeline as op
+    from sklearn import cluster
+    cfg = {"keypoint_config": [1, 3]}
+    ex = op.KeypointExtractionComponent(cfg, [64, 64])
+    key = lambda a: sorted(map(tuple, np.round(np.asarray(a, dtype=np.float64), 3).tolist()))
+    checked = 0
+    for i in range(24):
+        s = synth.add_double_detections(synth.bump_scene([1, 3], n_objects=1, seed=47, index=i, max_radius=18.0), 2, offset=(5.0, 3.0))
+        pts, _ = ex(s["heat"][None])
+        P = np.stack(pts[0][2]).astype(np.float64)
+        if len(P) <= 3 or len(P) > 7:
+            continue
+        best = None
+        for a in itertools.product(range(3), repeat=len(P)):
+            a = np.array(a)
+            if len(set(a.tolist())) < 3:
+                continue
+            c = np.stack([P[a == t].mean(axis=0) for t in range(3)])
+            inertia = float(((P - c[a]) ** 2).sum())
+            if best is None or inertia < best[0] - 1e-12:
+                best = (inertia, c)
+        got = op._kmeans(P.astype(np.float32), 3)
+        assert key(got) == key(best[1])
+        sk = cluster.KMeans(init="random", n_clusters=3, n_init=10, random_state=i).fit(P.astype(np.float32)).cluster_centers_
+        assert key(sk) == key(best[1])
+        checked += 1
+    assert checked >= 12
