@@ -43,7 +43,14 @@ constexpr int SP = 128;                          // squeeze-tile rows in LDS
 constexpr int PBI = 6;                           // interior pixel blocks of 16 (IP <= 96)
 constexpr int NST = 4;                           // x ring stages
 constexpr int MAXIH = 6;                         // interior rows per tile (depth-wise phase keeps a column's residuals in registers)
-constexpr int XST = SP * 64;                     // bytes per stage
+// bytes per ring stage.  +64: a depth-wise thread takes its skip values from FOUR stages of one ring row (RING_SKIP: stage = channel group / 4);
+// with stages a multiple of 256 bytes apart those four 64-byte pieces sit in the same banks (4-way conflict), 64 bytes further each they cover
+// the 64 banks once
+#ifdef OKP_F2_NO_REMAP
+constexpr int XST = SP * 64;
+#else
+constexpr int XST = SP * 64 + 64;
+#endif
 
 template <int MID> struct FireLds {
   static constexpr int OFF_S = 0;                         // [128][MID x 2 B] squeeze tile, 16-B chunks XOR-swizzled by the row
@@ -99,12 +106,25 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   constexpr int DWB = 1;
 #else
   constexpr bool RES = false;
+#ifdef OKP_F2_RESIDENT_WA
+  constexpr int DWB = (CIN == 256 && MID == 128) ? OKP_F2_RESIDENT_WA : 1;
+#else
   constexpr int DWB = (CIN == 256 && MID == 128) ? 4 : 1;   // (the other instances have no registers to spare: batching spills there)
+#endif
 #endif
   // Wider inputs stream the squeeze weights.  With >= 192 squeeze channels (one workgroup per CU, LDS to spare) they go through a
   // per-wave LDS ring of DW k-steps filled by LDS-DMA (fragment order: 1 KiB per instruction, read back by the lane that needs it -
   // no barrier, no registers): DW - 1 steps in flight cover the 2-3 us a weight load takes to return under load (hot or cold in L2
   // alike), where the three register sets of the 128-channel instance (two workgroups per CU, no LDS left) cover 2 steps.
+  // Expand weights: per tile they were requested behind the squeeze GEMM and waited for in front of the expand GEMM - a weight load takes
+  // 2-3 us to return under load, most of the expand phase's 5.3 k clocks (profiles/r05g_fire2_stamps.txt: 48 MFMAs = 768 clocks of pipe).
+  // OKP_F2_RESIDENT_WA: the 256 -> 128 instance keeps them in registers for the whole kernel (32 per lane) and gives the depth-wise phase
+  // smaller read batches in exchange.
+#ifdef OKP_F2_RESIDENT_WA
+  constexpr bool RESWA = CIN == 256 && MID == 128;
+#else
+  constexpr bool RESWA = false;
+#endif
   constexpr bool WRING = !RES && MID >= 192;
   constexpr int DW = !WRING ? 0 : MID == 192 ? 5 : 3;
   constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
@@ -160,6 +180,13 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     for (int ks = 0; ks < KS1; ++ks) load_w1(ks, w1f[ks]);
   }
   const u32x4* const wa_lane = static_cast<const u32x4*>(p.wa) + (size_t)w * 2 * KS2 * 64 + lane;
+  u32x4 waf[2][KS2];                                          // expand weights: resident (RESWA) or re-fetched per tile
+  if constexpr (RESWA) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) waf[b][ks] = wa_lane[(size_t)(b * KS2 + ks) * 64];
+  }
   const f32x4 b1v0 = *reinterpret_cast<const f32x4*>(p.b1 + chq), b1v1 = *reinterpret_cast<const f32x4*>(p.b1 + chq + 4);
   const f32x4 bav0 = *reinterpret_cast<const f32x4*>(p.ba + chq), bav1 = *reinterpret_cast<const f32x4*>(p.ba + chq + 4);
   for (int i = tid; i < 10 * HALF; i += NT)
@@ -263,9 +290,21 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     // values out of the tile loop costs more registers than recomputing them (a multiply-high each)
     int qt = q, tidt = tid;
     asm volatile("" : "+v"(qt), "+v"(tidt));
+    // depth-wise phase: thread -> (8-channel group cg, column slot).  ds_read_b128 is served in groups of 16 lanes that are NOT 16 consecutive
+    // lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32 (docs/HARDWARE_NOTES.md) - so with cg = tid % 16 a group read half of one squeeze
+    // row and half of the next, whose swizzle keys (row & 15) differ in the high chunk bits one time in four: 2-way conflicts, 23 % of the
+    // kernel's LDS cycles (SQ_LDS_BANK_CONFLICT, profiles/r05v_sq_counters.json).  With 16 channel groups (MID = 128) the lanes of a hardware
+    // group are given ONE row: lane l of a half-wave belongs to group parity(l bits 2, 3, 4), and (l & 3) | ((l >> 1) & 12) numbers its lanes.
+#ifdef OKP_F2_NO_REMAP
+    const int dw_cg = tidt % CG, dw_slot = tidt / CG;
+#else
+    const int dw_l = tidt & 31;
+    const int dw_cg = CG == 16 ? ((dw_l & 3) | ((dw_l >> 1) & 12)) : tidt % CG;
+    const int dw_slot = CG == 16 ? 4 * (tidt >> 6) + 2 * ((tidt >> 5) & 1) + (((dw_l >> 2) ^ (dw_l >> 3) ^ (dw_l >> 4)) & 1) : tidt / CG;
+#endif
     // phase 2b residuals of column `ix` (thread = 8-channel group cg, column slot): one 16-byte load per output row
     auto load_col_residuals = [&](int ix, u32x4 (&rr)[MAXIH], uint32_t (&oo)[MAXIH]) {
-      const int cg = tidt % CG;
+      const int cg = dw_cg;
       const int ox = x0 + ix;
       const uint32_t pix = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + ox);
       uint32_t xo = pix * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u, oof = pix * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + cg * 8) * 2u;
@@ -343,12 +382,13 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     }
     F2_STAMP(1);
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
-    u32x4 waf[2][KS2];
+    if constexpr (!RESWA) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int ks = 0; ks < KS2; ++ks)
-        waf[b][ks] = wa_lane[(size_t)(b * KS2 + ks) * 64];
+        for (int ks = 0; ks < KS2; ++ks)
+          waf[b][ks] = wa_lane[(size_t)(b * KS2 + ks) * 64];
+    }
     // s -> LDS (zero outside the frame: the reference zero-pads the squeeze output)
     {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(smem + OFF_MASK);
@@ -434,7 +474,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
     // output rows that see it as tap row 2, 1, 0; depth-wise weights in registers for the phase.
     {
-      const int cg = tidt % CG;
+      const int cg = dw_cg;
       const float* const wl = reinterpret_cast<const float*>(smem + OFF_WD) + cg * 8;     // [tap][128] fp32, bias at tap 9
       float breg[8];
       {
@@ -443,7 +483,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         for (int e = 0; e < 4; ++e) { breg[e] = u0[e]; breg[4 + e] = u1[e]; }
       }
       bool prefetched = false;
-      for (int ix = tidt / CG; ix < ((p.IW + 15) & ~15); ix += 16) {       // uniform trip count: the prefetch sits inside
+      for (int ix = dw_slot; ix < ((p.IW + 15) & ~15); ix += 16) {       // uniform trip count: the prefetch sits inside
         // residuals of the whole column first, then the next tile's first ring steps (HBM): those land behind the
         // residuals, while the taps run
         load_col_residuals(ix, rr, oo);

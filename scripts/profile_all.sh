@@ -22,7 +22,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # (--no-probes / --no-cups: nothing but the warm-up and the timed steps runs under the profiler, so per-kernel averages hold those steps only)
-A="--dtype $dt --no-cpu-baseline --no-stream8 --no-cups --no-probes --extra-dtypes="
+A="--dtype $dt --no-cpu-baseline --no-stream8 --no-cups --no-host-fed --no-probes --extra-dtypes="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -- python3 $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 2 $A > $out/${p}bench_profiled.json 2> $out/${p}bench_profiled.err
 echo "trace pass rc=$?"
 stats=$(ls $out/raw/*/*kernel_stats.csv | head -1); trace=$(ls $out/raw/*/*kernel_trace.csv | head -1)
@@ -42,7 +42,7 @@ python3 scripts/pmc_traffic.py $out/fetch $out/write > $out/${p}pmc_hbm_traffic.
 python3 scripts/pmc_sq_bench.py $out/sqa $out/sqb $out/${p}pmc_hbm_traffic.json $out/${p}kernel_stats.csv > $out/${p}sq_counters.json
 rm -rf $out/fetch $out/write $out/sqa $out/sqb
 for f in pmc_hbm_traffic sq_counters; do
-  python3 -c "import json,sys,time; sys.path.insert(0,'.'); import bench; json.dump({'commit': '$commit', 'csrc_sha16': bench.csrc_sha16(), 'dtype': '$dt', 'collected_unix': int(time.time()), 'command': 'bench.py --dtype $dt --no-cpu-baseline --no-stream8 --no-cups --no-probes --extra-dtypes='}, open('$out/${p}$f.meta.json','w'))"
+  python3 -c "import json,sys,time; sys.path.insert(0,'.'); import bench; json.dump({'commit': '$commit', 'csrc_sha16': bench.csrc_sha16(), 'dtype': '$dt', 'collected_unix': int(time.time()), 'command': 'bench.py --dtype $dt --no-cpu-baseline --no-stream8 --no-cups --no-host-fed --no-probes --extra-dtypes='}, open('$out/${p}$f.meta.json','w'))"
 done
 tail -12 $out/${p}last_forward.txt
 head -24 $out/${p}sq_counters.json

@@ -437,6 +437,33 @@ def test_mixed_network_holds_the_heat_bar_on_many_frames():
     assert worst.max() <= _bounds()["f32mix"]["heat_max_any_frame"] and np.median(worst) <= 6e-4 and worst.min() >= 1e-4
 
 
+@pytest.mark.parametrize("config,bound", [("float32mix", "heat_max_any_frame"), ("float32x3", None)])
+def test_split_configurations_against_the_oracle_at_batch_64_and_batch_1(config, bound):
+    """The split configurations' bits depend on the batch size (the launch heuristic takes the patch-resident kernel - 16x16x32 MFMAs -
+    at batch 64 and the gather tiles - 32x32x16 - at batch 1: same products, another summation order), so the distance to the REFERENCE
+    is measured at both: frames 0, 21, 42, 63 of a 64-frame batch and the same four frames alone, against the oracle (= the reference,
+    tests/golden) on those frames.  float32mix: inside its any-frame bound (9e-4, below the 1e-3 heat bar) at both batch sizes;
+    float32x3: 2e-5 at both (the bar is 1e-3), and the two batch sizes agree with each other to summation noise."""
+    from object_keypoints_amd import ops, synth
+    from oracle import net as onet
+    case = cases.NET_CASES["valve_k3"]
+    net = _net(case, config)
+    picks = [0, 21, 42, 63]
+    frames = synth.frames(64, seed=7, start=300)
+    o = onet.load_synthetic(onet.KeypointNet(features=128, heatmaps_out=3), seed=case["weight_seed"])
+    want = onet.deployed_forward(o, torch.from_numpy(frames[picks]))[0]
+    x = torch.from_numpy(frames).cuda()
+    with torch.no_grad():
+        full = net.deployed(x)[0][picks].cpu()
+        alone = torch.cat([net.deployed(x[i:i + 1])[0] for i in picks]).cpu()
+    e64 = (full - want).abs().flatten(1).max(dim=1).values.numpy()
+    e1 = (alone - want).abs().flatten(1).max(dim=1).values.numpy()
+    print(config, "heat error vs the oracle, batch 64:", " ".join(f"{v:.1e}" for v in e64), "| batch 1:", " ".join(f"{v:.1e}" for v in e1))
+    limit = _bounds()["f32mix"][bound] if bound else 2e-5
+    assert e64.max() <= limit and e1.max() <= limit
+    assert float((full - alone).abs().max()) <= (5e-4 if config == "float32mix" else 2e-5)
+
+
 def test_audit_frames_falls_back_to_float32x3_on_unit_gain_weights():
     """load_keypoint_net(..., compute_dtype="float32mix", audit_frames=...): the mixed plan was derived on weights whose branches close
     with BatchNorm gains of 0.3; on the `torch-default` family of tests/precision/families.py (gamma 1 / beta 0, calibrated running
