@@ -88,9 +88,21 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
 #define F2_STAMP(i) do {} while (0)
 #endif
 
-template <typename T, int CIN, int MID, int STR>
+// DWM: the depth-wise branch on the MATRIX pipe (stride 1, interior tiles 16 pixels wide).  The kernel is bound by vector-ALU issue
+// (1 880 VALU instructions per wave and tile beside 176 MFMAs; the depth-wise block alone: 216 packed FMAs + 264 unpacking shifts / masks +
+// the epilogue = 716), while the matrix pipe idles three quarters of the time.  A depth-wise 3x3 is, per tap, a DIAGONAL 32 x 32 matrix
+// applied to the wave's 32 channels: with the channels-as-rows layout of the two GEMMs the B operand of tap (dy, dx) at pixel p is the very
+// fragment the expand GEMM reads, taken from squeeze row p + (dy - 1) SW + (dx - 1), and the A operand of (tap, block b) has ONE non-zero
+// element per lane - the tap's weight of the lane's own channel, at a lane-constant position - so it is built from one LDS dword and two
+// ANDs.  Nine K-steps of one MFMA per pixel block and accumulator block: 90 MFMAs, 21 fragment reads, no unpacking (the accumulators come
+// out as the expand GEMM's do: eight adjacent channels of a pixel per lane, one 16-byte store).  The tap weights are rounded to the
+// activation type T on this path (the VALU path multiplies by fp32 weights): one more rounding point of the 16-bit configurations, inside
+// their bounds (tests/precision/bounds.py); the products are exact in the fp32 accumulators either way.
+template <typename T, int CIN, int MID, int STR, bool DWM = false>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
   static_assert(STR == 1 || STR == 2, "stride of both branches");
+  static_assert(!DWM || STR == 1, "depth-wise branch on the matrix pipe: the stride-1 instances");
+  constexpr int DIH = 5;                           // DWM: interior rows per tile (7 squeeze rows of 18 pixels = 126 <= SP)
   constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
   constexpr int NT = 64 * NW;
   constexpr int HALF = MID;
@@ -189,8 +201,15 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   }
   const f32x4 b1v0 = *reinterpret_cast<const f32x4*>(p.b1 + chq), b1v1 = *reinterpret_cast<const f32x4*>(p.b1 + chq + 4);
   const f32x4 bav0 = *reinterpret_cast<const f32x4*>(p.ba + chq), bav1 = *reinterpret_cast<const f32x4*>(p.ba + chq + 4);
-  for (int i = tid; i < 10 * HALF; i += NT)
-    reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
+  for (int i = tid; i < 10 * HALF; i += NT) {
+    if constexpr (DWM) {
+      // [tap][channel]: the weight rounded to T, in the half of the dword its channel's parity selects (the A operand's element), bias as fp32
+      if (i < 9 * HALF) reinterpret_cast<uint32_t*>(smem + OFF_WD)[i] = (i & 1) ? okp_pack2<T>(0.f, p.wd[i]) : okp_pack2<T>(p.wd[i], 0.f);
+      else reinterpret_cast<float*>(smem + OFF_WD)[i] = p.bd[i - 9 * HALF];
+    } else {
+      reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
+    }
+  }
   if (tid < 16 * PBI) {
     const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
     // (the x table serves the skip connection: stride 1, where input and output geometry coincide)
@@ -471,6 +490,102 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     F2_STAMP(3);
 
     // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
+    if constexpr (DWM) {
+      // On the matrix pipe (see the kernel's head).  Lane (l16 = pixel column ix = row i of the A operand, q): channels chq .. chq + 7.
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
+      const bool full = y0 + p.IH <= p.Ho && x0 + p.IW <= p.Wo;
+      const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
+      const uint32_t ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + chq) * 2u;
+      u32x4 rr2[DIH];
+      uint32_t oo2[DIH];
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) {
+        const int ip = 16 * iy + l16t;
+        uint32_t orr = kInvalid, xr = kInvalid;
+        if (iy < p.IH) {
+          orr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + (96 + ip) * 4);
+          xr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + ip * 4);
+          if (!full && (y0 + iy >= p.Ho || x0 + l16t >= p.Wo)) { orr = kInvalid; xr = kInvalid; }
+        }
+        oo2[iy] = orr == kInvalid ? kInvalid : ob + orr;
+        rr2[iy] = u32x4{0u, 0u, 0u, 0u};
+        if (p.skip && iy < p.IH) {
+          if constexpr (RING_SKIP) {      // x[:, MID + chq ..] = k-step KS1/2 + w of the ring, chunk q of squeeze row (iy + 1, ix + 1)
+            const int row = (iy + 1) * p.SW + l16t + 1;
+            rr2[iy] = *reinterpret_cast<const u32x4*>(smem + OFF_X + ((KS1 / 2 + w) % NST) * XST + row * 64 + ((qt + 2 * (row >> 2)) & 3) * 16);
+          } else {
+            const uint32_t xb2 = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + chq) * 2u;
+            rr2[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xr == kInvalid ? kInvalid : xb2 + xr), 0, 0);
+          }
+        }
+      }
+      if constexpr (RING_SKIP) {
+        if (p.skip) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }   // every thread has its skip values: the ring is free
+      }
+      {
+        const int next = tile + gridDim.x;
+        if (next < p.n_tiles) {
+          tile_setup(next);                                  // (the validity bits are next read behind >= 8 barriers)
+          first_weights(w1f);
+#pragma unroll
+          for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+        }
+      }
+      const float* const bl = reinterpret_cast<const float*>(smem + OFF_WD) + 9 * HALF + chq;
+      const f32x4 bdv0 = *reinterpret_cast<const f32x4*>(bl), bdv1 = *reinterpret_cast<const f32x4*>(bl + 4);
+      f32x4 acd[DIH][2];
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) { acd[iy][0] = bdv0; acd[iy][1] = bdv1; }
+      // A operand of (tap, block b): lane (i = l16, q) is non-zero only where q == i >> 2, with the weight of channel chq + 4 b + (i & 3) in
+      // dword 2 b + ((i & 3) >> 1) (its half is already in the table's dword)
+      const uint32_t am = (qt == (l16t >> 2)) ? 0xffffffffu : 0u;
+      const uint32_t m_lo = (l16t & 2) ? 0u : am, m_hi = (l16t & 2) ? am : 0u;
+      const uint32_t wt_lane = (uint32_t)OFF_WD + (uint32_t)(chq + (l16t & 3)) * 4u;
+      const uint32_t cx = (uint32_t)(4 * w) + (uint32_t)qt;
+      // (all DIH + 2 squeeze rows are walked whatever the tile's height: rows beyond it hold stale - finite or not, it does not matter -
+      //  values of the LDS tile, and the accumulator rows they feed are never stored; no branch, so the reads run ahead of the MFMAs)
+      u32x4 a0[3], a1[3];                                     // A operands of the three dy taps of a column position: block 0 {lo, hi, 0, 0}, block 1 {0, 0, lo, hi}
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) { a0[dy] = u32x4{0u, 0u, 0u, 0u}; a1[dy] = u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const uint32_t v0 = *reinterpret_cast<const uint32_t*>(smem + wt_lane + ((dy * 3 + dx) * HALF) * 4);
+          const uint32_t v1 = *reinterpret_cast<const uint32_t*>(smem + wt_lane + ((dy * 3 + dx) * HALF + 4) * 4);
+          a0[dy][0] = v0 & m_lo; a0[dy][1] = v0 & m_hi;
+          a1[dy][2] = v1 & m_lo; a1[dy][3] = v1 & m_hi;
+        }
+        u32x4 bf[DIH + 2];
+#pragma unroll
+        for (int r = 0; r < DIH + 2; ++r) {
+          const uint32_t sp = (uint32_t)(r * p.SW + dx) + (uint32_t)l16t;
+          bf[r] = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cx ^ (sp & SWM)) << 4));
+        }
+#pragma unroll
+        for (int r = 0; r < DIH + 2; ++r) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int iy = r - dy;
+            if (iy >= 0 && iy < DIH) {
+              acd[iy][0] = H16<T>::mfma16(a0[dy], bf[r], acd[iy][0]);
+              acd[iy][1] = H16<T>::mfma16(a1[dy], bf[r], acd[iy][1]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) {
+        u32x4 o;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          o[2 * b] = okp_pack2<T>(fmaxf(acd[iy][b][0] + H16<T>::lo(rr2[iy][2 * b]), 0.f), fmaxf(acd[iy][b][1] + H16<T>::hi(rr2[iy][2 * b]), 0.f));
+          o[2 * b + 1] = okp_pack2<T>(fmaxf(acd[iy][b][2] + H16<T>::lo(rr2[iy][2 * b + 1]), 0.f), fmaxf(acd[iy][b][3] + H16<T>::hi(rr2[iy][2 * b + 1]), 0.f));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo2[iy], 0, 0);
+      }
+    } else
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
     // output rows that see it as tap row 2, 1, 0; depth-wise weights in registers for the phase.
     {
@@ -613,6 +728,15 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
       const long score = ty * tx * 4096 - iw;
       if (best < 0 || score < best) { best = score; p.IH = ih; p.IW = iw; p.SH = sh; p.SW = sw; p.tiles_y = (int)ty; p.tiles_x = (int)tx; }
     }
+  // the 256 -> 128 stride-1 instance on maps whose width is a multiple of 16: tiles of 5 x 16 interior pixels, depth-wise branch on the matrix
+  // pipe (okp_fire2_kernel<..., DWM>; OKP_F2_DWM=0 keeps the vector-ALU form for A/B)
+  static const bool dwm_on = [] { const char* e = getenv("OKP_F2_DWM"); return !(e && e[0] == '0'); }();
+  static const int dwm_mid = [] { const char* e = getenv("OKP_F2_DWM_MID"); return e ? atoi(e) : 256; }();      // (A/B: largest squeeze width that takes it)
+  const bool dwm = dwm_on && stride == 1 && p.Wo % 16 == 0 && mid <= dwm_mid;
+  if (dwm) {
+    p.IH = p.Ho < 5 ? p.Ho : 5; p.IW = 16; p.SH = p.IH + 2; p.SW = 18;
+    p.tiles_y = (p.Ho + p.IH - 1) / p.IH; p.tiles_x = p.Wo / 16;
+  }
   p.IP = p.IH * p.IW;
   p.RPR = (p.IW + 3) / 4;
   const long tiles = (long)p.N * p.tiles_y * p.tiles_x;
@@ -650,7 +774,12 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
   } } print_at_exit{p, mid, stream, dbg};
 #endif
   if (stride == 1) {
-    if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 1>), grid, block, 0, stream, p);
+    if (dwm && cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 1, true>), grid, block, 0, stream, p);
+    else if (dwm && cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 1, true>), grid, block, 0, stream, p);
+    else if (dwm && cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 256, 1, true>), grid, block, 0, stream, p);
+    else if (dwm && cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 128, 1, true>), grid, block, 0, stream, p);
+    else if (dwm && cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 192, 1, true>), grid, block, 0, stream, p);
+    else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 1>), grid, block, 0, stream, p);
     else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 1>), grid, block, 0, stream, p);
     else if (cin == 512 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 256, 1>), grid, block, 0, stream, p);
     else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 128, 1>), grid, block, 0, stream, p);

@@ -250,11 +250,14 @@ def load_cornernet_backbone(net, pretrained):
 class InferenceComponent:
     name = "inference"
 
-    def __init__(self, model, cuda=True, compute_dtype=torch.float32):
+    def __init__(self, model, cuda=True, compute_dtype=torch.float32, on_overflow="float32"):
+        """on_overflow (split-product compute dtypes only): the reference's fp32 model returns numbers for any input; the drop-in does too -
+        a pass whose activations leave the fp16 range is re-run with the exact float32 kernels ("float32", with a RuntimeWarning the first
+        time) - unless the caller prefers an OkpError ("raise")."""
         if not cuda:
             raise OkpError("InferenceComponent(cuda=False): this build has no CPU path (the CPU restatement is oracle/, test-only)")
         self.cuda = cuda
-        self.model = load_keypoint_net(model, compute_dtype)
+        self.model = load_keypoint_net(model, compute_dtype, on_overflow=on_overflow)
 
     def __call__(self, frames):
         frames = frames.to(_device())
@@ -443,8 +446,9 @@ class ObjectKeypointPipeline:
 class LearnedKeypointTrackingPipeline(ObjectKeypointPipeline):
     def __init__(self, model, cuda=True, *args, **kwargs):
         compute_dtype = kwargs.pop("compute_dtype", torch.float32)
+        on_overflow = kwargs.pop("on_overflow", "float32")
         super().__init__(*args, **kwargs)
-        self.inference = InferenceComponent(model, cuda, compute_dtype=compute_dtype)
+        self.inference = InferenceComponent(model, cuda, compute_dtype=compute_dtype, on_overflow=on_overflow)
 
     def __call__(self, frame):
         heatmap, depth, centers = self.inference(frame)
