@@ -129,7 +129,11 @@ class EmuNet:
         scale2 = sd[f"{name}.bn2.weight"].double() / torch.sqrt(sd[f"{name}.bn2.running_var"].double() + 1e-5)
         shift2 = (sd[f"{name}.bn2.bias"].double() - sd[f"{name}.bn2.running_mean"].double() * scale2).float()
         wa = (sd[f"{name}.conv_1x1.weight"].double() * scale2[:half].view(-1, 1, 1, 1)).float()
-        wd = (sd[f"{name}.conv_3x3.weight"].double() * scale2[half:].view(-1, 1, 1, 1)).float()     # depth-wise: fp32 weights on the vector ALUs
+        wd = (sd[f"{name}.conv_3x3.weight"].double() * scale2[half:].view(-1, 1, 1, 1)).float()     # depth-wise: fp32 weights on the vector ALUs ...
+        if stride == 1 and s.shape[3] % 16 == 0:
+            # ... except where the one-launch kernel runs the branch on the matrix pipe (okp_fire2_kernel<..., DWM>: stride 1, maps 16 k pixels
+            # wide - the 64 x 64, 32 x 32 and 16 x 16 levels): there the tap weights are rounded to the activation type (round 6)
+            wd = p.weight(f"{name}.conv_3x3", wd)
         ya = p.conv(s, p.weight(f"{name}.conv_1x1", wa), shift2[:half], stride=stride)
         yd = F.conv2d(s, wd, shift2[half:], stride=stride, padding=1, groups=s.shape[1])
         y = torch.cat([ya, yd], dim=1)
