@@ -32,6 +32,15 @@
 
 #include "okp_internal.h"
 
+// Timing ablations (wrong results, right timing; experiment builds only): OKP_F2_ABL_NOSTORE drops every output store, OKP_F2_ABL_NOX the
+// x requests of every tile but a workgroup's first, OKP_F2_ABL_NOSKIP the skip values, OKP_F2_ABL_NODW the depth-wise branch's MFMAs and reads,
+// OKP_F2_ABL_NOWEIGHTS the weight stream.
+#ifdef OKP_F2_ABL_NOSTORE
+#define F2_STORE(v, rs, off) do { if ((off) == 0x7ffffff0u) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(off), 0, 0); } while (0)
+#else
+#define F2_STORE(v, rs, off) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(off), 0, 0)
+#endif
+
 
 namespace {
 
@@ -60,6 +69,26 @@ template <int MID> struct FireLds {
   static constexpr int OFF_MASK = OFF_TAB + 2 * 96 * 4;   // 4 x u32 validity bits of the squeeze pixels
   static constexpr int BYTES = OFF_MASK + 16;
 };
+
+// relu(acc + residual) of a lane's eight adjacent channels, rounded to T: packed fp32 adds, round, then the ReLU on the packed 16-bit words
+// (bf16 / fp16 read as int16 keep the sign and the order of the positive values: one v_pk_max_i16 per dword instead of a v_max_f32 per value;
+// relu(round(x)) == round(relu(x)), so the bits are those of the unpack / add / max / pack form for every non-NaN value)
+template <typename T>
+__device__ __forceinline__ u32x4 relu_add_pack8(const f32x4& a0, const f32x4& a1, const u32x4& r) {
+  u32x4 v;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const f32x4& a = b ? a1 : a0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 s2 = f32x2{a[2 * h], a[2 * h + 1]} + f32x2{H16<T>::lo(r[2 * b + h]), H16<T>::hi(r[2 * b + h])};
+      v[2 * b + h] = okp_pack2<T>(s2[0], s2[1]);
+    }
+  }
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
 
 __device__ __forceinline__ int fastdiv(int x, const OkpFastDiv& f) {
   return f.mul ? (int)(__umulhi((uint32_t)x, f.mul) >> f.shift) : x;
@@ -166,6 +195,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   // wave (the packed plan layout would give 16 separate 64-byte segments per load: measured 4x slower to stream)
   const u32x4* const w1_lane = static_cast<const u32x4*>(p.w1) + (size_t)w * 2 * KS1 * 64 + lane;
   auto load_w1 = [&](int ks, u32x4 (&dst)[2]) {
+#ifdef OKP_F2_ABL_NOWEIGHTS        // timing ablation (wrong results): every k-step multiplies with the weights of k-step 0, requested once per tile
+    if (ks != 0) { dst[0] = u32x4{0x3c003c00u, 0u, 0u, 0u}; dst[1] = dst[0]; return; }
+#endif
 #pragma unroll
     for (int b = 0; b < 2; ++b) dst[b] = w1_lane[(size_t)(b * KS1 + ks) * 64];
   };
@@ -282,7 +314,13 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
     }
   };
+#ifdef OKP_F2_ABL_NOX
+  bool abl_started = false;
+#endif
   auto issue_x = [&](int ks, int stage) {
+#ifdef OKP_F2_ABL_NOX
+    if (abl_started) return;
+#endif
 #pragma unroll
     for (int i = 0; i < NDM; ++i)
       if (UNI || i < nd)
@@ -400,13 +438,20 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           acc[pb][b] = H16<T>::mfma16(WRING ? wr[b] : w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
     }
     F2_STAMP(1);
+#ifdef OKP_F2_ABL_NOX
+    abl_started = true;
+#endif
     // expand weights for this tile (dead after phase 2a): issue now, consumed after the barrier
     if constexpr (!RESWA) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int ks = 0; ks < KS2; ++ks)
+        for (int ks = 0; ks < KS2; ++ks) {
+#ifdef OKP_F2_ABL_NOWEIGHTS
+          if (b + ks != 0) { waf[b][ks] = u32x4{0x3c003c00u, 0u, 0u, 0u}; continue; }
+#endif
           waf[b][ks] = wa_lane[(size_t)(b * KS2 + ks) * 64];
+        }
     }
     // s -> LDS (zero outside the frame: the reference zero-pads the squeeze output)
     {
@@ -421,9 +466,10 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         const bool ok = (mq[pb >> 1] >> (16 * (pb & 1))) & 1u;
         u32x4 v;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          v[2 * b] = okp_pack2<T>(ok ? acc[pb][b][0] : 0.f, ok ? acc[pb][b][1] : 0.f);
-          v[2 * b + 1] = okp_pack2<T>(ok ? acc[pb][b][2] : 0.f, ok ? acc[pb][b][3] : 0.f);
+        for (int b = 0; b < 2; ++b) {          // (the zero of a pixel outside the frame is selected on the packed words: four selects, not eight)
+          const uint32_t p0 = okp_pack2<T>(acc[pb][b][0], acc[pb][b][1]), p1 = okp_pack2<T>(acc[pb][b][2], acc[pb][b][3]);
+          v[2 * b] = ok ? p0 : 0u;
+          v[2 * b + 1] = ok ? p1 : 0u;
         }
         *reinterpret_cast<u32x4*>(smem + s_dst + pb * 16 * (MID * 2)) = v;
       }
@@ -476,13 +522,8 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
       for (int pb = 0; pb < PBI; ++pb) {
         if (16 * pb < p.IP) {
-          u32x4 v;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            v[2 * b] = okp_pack2<T>(fmaxf(ac2[pb][b][0] + H16<T>::lo(r_raw[pb][2 * b]), 0.f), fmaxf(ac2[pb][b][1] + H16<T>::hi(r_raw[pb][2 * b]), 0.f));
-            v[2 * b + 1] = okp_pack2<T>(fmaxf(ac2[pb][b][2] + H16<T>::lo(r_raw[pb][2 * b + 1]), 0.f), fmaxf(ac2[pb][b][3] + H16<T>::hi(r_raw[pb][2 * b + 1]), 0.f));
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)o_off[pb], 0, 0);
+          const u32x4 v = relu_add_pack8<T>(ac2[pb][0], ac2[pb][1], r_raw[pb]);
+          F2_STORE(v, rs_o, o_off[pb]);
         }
       }
     }
@@ -543,6 +584,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       const uint32_t m_lo = (l16t & 2) ? 0u : am, m_hi = (l16t & 2) ? am : 0u;
       const uint32_t wt_lane = (uint32_t)OFF_WD + (uint32_t)(chq + (l16t & 3)) * 4u;
       const uint32_t cx = (uint32_t)(4 * w) + (uint32_t)qt;
+#ifndef OKP_F2_ABL_NODW
       // (all DIH + 2 squeeze rows are walked whatever the tile's height: rows beyond it hold stale - finite or not, it does not matter -
       //  values of the LDS tile, and the accumulator rows they feed are never stored; no branch, so the reads run ahead of the MFMAs)
       u32x4 a0[3], a1[3];                                     // A operands of the three dy taps of a column position: block 0 {lo, hi, 0, 0}, block 1 {0, 0, lo, hi}
@@ -575,15 +617,11 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
           }
         }
       }
+#endif
 #pragma unroll
       for (int iy = 0; iy < DIH; ++iy) {
-        u32x4 o;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          o[2 * b] = okp_pack2<T>(fmaxf(acd[iy][b][0] + H16<T>::lo(rr2[iy][2 * b]), 0.f), fmaxf(acd[iy][b][1] + H16<T>::hi(rr2[iy][2 * b]), 0.f));
-          o[2 * b + 1] = okp_pack2<T>(fmaxf(acd[iy][b][2] + H16<T>::lo(rr2[iy][2 * b + 1]), 0.f), fmaxf(acd[iy][b][3] + H16<T>::hi(rr2[iy][2 * b + 1]), 0.f));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo2[iy], 0, 0);
+        const u32x4 o = relu_add_pack8<T>(acd[iy][0], acd[iy][1], rr2[iy]);
+        F2_STORE(o, rs_o, oo2[iy]);
       }
     } else
     // thread = (8-channel group cg, column slot): it walks DOWN its column, each new squeeze row feeding the three
@@ -693,7 +731,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
             const float hi = fmaxf(v[iy][e][1] + H16<T>::hi(rr[iy][e]), 0.f);
             o[e] = okp_pack2<T>(lo, hi);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, (int)oo[iy], 0, 0);
+          F2_STORE(o, rs_o, oo[iy]);
         }
       }
     }
@@ -845,7 +883,7 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.x = a->x.data; q.x_bytes = (uint32_t)a->x.bytes; q.H = a->x.h; q.W = a->x.w; q.x_ps = a->x.pix_stride;
     q.out = a->out.data; q.out_bytes = (uint32_t)a->out.bytes; q.Ho = ho; q.Wo = wo; q.out_ps = a->out.pix_stride;
     q.N = a->n; q.skip = a->skip;
-#ifdef OKP_FIRE_STAMPS
+#if defined(OKP_FIRE_STAMPS) || defined(OKP_F2_ABL_NOSKIP)
     if (getenv("OKP_FIRE_NOSKIP")) q.skip = 0;       // timing ablation of the debug build (wrong results): no skip values are requested
 #endif
     if (int e = okp_ensure_frags(squeeze, (hipStream_t)stream)) return e;
