@@ -766,7 +766,7 @@ def run_host_fed(ctx, name="bf16", steps=12, warmup=3):
     return res
 
 
-FRAME_BATCHES = 4      # different resident frame batches the timed steps walk through
+FRAME_BATCHES = int(os.environ.get("OKP_BENCH_FRAME_BATCHES", "4"))      # different resident frame batches the timed steps walk through (1: A/B against one re-read batch)
 
 
 SAMPLE_CAP = 1024      # peak slots per map of the error sample (random-weight networks give flat maps: ~100 peaks each)

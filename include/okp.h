@@ -31,7 +31,8 @@ extern "C" {
                                  5: OKP_F32X3 in okp_stem_create_dtype / okp_stem_forward_nchw (fp32 NHWC output) and okp_fire_forward; tile 13 for OKP_F32X3 plans; tile 14
                                  6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs
                                  7: okp_conv_patch_applies; okp_group_objects: `reduced_dev` (device k-means reduction of surplus votes);
-                                    okp_conv_set_range_flag / okp_stem_set_range_flag (fp16-range guard of split-product plans), okp_capacity_overflow: `range_flag_dev` */
+                                    okp_conv_set_range_flag / okp_stem_set_range_flag (fp16-range guard of split-product plans), `range_flag_dev` of
+                                    okp_capacity_overflow, okp_cast and okp_add_f16_f32 */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -94,9 +95,11 @@ okp_conv* okp_conv_create_x3(int n_src, const int32_t* cin, const int32_t* conv_
 /* OKP_F32X3 range guard (ABI 7).  A split-product plan halves its fp32 operands into fp16: a value beyond +-65504 (or a non-finite one)
  * becomes (inf, -inf), its products NaN, and the next ReLU turns the NaN into 0 - silently, where the reference's fp32 arithmetic
  * (py_utils/utils.py:143-156) returns numbers.  With a flag attached, every launch of the plan (okp_conv_forward on any tile, and
- * okp_fire_forward / okp_heads_forward through their squeeze / first-layer plan) ORs 1 into *flag_dev when one of its RESULTS - a value
- * the next split-product layer will halve, including the squeeze tile of the one-launch fire module and the hidden layer of the heads -
- * is outside the fp16 range or not finite; okp_stem_set_range_flag does the same for the stem and also checks the frames it reads.  The
+ * okp_fire_forward / okp_heads_forward through their squeeze / first-layer plan) ORs 1 into *flag_dev when the magnitude of one of its
+ * RESULTS - a value the next split-product layer will halve, including the squeeze tile of the one-launch fire module and the hidden layer
+ * of the heads - passes 65504 (a running maximum; with every input in range no NaN can arise, so infinity is the only way out);
+ * okp_stem_set_range_flag does the same for the stem and checks the frames it reads exactly (NaN included), as okp_cast / okp_add_f16_f32
+ * do for the fp16 data they hand to split-product consumers.  The
  * flag is never cleared by the library: the caller zeroes it before a pass and reads it after (or hands it to okp_capacity_overflow).
  * flag_dev: DEVICE int32, NULL = off (the default).  Set once, before the plan is used from several threads or captured in a graph. */
 int okp_conv_set_range_flag(okp_conv* plan, int32_t* flag_dev);
@@ -215,11 +218,13 @@ int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t conv_stride,
 /* Element type conversion of a contiguous tensor of `count` elements (OKP_F32 <-> OKP_F16 / OKP_BF16, round to nearest even): the
  * boundary between the fp32 skip stream and an fp16 sub-network in the mixed configuration (KeypointNet(compute_dtype="float32mix")
  * runs the innermost hourglass levels, modules.py:25-66, in fp16). */
-int okp_cast(int src_dtype, const void* src_dev, int dst_dtype, void* dst_dev, int64_t count, void* stream);
+int okp_cast(int src_dtype, const void* src_dev, int dst_dtype, void* dst_dev, int64_t count, int32_t* range_flag_dev /* ABI 7; may be NULL */, void* stream);
+/* range_flag_dev (conversions TO fp32, and okp_add_f16_f32): what these two make of fp16 tensors is read by split-product plans; with a flag
+ * given they OR 1 into it when a value they write is outside the fp16 range or not finite (okp_conv_set_range_flag). */
 
 /* out = act(a + b) on contiguous tensors of `count` elements, a fp16, b and out fp32: the closing add of a residual block whose branch
  * ran on the fp16 kernels while the skip is the fp32 stream itself (residual without projection, py_utils/utils.py:184-185). */
-int okp_add_f16_f32(const void* a_f16_dev, const float* b_dev, float* out_dev, int64_t count, int act, void* stream);
+int okp_add_f16_f32(const void* a_f16_dev, const float* b_dev, float* out_dev, int64_t count, int act, int32_t* range_flag_dev /* ABI 7; may be NULL */, void* stream);
 
 /* Stream `waiter` waits for everything enqueued on stream `signaller` so far (both on the current device): the fork / join of the hourglass'
  * up1 branch that runs on a side stream next to the low path (hg_module.forward, py_utils/modules.py:50-66 - the reference runs the two

@@ -65,8 +65,8 @@ SIGNATURES = [
     ("okp_conv_set_range_flag", c_int, [c_void_p, c_void_p]),
     ("okp_stem_set_range_flag", c_int, [c_void_p, c_void_p]),
     ("okp_conv_destroy", None, [c_void_p]),
-    ("okp_cast", c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
-    ("okp_add_f16_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    ("okp_cast", c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    ("okp_add_f16_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     ("okp_stream_wait_stream", c_int, [c_void_p, c_void_p]),
     ("okp_conv_forward", c_int, [c_void_p, POINTER(okp_conv_args), c_void_p]),
     ("okp_conv_select_tile", c_int, [c_void_p, POINTER(okp_conv_args)]),

@@ -68,7 +68,6 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, q = lane >> 4;
-  bool range_bad = false;                                     // a squeeze value or a result outside the fp16 range (okp_unsplittable)
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
@@ -245,13 +244,14 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
       const int g = 2 * w + (qt >> 1);                       // this lane's k-group of 8 squeeze channels, and which half of it
       const uint32_t hl_off = (uint32_t)(qt & 1) * 8u;
       const f32x4 b1v = *reinterpret_cast<const f32x4*>(smem + OFF_BS + chq * 4), s1v = *reinterpret_cast<const f32x4*>(smem + OFF_BS + (MID + chq) * 4);
+      float range_m = 0.f;                                   // largest |squeeze value| this lane splits (okp_range_max; local to the block)
 #pragma unroll
       for (int pb = 0; pb < SP / 16; ++pb) {
         const bool ok = (mq[pb >> 1] >> (16 * (pb & 1))) & 1u;
         const int row = 16 * pb + l16t;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = ok ? __builtin_fmaf(acc[pb][e], s1v[e], b1v[e]) : 0.f; range_bad |= okp_unsplittable(v[e]); }
+        for (int e = 0; e < 4; ++e) { v[e] = ok ? __builtin_fmaf(acc[pb][e], s1v[e], b1v[e]) : 0.f; range_m = okp_range_max(range_m, v[e]); }
         *reinterpret_cast<f32x4*>(smem + OFF_S32 + row * 512 + ((((uint32_t)(4 * w + qt)) ^ (uint32_t)(row & 15)) << 4)) = v;
         u32x2 hi, lo;
         okp_split4(v, hi, lo);
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
         *reinterpret_cast<u32x2*>(hp + ((((uint32_t)(2 * g)) ^ (uint32_t)(row & 15)) << 4)) = hi;
         *reinterpret_cast<u32x2*>(hp + ((((uint32_t)(2 * g + 1)) ^ (uint32_t)(row & 15)) << 4)) = lo;
       }
+      okp_raise_range_flag(p.range_flag, okp_range_exceeded(range_m));
     }
     __syncthreads();
     FX3_STAMP(3);
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
       u32x4 sh[KS2], sl[KS2];
       sh[0] = s_frag(a_nx, 0, 0); sl[0] = s_frag(a_nx, 0, 1);
       sh[1] = s_frag(a_nx, 1, 0); sl[1] = s_frag(a_nx, 1, 1);
+      float range_m2 = 0.f;
 #pragma unroll 1
       for (int pb = 0; pb < n_pb; ++pb) {
         const uint32_t o_off = o_nx, a_row = a_nx;
@@ -317,9 +319,10 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
         const f32x4 r = __builtin_bit_cast(f32x4, r_raw);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float u = __builtin_fmaf(ac2[e], sav[e], bav[e]) + r[e]; range_bad |= okp_unsplittable(u); v[e] = fmaxf(u, 0.f); }
+        for (int e = 0; e < 4; ++e) { v[e] = fmaxf(__builtin_fmaf(ac2[e], sav[e], bav[e]) + r[e], 0.f); range_m2 = okp_range_max(range_m2, v[e]); }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, (int)o_off, 0, 0);
       }
+      okp_raise_range_flag(p.range_flag, okp_range_exceeded(range_m2));
     }
     FX3_STAMP(4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
       const float* const wl = reinterpret_cast<const float*>(smem + OFF_WD) + cg * 4;     // [tap][128] fp32, bias at tap 9
       const f32x4 breg = *reinterpret_cast<const f32x4*>(wl + 9 * MID);
       stores_behind_ring = 0;
+      float range_m3 = 0.f;
       for (int ix = tidt >> 5; ix < ((p.IW + 15) & ~15); ix += 16) {
         stores_behind_ring += MAXIH;
         const int ox = x0 + ix;
@@ -388,15 +392,15 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
           const f32x4 r = __builtin_bit_cast(f32x4, rr[iy]);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float u = v[iy][e] + r[e]; range_bad |= okp_unsplittable(u); o[e] = fmaxf(u, 0.f); }
+          for (int e = 0; e < 4; ++e) { o[e] = fmaxf(v[iy][e] + r[e], 0.f); range_m3 = okp_range_max(range_m3, o[e]); }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, (int)oo[iy], 0, 0);
         }
       }
+      okp_raise_range_flag(p.range_flag, okp_range_exceeded(range_m3));
     }
     FX3_STAMP(6);
     // no barrier here: the next tile's phase 1 starts with one (behind its vmcnt(0)), and nothing of this phase is overwritten before it
   }
-  okp_raise_range_flag(p.range_flag, range_bad);
 }
 
 }  // namespace

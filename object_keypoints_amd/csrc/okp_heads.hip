@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void okp_heads_x3_kernel(const Params p) {
           for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = H16<_Float16>::mfma16(w1h[cb][ks], xh[ks & 1][pb], acc[cb][pb]);
       }
       // h1 as pairs: channels 32 w + 16 cb + 4 q .. + 3 of the head = half (q & 1) of pair 4 w + 2 cb + (q >> 1) of pixel 16 pb + l16
-      bool range_bad = false;                              // a hidden value (split for the second layer) outside the fp16 range: local to this block,
+      float range_m = 0.f;                                 // largest hidden value split for the second layer (okp_range_max): local to this block,
                                                            // so that nothing of the guard is live across the GEMMs
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void okp_heads_x3_kernel(const Params p) {
         for (int pb = 0; pb < 2; ++pb) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = fmaxf(__builtin_fmaf(acc[cb][pb][e], s1v[cb][e], b1v[cb][e]), 0.f); range_bad |= okp_unsplittable(v[e]); }   // (x's producer has checked x)
+          for (int e = 0; e < 4; ++e) { v[e] = fmaxf(__builtin_fmaf(acc[cb][pb][e], s1v[cb][e], b1v[cb][e]), 0.f); range_m = okp_range_max(range_m, v[e]); }
           u32x2 hi, lo;
           okp_split4(v, hi, lo);
           const int px = 16 * pb + l16;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void okp_heads_x3_kernel(const Params p) {
           *reinterpret_cast<u32x2*>(row + pos) = hi;
           *reinterpret_cast<u32x2*>(row + (pos ^ 16u)) = lo;
         }
-      okp_raise_range_flag(p.range_flag, range_bad);
+      okp_raise_range_flag(p.range_flag, okp_range_exceeded(range_m));
     }
     __syncthreads();
     // x is free (every wave has read its fragments): the next tile streams in under GEMM 2 and the last layer

@@ -620,8 +620,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
     // Residual vectors: requested UH items at a time (the accumulators are dead - they were staged above - so registers
     // are available), instead of one exposed memory round trip per batch of two items.
     constexpr int UH = U >= 16 ? U / 4 : (U >= 8 ? U / 2 : U);
-    bool range_bad = false;                        // split-product plans: a result of this pass leaves the fp16 range (okp_unsplittable); local to
-                                                   // the epilogue, so that nothing of it is live across the K loop
+    float range_m = 0.f;                           // split-product plans: largest |result| of this pass (okp_range_max); local to the epilogue, so that
+                                                   // nothing of the guard is live across the K loop
 #pragma unroll 1
     for (int ub = 0; ub < U; ub += UH) {
     u32x4 rres[UH][CH8];
@@ -727,13 +727,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
                 for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb[e]; }
               }
             }
-            if constexpr (X3) {            // before the ReLU: fmaxf would turn the NaN of an out-of-range operand upstream into 0
-#pragma unroll
-              for (int e = 0; e < 8; ++e) range_bad |= okp_unsplittable(v[e]);
-            }
             if (p.act == OKP_ACT_RELU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (X3) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) range_m = okp_range_max(range_m, v[e]);
             }
             if (st32) Io<T>::store8(v, op);
             if constexpr (X3) {
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
       }
     }
     }  // ub
-    if constexpr (X3) okp_raise_range_flag(p.range_flag, range_bad);
+    if constexpr (X3) okp_raise_range_flag(p.range_flag, okp_range_exceeded(range_m));
     __syncthreads();       // staging is free again (next pass, or the next tile's LDS-DMA)
   }
   }
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
     static_assert(NT % CG == 0 && BPX % PSEG == 0 && SEG % G == 0, "depth-wise work split");
     const int cq = tid % CG, pl = tid / CG;
     const int ch = co0 + cq * VN;
-    bool dw_range_bad = false;
+    float dw_range_m = 0.f;
     if (ch < p.cout) {
       float wreg[9][VN], breg[VN];
 #pragma unroll
@@ -803,13 +803,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] += r[e];
         }
-        if constexpr (X3) {
-#pragma unroll
-          for (int e = 0; e < VN; ++e) dw_range_bad |= okp_unsplittable(v[e]);
-        }
         if (p.act == OKP_ACT_RELU) {
 #pragma unroll
           for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (X3) {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) dw_range_m = okp_range_max(dw_range_m, v[e]);
         }
         char* op = static_cast<char*>(p.dw_out) + (opix * p.dw_out_pix_stride + ch) * ESZ;
         if constexpr (ESZ == 2) {
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (std::is_same<T, F32S>::value ? 2 :
         }
       }
     }
-    if constexpr (X3) okp_raise_range_flag(p.range_flag, dw_range_bad);
+    if constexpr (X3) okp_raise_range_flag(p.range_flag, okp_range_exceeded(dw_range_m));
   }
   }  // tile loop
 }

@@ -87,8 +87,21 @@ static __device__ __forceinline__ void okp_split4(const f32x4& x, u32x2& hi, u32
 // OKP_F32X3 range guard: a value that a split-product consumer will halve (hi = fp16(x)) must fit fp16, |x| <= 65504 - beyond it hi is
 // inf, lo = fp16(x - hi) is -inf and the three-term product is NaN, which the next ReLU (fmaxf) silently turns into 0.  Every kernel that
 // PRODUCES such a value (an output tensor of a split-product plan, the squeeze tile of the one-launch fire module, the hidden layer of the
-// heads, the frames the stem reads) accumulates `bad` per lane and raises the plan's flag (okp_conv_set_range_flag) at its end.
+// heads) keeps a running MAXIMUM of the magnitudes it hands on (okp_range_max: one v_max / half a v_max3 per value) and raises the plan's
+// flag (okp_conv_set_range_flag) when it passes 65504.  A maximum does not see NaN, and does not have to: with every input in range (their
+// producers checked them: induction over the layers) a convolution's sums are finite - 2 304 products below 65504^2 - so infinity is the only
+// way out of range.  Data that enters from OUTSIDE the split-product kernels is checked exactly, NaN included (okp_unsplittable): the frames
+// the stem reads, and what okp_cast / okp_add_f16_f32 make of fp16 tensors for a split-product consumer (the mixed configuration).  (The
+// patch-resident kernel keeps the exact per-value form as a lane mask in scalar registers: free there, where a maximum in a vector register
+// cost 1.4 %; the fire module and the stem are the other way round - 5-7 % with the mask, nothing measurable with the maximum.)
+#ifdef OKP_NO_RANGE_GUARD      // experiment build: what the guard costs (A/B against the committed kernels)
+static __device__ __forceinline__ bool okp_unsplittable(float) { return false; }
+static __device__ __forceinline__ float okp_range_max(float m, float) { return m; }
+#else
 static __device__ __forceinline__ bool okp_unsplittable(float v) { return !(__builtin_fabsf(v) <= 65504.f); }     // (true for NaN)
+static __device__ __forceinline__ float okp_range_max(float m, float v) { return __builtin_fmaxf(m, __builtin_fabsf(v)); }
+#endif
+static __device__ __forceinline__ bool okp_range_exceeded(float m) { return !(m <= 65504.f); }
 static __device__ __forceinline__ void okp_raise_range_flag(int32_t* flag, bool bad) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (flag != nullptr && bad) atomicOr(flag, 1);     // (no lane takes this branch in a healthy launch)

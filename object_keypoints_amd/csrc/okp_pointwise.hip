@@ -364,7 +364,8 @@ extern "C" int okp_dwconv3x3_forward(int dtype, int32_t n, int32_t c, int32_t co
 namespace {
 // 8 elements per thread and iteration: 32 + 16 bytes per lane, grid-stride
 template <typename S, typename D>
-__global__ __launch_bounds__(256) void okp_cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n8, long count) {
+__global__ __launch_bounds__(256) void okp_cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long n8, long count, int32_t* range_flag) {
+  bool bad = false;         // range_flag (conversions TO fp32 for a split-product consumer): a value outside the fp16 range or not finite, exactly
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const long e0 = i * 8;
     if (e0 + 8 <= count) {
@@ -373,23 +374,26 @@ __global__ __launch_bounds__(256) void okp_cast_kernel(const S* __restrict__ src
       const sv8 v = *reinterpret_cast<const sv8*>(src + e0);
       dv8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (D)(float)v[e];
+      for (int e = 0; e < 8; ++e) { o[e] = (D)(float)v[e]; bad |= okp_unsplittable((float)v[e]); }
       *reinterpret_cast<dv8*>(dst + e0) = o;
     } else {
-      for (long e = e0; e < count; ++e) dst[e] = (D)(float)src[e];
+      for (long e = e0; e < count; ++e) { dst[e] = (D)(float)src[e]; bad |= okp_unsplittable((float)src[e]); }
     }
   }
+  okp_raise_range_flag(range_flag, bad);
 }
 template <typename S, typename D>
-void launch_cast(const void* src, void* dst, long count, hipStream_t stream) {
+void launch_cast(const void* src, void* dst, long count, int32_t* range_flag, hipStream_t stream) {
   const long n8 = (count + 7) / 8;
   const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
-  hipLaunchKernelGGL((okp_cast_kernel<S, D>), dim3(grid), dim3(256), 0, stream, static_cast<const S*>(src), static_cast<D*>(dst), n8, count);
+  hipLaunchKernelGGL((okp_cast_kernel<S, D>), dim3(grid), dim3(256), 0, stream, static_cast<const S*>(src), static_cast<D*>(dst), n8, count, range_flag);
 }
 }  // namespace
 
 namespace {
-__global__ __launch_bounds__(256) void okp_add_f16_f32_kernel(const _Float16* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n8, long count, int relu) {
+__global__ __launch_bounds__(256) void okp_add_f16_f32_kernel(const _Float16* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n8, long count, int relu,
+                                                              int32_t* range_flag) {
+  bool bad = false;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const long e0 = i * 8;
     if (e0 + 8 <= count) {
@@ -399,35 +403,38 @@ __global__ __launch_bounds__(256) void okp_add_f16_f32_kernel(const _Float16* __
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o0[e] = (float)av[e] + b0[e]; o1[e] = (float)av[4 + e] + b1[e];
+        bad |= okp_unsplittable(o0[e]) || okp_unsplittable(o1[e]);        // (before the ReLU: fmaxf turns a NaN into 0)
         if (relu) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
       }
       *reinterpret_cast<f32x4*>(out + e0) = o0;
       *reinterpret_cast<f32x4*>(out + e0 + 4) = o1;
     } else {
-      for (long e = e0; e < count; ++e) { const float v = (float)a[e] + b[e]; out[e] = relu ? fmaxf(v, 0.f) : v; }
+      for (long e = e0; e < count; ++e) { const float v = (float)a[e] + b[e]; bad |= okp_unsplittable(v); out[e] = relu ? fmaxf(v, 0.f) : v; }
     }
   }
+  okp_raise_range_flag(range_flag, bad);
 }
 }  // namespace
 
-extern "C" int okp_add_f16_f32(const void* a, const float* b, float* out, int64_t count, int act, void* stream) {
+extern "C" int okp_add_f16_f32(const void* a, const float* b, float* out, int64_t count, int act, int32_t* range_flag, void* stream) {
   if (!a || !b || !out || count < 1) { okp_set_error("okp_add_f16_f32: null / empty argument"); return OKP_EINVAL; }
   if (((uintptr_t)a) % 16 || ((uintptr_t)b) % 16 || ((uintptr_t)out) % 16) { okp_set_error("okp_add_f16_f32: tensors must be 16-byte aligned"); return OKP_EINVAL; }
   if (act != OKP_ACT_NONE && act != OKP_ACT_RELU) { okp_set_error("okp_add_f16_f32: activation %d", act); return OKP_EINVAL; }
   const long n8 = (count + 7) / 8;
   const int grid = (int)std::min<long>((n8 + 255) / 256, 2048);
-  hipLaunchKernelGGL(okp_add_f16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, static_cast<const _Float16*>(a), b, out, n8, (long)count, act == OKP_ACT_RELU ? 1 : 0);
+  hipLaunchKernelGGL(okp_add_f16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, static_cast<const _Float16*>(a), b, out, n8, (long)count, act == OKP_ACT_RELU ? 1 : 0, range_flag);
   return okp_check_hip(hipGetLastError(), "okp_add_f16_f32 launch");
 }
 
-extern "C" int okp_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t count, void* stream) {
+extern "C" int okp_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t count, int32_t* range_flag, void* stream) {
   if (!src || !dst || count < 1) { okp_set_error("okp_cast: null / empty argument"); return OKP_EINVAL; }
   if (((uintptr_t)src) % 16 || ((uintptr_t)dst) % 16) { okp_set_error("okp_cast: tensors must be 16-byte aligned"); return OKP_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
-  if (src_dtype == OKP_F32 && dst_dtype == OKP_F16) launch_cast<float, _Float16>(src, dst, count, st);
-  else if (src_dtype == OKP_F32 && dst_dtype == OKP_BF16) launch_cast<float, __bf16>(src, dst, count, st);
-  else if (src_dtype == OKP_F16 && dst_dtype == OKP_F32) launch_cast<_Float16, float>(src, dst, count, st);
-  else if (src_dtype == OKP_BF16 && dst_dtype == OKP_F32) launch_cast<__bf16, float>(src, dst, count, st);
+  if (range_flag && dst_dtype != OKP_F32) { okp_set_error("okp_cast: the range flag belongs to conversions to fp32"); return OKP_EINVAL; }
+  if (src_dtype == OKP_F32 && dst_dtype == OKP_F16) launch_cast<float, _Float16>(src, dst, count, nullptr, st);
+  else if (src_dtype == OKP_F32 && dst_dtype == OKP_BF16) launch_cast<float, __bf16>(src, dst, count, nullptr, st);
+  else if (src_dtype == OKP_F16 && dst_dtype == OKP_F32) launch_cast<_Float16, float>(src, dst, count, range_flag, st);
+  else if (src_dtype == OKP_BF16 && dst_dtype == OKP_F32) launch_cast<__bf16, float>(src, dst, count, range_flag, st);
   else { okp_set_error("okp_cast: unsupported conversion %d -> %d (fp32 <-> fp16 / bf16)", src_dtype, dst_dtype); return OKP_EINVAL; }
   return okp_check_hip(hipGetLastError(), "okp_cast launch");
 }

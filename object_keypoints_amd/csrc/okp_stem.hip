@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  bool range_bad = false;                    // a frame value or a result outside the fp16 range (okp_unsplittable)
+  bool range_bad = false;                    // a frame value outside the fp16 range or not finite (okp_unsplittable: exact, the frames come from outside)
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   u32x4 wh[KSTEPS], wl[KSTEPS];              // B-operand fragments of this wave's 32 channels: [wave][hi | lo][k-step][lane]
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
         for (int r = 0; r < 2; ++r) acc[r] = H16<_Float16>::mfma32(ph[r], wh[s], acc[r]);
       }
       if (g == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next patch's pixels have arrived, older stores have drained
+      float range_m = 0.f;                          // largest result of this row pair (okp_range_max)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + ry0 + r;
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int i0 = 8 * (e >> 2) + (e & 3);                  // pixel (MFMA row) of register e is i0 + 4 h
-            range_bad |= okp_unsplittable(acc[r][e] * osc);
             const float v = fmaxf(acc[r][e] * osc, 0.f);
+            range_m = okp_range_max(range_m, v);
             uint32_t word = __builtin_bit_cast(uint32_t, v);
             if constexpr (PAIRS) {
               f16x2 hl;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
           }
         }
       }
+      range_bad |= okp_range_exceeded(range_m);
     }
     if (next < p.n_tiles) store_patch(buf ^ 1);
     __syncthreads();            // every thread's part of the next patch is in LDS; this patch is free

@@ -371,15 +371,21 @@ void preprocess_u8(const Tensor& frames, int64_t resized_h, int64_t resized_w, i
            "okp_preprocess_u8");
 }
 
-void cast(const Tensor& src, const Tensor& dst, int64_t stream) {
-  TORCH_CHECK(src.is_cuda() && dst.is_cuda() && src.is_contiguous() && dst.is_contiguous() && src.numel() == dst.numel(), "okp: cast takes contiguous device tensors of one size");
-  check_rc(okp_cast(dtype_of(src), src.data_ptr(), dtype_of(dst), dst.data_ptr(), src.numel(), sp(stream)), "okp_cast");
+inline int32_t* flag_ptr(const optional<Tensor>& f) {
+  if (!f.has_value()) return nullptr;
+  TORCH_CHECK(f->is_cuda() && f->scalar_type() == at::kInt && f->numel() >= 1, "okp: range_flag is an int32 device tensor");
+  return f->data_ptr<int32_t>();
 }
 
-void add_f16_f32(const Tensor& a, const Tensor& b, const Tensor& out, int64_t act, int64_t stream) {
+void cast(const Tensor& src, const Tensor& dst, int64_t stream, const optional<Tensor>& range_flag) {
+  TORCH_CHECK(src.is_cuda() && dst.is_cuda() && src.is_contiguous() && dst.is_contiguous() && src.numel() == dst.numel(), "okp: cast takes contiguous device tensors of one size");
+  check_rc(okp_cast(dtype_of(src), src.data_ptr(), dtype_of(dst), dst.data_ptr(), src.numel(), flag_ptr(range_flag), sp(stream)), "okp_cast");
+}
+
+void add_f16_f32(const Tensor& a, const Tensor& b, const Tensor& out, int64_t act, int64_t stream, const optional<Tensor>& range_flag) {
   check_dev(a, at::kHalf, "a"); check_dev(b, at::kFloat, "b"); check_dev(out, at::kFloat, "out");
   TORCH_CHECK(a.numel() == b.numel() && b.numel() == out.numel(), "okp: add_f16_f32 takes tensors of one size");
-  check_rc(okp_add_f16_f32(a.data_ptr(), b.data_ptr<float>(), out.data_ptr<float>(), out.numel(), (int)act, sp(stream)), "okp_add_f16_f32");
+  check_rc(okp_add_f16_f32(a.data_ptr(), b.data_ptr<float>(), out.data_ptr<float>(), out.numel(), (int)act, flag_ptr(range_flag), sp(stream)), "okp_add_f16_f32");
 }
 
 void dwconv3x3_forward(const Tensor& src, int64_t src_c0, int64_t c, int64_t conv_stride, const Tensor& w, const Tensor& bias, const optional<Tensor>& res, int64_t res_c0,
@@ -512,8 +518,8 @@ TORCH_LIBRARY(okp, m) {
   m.def("pack_frames(Tensor frames, Tensor(a!) out, int stream) -> ()", pack_frames);
   m.def("pack_frames_u8(Tensor frames, float[] mean, float[] std, Tensor(a!) out, int stream) -> ()", pack_frames_u8);
   m.def("preprocess_u8(Tensor frames, int resized_h, int resized_w, int crop_y, int crop_x, int h, int w, float[] mean, float[] std, Tensor(a!) out, int stream) -> ()", preprocess_u8);
-  m.def("cast(Tensor src, Tensor(a!) dst, int stream) -> ()", cast);
-  m.def("add_f16_f32(Tensor a, Tensor b, Tensor(a!) out, int act, int stream) -> ()", add_f16_f32);
+  m.def("cast(Tensor src, Tensor(a!) dst, int stream, Tensor(b!)? range_flag=None) -> ()", cast);
+  m.def("add_f16_f32(Tensor a, Tensor b, Tensor(a!) out, int act, int stream, Tensor(b!)? range_flag=None) -> ()", add_f16_f32);
   m.def("dwconv3x3_forward(Tensor src, int src_c0, int c, int conv_stride, Tensor w, Tensor bias, Tensor? res, int res_c0, Tensor(a!) out, int out_c0, int act, int stream) -> ()", dwconv3x3_forward);
   m.def("nms_maxpool(Tensor x, int size, Tensor(a!) out, int stream) -> ()", nms_maxpool);
   m.def("capacity_overflow(Tensor count, int K, int cap, int max_obj, Tensor(a!) flag, int stream, Tensor? range_flag=None) -> ()", capacity_overflow);

@@ -544,11 +544,14 @@ def cast(src, dtype):
         raise OkpError("cast takes a whole tensor, not a channel window")
     out = Act(torch.empty(src.t.shape, dtype=dtype, device=src.t.device))
     okp_dtype(dtype)
+    # to fp32 inside a split-product pass: what the fp16 sub-network made is about to be halved again - its range is checked here, exactly
+    flag = getattr(_MODE, "range_flag", None) if dtype == torch.float32 else None
     T = _ops()
     if T is not None:
-        _dispatch(T.cast, src.t, out.t, stream_int())
+        _dispatch(T.cast, src.t, out.t, stream_int(), flag)
     else:
-        _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(), stream_handle()), "okp_cast")
+        _lib.check(_lib.lib().okp_cast(okp_dtype(src.dtype), src.t.data_ptr(), okp_dtype(dtype), out.t.data_ptr(), src.t.numel(),
+                                       flag.data_ptr() if flag is not None else None, stream_handle()), "okp_cast")
     COUNTERS["launches"] += 1
     return out
 
@@ -559,11 +562,13 @@ def add_f16_f32(a16, b32, relu=True):
     if a16.dtype != torch.float16 or b32.dtype != torch.float32 or a16.t.shape != b32.t.shape or a16.c0 or b32.c0 or a16.c != a16.t.shape[3] or b32.c != b32.t.shape[3]:
         raise OkpError("add_f16_f32 takes whole float16 / float32 tensors of one shape")
     out = Act(torch.empty_like(b32.t))
+    flag = getattr(_MODE, "range_flag", None)
     T = _ops()
     if T is not None:
-        _dispatch(T.add_f16_f32, a16.t, b32.t, out.t, ACT_RELU if relu else ACT_NONE, stream_int())
+        _dispatch(T.add_f16_f32, a16.t, b32.t, out.t, ACT_RELU if relu else ACT_NONE, stream_int(), flag)
     else:
-        _lib.check(_lib.lib().okp_add_f16_f32(a16.t.data_ptr(), b32.t.data_ptr(), out.t.data_ptr(), out.t.numel(), ACT_RELU if relu else ACT_NONE, stream_handle()), "okp_add_f16_f32")
+        _lib.check(_lib.lib().okp_add_f16_f32(a16.t.data_ptr(), b32.t.data_ptr(), out.t.data_ptr(), out.t.numel(), ACT_RELU if relu else ACT_NONE,
+                                              flag.data_ptr() if flag is not None else None, stream_handle()), "okp_add_f16_f32")
     COUNTERS["launches"] += 1
     return out
 
