@@ -503,7 +503,7 @@ def run_precision(name, ctx, steps, warmup, workload="batch64"):
                            "mfma_busy": ctr_6["mfma_busy"], "lds_wait": ctr_6["lds_wait"], "hbm_GBps": ctr_6["hbm_GBps"], "counter_source": ctr_6["counter_source"],
                            "counter_commit": ctr_6["counter_commit"], "stale": ctr_6["stale"], "launches_timed": n_6,
                            "avg_launch_us": (ms_6 * 1e3 / n_6) if n_6 else None, "avg_gflop_per_launch": (fl_6 / n_6 / 1e9) if n_6 else None, "mfma_terms": 1,
-                           "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f16"], name)}
+                           "share_of_kernel_time": kernel_time_share(KERNEL_SIG["f16"], name), "step_frac": roof["step_frac"]}
     if name == "f32x3":
         res["roofline"]["mfma_terms"] = 3       # MFMA FLOPs issued per algorithmic FLOP (hi*hi + lo*hi + hi*lo): frac 1/3 = the pipe saturated
         res["roofline"]["issued_frac"] = 3.0 * res["roofline"]["frac"] if res["roofline"].get("frac") is not None else None   # ... i.e. what the matrix pipe itself sees
