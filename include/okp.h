@@ -32,7 +32,8 @@ extern "C" {
                                  6: okp_conv_args.src_pairs / out_pairs (pair-format tensors between split-product 3x3 convolutions), okp_stem_forward_nchw_pairs
                                  7: okp_conv_patch_applies; okp_group_objects: `reduced_dev` (device k-means reduction of surplus votes);
                                     okp_conv_set_range_flag / okp_stem_set_range_flag (fp16-range guard of split-product plans), `range_flag_dev` of
-                                    okp_capacity_overflow, okp_cast and okp_add_f16_f32 */
+                                    okp_capacity_overflow, okp_cast and okp_add_f16_f32; views of 2 GiB and more as the output of an OKP_F32X3
+                                    stem and as sources of OKP_F32X3 plans on the patch-resident kernel */
 
 /* OKP_F16: IEEE half activations / weights, fp32 accumulate (BASELINE configs[4]).
  * OKP_F32X3 (okp_conv plans only): fp32 activations, weights and results like OKP_F32 - every tensor argument of such a plan is an
@@ -109,7 +110,9 @@ typedef struct okp_tensor {        /* an NHWC view */
   void* data;                      /* device pointer to element (n=0,y=0,x=0,c=0) of the view */
   int32_t h, w;                    /* spatial size */
   int32_t pix_stride;              /* elements between consecutive pixels (>= channels of the view) */
-  int64_t bytes;                   /* bytes addressable from `data` (bounds for hardware range checks) */
+  int64_t bytes;                   /* bytes addressable from `data` (bounds for hardware range checks); < 2 GiB - except the output of an OKP_F32X3
+                                      stem and a source of an OKP_F32X3 plan whose launch runs on the patch-resident kernel (tile 13): those two
+                                      kernels address frame by frame, one FRAME must stay below 2 GiB (ABI 7) */
 } okp_tensor;
 
 typedef struct okp_conv_args {

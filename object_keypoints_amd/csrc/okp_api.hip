@@ -394,13 +394,13 @@ extern "C" void okp_conv_destroy(okp_conv* plan) {
 }
 
 namespace {
-int check_view(const char* name, const okp_tensor& t, int esz, bool required, int align = 16) {
+int check_view(const char* name, const okp_tensor& t, int esz, bool required, int align = 16, int64_t max_bytes = 0x7FFF0000ll) {
   if (!t.data) {
     if (required) { okp_set_error("okp_conv_forward: %s is null", name); return OKP_EINVAL; }
     return OKP_OK;
   }
   if ((t.pix_stride * esz) % align || ((uintptr_t)t.data) % align) { okp_set_error("okp_conv_forward: %s is not %d-byte aligned (pix_stride %d)", name, align, t.pix_stride); return OKP_EINVAL; }
-  if (t.bytes <= 0 || t.bytes >= 0x7FFF0000ll) { okp_set_error("okp_conv_forward: %s spans %lld bytes; views must be < 2 GiB (sub-batch the frames)", name, (long long)t.bytes); return OKP_EINVAL; }
+  if (t.bytes <= 0 || t.bytes >= max_bytes) { okp_set_error("okp_conv_forward: %s spans %lld bytes; views must be < 2 GiB (sub-batch the frames)", name, (long long)t.bytes); return OKP_EINVAL; }
   if (t.h < 1 || t.w < 1) { okp_set_error("okp_conv_forward: %s has empty spatial size", name); return OKP_EINVAL; }
   return OKP_OK;
 }
@@ -416,7 +416,9 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   for (int s = 0; s < plan->n_src; ++s) {
     // sources are read with dword-aligned 16-byte buffer loads (the packed stem frame has 8-byte bf16 pixels);
     // out/res rows are written/read as aligned 16-byte vectors
-    if (int e = check_view(s ? "src[1]" : "src[0]", a->src[s], esz, true, 8)) return e;
+    // (a SOURCE of a split-product plan may pass 2 GiB where the launch runs on the patch-resident kernel, which addresses frame by frame:
+    //  checked again below, once the tile is known)
+    if (int e = check_view(s ? "src[1]" : "src[0]", a->src[s], esz, true, 8, plan->dtype == OKP_F32X3 ? (1ll << 40) : 0x7FFF0000ll)) return e;
     // cin may span several consecutive pixels of a row (the stem reads 8 px x 4 ch per tap)
     if (a->src[s].pix_stride < plan->cin[s] && plan->cin[s] % a->src[s].pix_stride != 0) {
       okp_set_error("okp_conv_forward: src[%d] pix_stride %d incompatible with cin %d", s, a->src[s].pix_stride, plan->cin[s]); return OKP_EINVAL;
@@ -464,7 +466,7 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
   std::memset(&p, 0, sizeof(p));
   for (int s = 0; s < 2; ++s) {
     const int ss = s < plan->n_src ? s : 0;
-    p.src[s] = a->src[ss].data; p.src_bytes[s] = (uint32_t)a->src[ss].bytes;
+    p.src[s] = a->src[ss].data; p.src_bytes[s] = (uint32_t)(a->src[ss].bytes < 0x7FFF0000ll ? a->src[ss].bytes : 0x7FFF0000ll); p.src_bytes64[s] = a->src[ss].bytes;
     p.srcH[s] = a->src[ss].h; p.srcW[s] = a->src[ss].w; p.src_pix_stride[s] = a->src[ss].pix_stride;
     p.conv_stride[s] = plan->conv_stride[ss];
   }
@@ -507,6 +509,11 @@ extern "C" int okp_conv_forward(const okp_conv* plan, const okp_conv_args* a, vo
     p.dw_out_pix_stride = a->dw_out.pix_stride; p.dw_res_pix_stride = a->dw_res.pix_stride;
   }
   const int tile = a->tile ? a->tile : select_tile(plan, a);
+  for (int s = 0; s < plan->n_src; ++s)
+    if (a->src[s].bytes >= 0x7FFF0000ll && tile != 13) {
+      okp_set_error("okp_conv_forward: src[%d] spans %lld bytes; only the patch-resident split-product kernel (tile 13; this launch: tile %d) reads views of 2 GiB and more", s, (long long)a->src[s].bytes, tile);
+      return OKP_EINVAL;
+    }
   if ((p.src_pairs || p.out_pairs) && tile != 13) {
     okp_set_error("okp_conv_forward: pair-format tensors are read / written by the patch-resident split-product kernel only (tile 13; this launch: tile %d)", tile);
     return OKP_EINVAL;

@@ -453,12 +453,16 @@ int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatc
     const int ss = plan->patch_src[gi];
     // geom_src holds one bit per geometry (sources 0 / 1), geom_ph five (<= 18 rows); bit 31 of a table entry is the
     // "outside" flag, which views below 2 GiB (check_view) leave free
-    if (ss < 0 || ss > 1 || plan->patch_PH[gi] > 18 || q.src_bytes[ss] >= 0x80000000u) { okp_set_error("okp_conv_forward: patch geometry %d outside what the in-loop tables encode", gi); return OKP_EINVAL; }
+    // (split-product plans address frame by frame: one FRAME of the source must leave bit 31 of a table entry free, not the whole view)
+    const int64_t span = plan->dtype == OKP_F32X3 ? (int64_t)q.srcH[ss] * q.srcW[ss] * q.src_pix_stride[ss] * 4 : (q.src_bytes64[ss] ? q.src_bytes64[ss] : (int64_t)q.src_bytes[ss]);
+    if (ss < 0 || ss > 1 || plan->patch_PH[gi] > 18 || span >= 0x7FFF0000ll) { okp_set_error("okp_conv_forward: patch geometry %d outside what the in-loop tables encode", gi); return OKP_EINVAL; }
     p.geom_ph |= (uint32_t)plan->patch_PH[gi] << (5 * gi);
     p.geom_src |= (uint32_t)ss << gi;
     p.src_data[ss] = q.src[ss]; p.src_bytes[ss] = q.src_bytes[ss];
+    p.src_total_bytes[ss] = q.src_bytes64[ss] ? q.src_bytes64[ss] : (int64_t)q.src_bytes[ss];
+    p.src_frame_bytes[ss] = (int64_t)q.srcH[ss] * q.srcW[ss] * q.src_pix_stride[ss] * okp_esz(plan->dtype);
   }
-  if (!p.src_data[1]) { p.src_data[1] = p.src_data[0]; p.src_bytes[1] = p.src_bytes[0]; }
+  if (!p.src_data[1]) { p.src_data[1] = p.src_data[0]; p.src_bytes[1] = p.src_bytes[0]; p.src_total_bytes[1] = p.src_total_bytes[0]; p.src_frame_bytes[1] = p.src_frame_bytes[0]; }
   p.weights = q.weights; p.w_bytes = q.w_bytes; p.cout_pad = q.cout_pad; p.cout = q.cout; p.bias = q.bias; p.oscale = q.oscale;
   p.steps = plan->patch_steps_dev; p.n_steps = plan->n_slices;
   p.n_classes = q.n_classes; p.steps_per_class = plan->n_slices / q.n_classes;

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weights), 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_co_tiles * 256 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.oscale), 0, p.n_co_tiles * 256 * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src_data[0]), 0, (int)p.src_bytes[0], 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src_data[1]), 0, (int)p.src_bytes[1], 0x00020000);
+  // (the sources' buffer resources are built per tile from the tile's FRAME - 64-bit base, frame-relative 32-bit offsets with bit 31 as the
+  //  "outside" flag - so a source may span more than 2 GiB: the fp32 / pair-format stem output of a 64-frame batch is 2.1 GB)
 
   if (tid < p.n_steps) reinterpret_cast<u32x4*>(steps_lds)[tid] = reinterpret_cast<const u32x4*>(p.steps)[tid];
   __syncthreads();
@@ -102,6 +102,11 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
     const int tyi = fastdiv(trem, p.div_tiles_x);
     const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
     const int co0 = co_tile * 256;
+    auto frame_rsrc = [&](int s_) {
+      const int64_t off = (int64_t)n * p.src_frame_bytes[s_], left = p.src_total_bytes[s_] - off;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.src_data[s_])) + off, 0, (int)(left < 0x7FFF0000ll ? left : 0x7FFF0000ll), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_s0 = frame_rsrc(0), rs_s1 = frame_rsrc(1);
 
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)bias_lds, 16, (int)((uint32_t)(co0 + lane * 4) * 4u), 0, 0, 0);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
       const int i = idx / kPitch, j = idx - i * kPitch;
       const int ys = G.conv_stride * y0 + G.oy + i * G.step, xs = G.conv_stride * x0 + G.ox + j * G.step;
       const bool ok = idx < G.npx && j < G.PW && ys >= 0 && ys < G.H && xs >= 0 && xs < G.W;
-      return ok ? ((uint32_t)((n * G.H + ys) * G.W + xs) * (uint32_t)(G.pix_stride * 4)) | patch_key_x3(j) : kInvalidOff;
+      return ok ? ((uint32_t)(ys * G.W + xs) * (uint32_t)(G.pix_stride * 4)) | patch_key_x3(j) : kInvalidOff;      // (relative to frame n)
     };
     // passes [k0, k1) of a patch: pass k = 1 KiB blocks 8 k .. 8 k + 7 (one per wave) = patch pixels 64 k .. 64 k + 63; addresses
     // from the tile's offset table (no scalar loads in the loop)
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(512) void okp_igemm_patch_x3_kernel(const OkpPatchP
     // the tile's first patch: addresses worked out in registers (the table is being written by other threads right now)
     auto issue_patch = [&](int geom, uint32_t c0b, int k0, int k1, int buf) {
       const OkpPatchGeom& G = p.g[geom];                         // uniform index into the kernel arguments: scalar loads
-      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.data), 0, (int)G.bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_x = ((p.geom_src >> geom) & 1) ? rs_s1 : rs_s0;
       for (int k = k0; k < k1; ++k) {
         const int blk = k * 8 + wave;
         if (blk * 8 >= G.npx) continue;

@@ -178,6 +178,7 @@ struct OkpIgemmParams {
   int32_t out_sub2, OH2, OW2;        // OKP_F32X3: the fp32 output keeps even rows / columns only (tensor of OH2 x OW2 pixels); out16 is full size
   int32_t mfma32;                    // tile 14: the patch-resident 16-bit kernel on 32x32x16 MFMAs (experiment)
   int32_t* range_flag;               // OKP_F32X3: the plan's range flag (okp_conv_set_range_flag) or NULL
+  int64_t src_bytes64[2];            // the sources' byte spans in full (src_bytes is clamped to 32 bits): a source of the split-product patch kernel may pass 2 GiB
   OkpTapDev taps[OKP_MAX_TAPS];
 };
 
@@ -220,6 +221,8 @@ struct OkpPatchParams {
   int32_t act, n_co_tiles, n_tiles;
   uint32_t pairs;              // okp_igemm_patch_x3.hip: bit s = source s arrives in pair format (its patches are not split), bit 2 = out is written in pair format
   int32_t* range_flag;         // okp_igemm_patch_x3.hip: the plan's range flag or NULL
+  int64_t src_total_bytes[2];  // okp_igemm_patch_x3.hip: a source's whole byte span (may pass 2 GiB) and the bytes of one frame of it: the kernel builds
+  int64_t src_frame_bytes[2];  // its buffer resources per tile from the tile's frame, offsets are frame-relative
 #ifdef OKP_PATCH_STAMPS
   uint32_t* dbg;
 #endif

@@ -54,6 +54,8 @@ struct StemParams {
   int32_t tiles_x, tiles_y, n_tiles;
   OkpFastDiv div_tiles_frame, div_tiles_x;
   int32_t* range_flag;      // split-product plan: raised when a frame value or a result leaves the fp16 range (okp_stem_set_range_flag), or NULL
+  int64_t out_total_bytes;  // split-product plan: bytes of the whole output view (it may pass 2 GiB: the kernel addresses frame by frame)
+  int64_t out_frame_bytes;  // ... and of one frame of it
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) { wh[s] = wf[s * 64]; wl[s] = wf[(KSTEPS + s) * 64]; }
   }
-  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  // (the output resource is built per tile from the tile's FRAME - 64-bit base, frame-relative 32-bit offsets - so that an fp32 output of
+  //  a whole batch, 2.1 GB at 64 frames, needs no frame chunks: okp_stem_forward_nchw lifts the 2 GiB view limit for this kernel)
   const uint32_t ps4 = (uint32_t)p.out_pix_stride * 4u;                       // bytes per output pixel
   const uint32_t st_lane = (uint32_t)(4 * h) * ps4 + (PAIRS ? (uint32_t)(32 * wave) * 4u + (uint32_t)(j >> 3) * 32u + (uint32_t)((j & 7) >> 1) * 4u + (uint32_t)(j & 1) * 16u
                                                                 : (uint32_t)(32 * wave + j) * 4u);
@@ -305,6 +308,8 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
     if (next < p.n_tiles) load_patch(next);
     int n, oy0, ox0;
     tile_coords(tile, n, oy0, ox0);
+    const int64_t frame_off = (int64_t)n * p.out_frame_bytes, left = p.out_total_bytes - frame_off;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.out) + frame_off, 0, (int)(left < 0x7FFF0000ll ? left : 0x7FFF0000ll), 0x00020000);
     const char* const patch = smem + (2 * buf) * PATCH_BYTES;
     const int lane_off = (2 * j + 2 * h) * 8;
 #pragma unroll 1
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void okp_stem_x3_kernel(const StemParams p)
       for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + ry0 + r;
         if (oy < p.Ho) {
-          const uint32_t row_off = (uint32_t)(((long)n * p.Ho + oy) * p.Wo + ox0) * ps4;       // scalar
+          const uint32_t row_off = (uint32_t)(oy * p.Wo + ox0) * ps4;       // scalar, relative to the frame
           const bool full = ox0 + TW <= p.Wo;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -509,8 +514,13 @@ static int stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w
   if (n < 1 || h < 1 || w < 1) { okp_set_error("okp_stem_forward_nchw: empty problem"); return OKP_EINVAL; }
   const int ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
   const int64_t src_bytes = (int64_t)n * 3 * h * w * 4;
-  if (src_bytes >= 0x7FFF0000ll || out->bytes <= 0 || out->bytes >= 0x7FFF0000ll) { okp_set_error("okp_stem_forward_nchw: views must be < 2 GiB (sub-batch the frames)"); return OKP_EINVAL; }
   const int esz = st->dtype == OKP_F32X3 ? 4 : 2;          // the split-product plan writes fp32 NHWC
+  // views are limited to 2 GiB (32-bit buffer offsets, bit 31 = "masked") - except the OUTPUT of the split-product kernel, which addresses
+  // frame by frame: there one frame must stay below the limit, the view below 2^40
+  const int64_t out_limit = st->dtype == OKP_F32X3 ? (1ll << 40) : 0x7FFF0000ll;
+  if (src_bytes >= 0x7FFF0000ll || out->bytes <= 0 || out->bytes >= out_limit || (int64_t)ho * wo * out->pix_stride * esz >= 0x7FFF0000ll) {
+    okp_set_error("okp_stem_forward_nchw: views must be < 2 GiB (sub-batch the frames)"); return OKP_EINVAL;
+  }
   if (out->h != ho || out->w != wo || out->pix_stride < kCout || (out->pix_stride * esz) % 64 || ((uintptr_t)out->data) % 64 || ((uintptr_t)frames_nchw_dev) % 4) {
     okp_set_error("okp_stem_forward_nchw: out must be %dx%d with 64-byte aligned pixels of >= 128 channels", ho, wo);
     return OKP_EINVAL;
@@ -520,7 +530,8 @@ static int stem_forward_nchw(const okp_stem* st, int32_t n, int32_t h, int32_t w
   std::memset(&p, 0, sizeof(p));
   p.src = frames_nchw_dev; p.src_bytes = (uint32_t)src_bytes; p.H = h; p.W = w;
   p.wfrag = st->wfrag_dev; p.bias = st->bias_dev; p.oscale = st->oscale_dev; p.range_flag = st->range_flag;
-  p.out = out->data; p.out_bytes = (uint32_t)out->bytes; p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
+  p.out = out->data; p.out_bytes = (uint32_t)(out->bytes < 0x7FFF0000ll ? out->bytes : 0x7FFF0000ll); p.N = n; p.Ho = ho; p.Wo = wo; p.out_pix_stride = out->pix_stride;
+  p.out_total_bytes = out->bytes; p.out_frame_bytes = (int64_t)ho * wo * out->pix_stride * esz;
   p.tiles_x = (wo + TW - 1) / TW; p.tiles_y = (ho + TH - 1) / TH;
   const long tiles = (long)n * p.tiles_x * p.tiles_y;
   if (tiles >= 0x7FFFFFFFl) { okp_set_error("okp_stem_forward_nchw: too many tiles"); return OKP_EINVAL; }

@@ -34,6 +34,9 @@ PAIR_TENSORS = True      # split-product configuration: a tensor whose only read
                          # not split every landed patch between their K-steps: conv1 -> conv2 of the residual blocks, pre[1] -> pre[2],
                          # hourglass -> cnvs.  Bit-identical results (the same split, done once per element in the producer's epilogue)
 STEM_PAIRS = True        # ... and the split-product stem kernel writes pairs for pre[1] (okp_stem_forward_nchw_pairs)
+BIG_VIEWS = True         # split-product configuration on raw frames: the stem kernel writes, and the patch-resident kernel reads, the stem's map of the WHOLE
+                         # batch (2.1 GB at 64 frames: both address frame by frame, include/okp.h) - no frame chunks in front of pre[2];
+                         # False = chunks under the 2 GiB view limit as for the other fp32-storage configurations (A/B)
 UNPOOL_TILE = 0          # tile code of the transposed-conv launches (0 = heuristic)
 SQUEEZE_TILE = 0         # tile code of the squeeze launch of a fire module that has no one-launch kernel (0 = heuristic)
 STEM_TILE = 4            # 7x7/s2 stem on the generic kernel: 128 co x 256 px tile measured fastest (603 vs 728 us)
@@ -274,6 +277,12 @@ class residual(_HipModule):
         """(conv1, conv2) of an input of n x h x w pixels run on the patch-resident split-product kernel, i.e. may exchange pair-format
         tensors (PAIR_TENSORS): pure split-product plans only - the mixed configuration keeps its fp16 side outputs."""
         if not (PAIR_TENSORS and dtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX):
+            return False, False
+        return self.launches_on_patch(n, h, w, dtype, in_pix_stride)
+
+    def launches_on_patch(self, n, h, w, dtype, in_pix_stride=None):
+        """(conv1, conv2) run on the patch-resident split-product kernel for this input (whatever the tensor format)."""
+        if not (dtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX):
             return False, False
         p1, p2 = self._plan(("p", dtype), lambda: self._build(dtype))
         if not p1.split:
@@ -629,6 +638,10 @@ class hg(_HipModule):
                 return self.pre[0](xi, shadow=sh, compact=sh and cp[0])
         want_shadow = mix16 and sdtype == torch.float32
         chunk = self.front_chunk(n, fh, fw, sdtype, compact=want_shadow and cp[0])
+        if (chunk < n and BIG_VIEWS and isinstance(x, torch.Tensor) and sdtype == torch.float32 and ops.F32_SPLIT and not ops.F32_MIX and STEM_X3_KERNEL
+                and STEM_KERNEL and STEM_DIRECT and self.pre[0].inp_dim == 3 and self.pre[0].out_dim == 128
+                and all(self.pre[1].launches_on_patch(n, conv_out_size(fh, 7, 2, 3), conv_out_size(fw, 7, 2, 3), sdtype))):
+            chunk = n       # the split-product stem kernel and the patch-resident kernel address frame by frame: the whole batch in one launch each
         # pair format between the stem and pre[1] (both of its launches read the stem's map): every frame chunk's launches on the patch kernel
         stem_pairs = STEM_PAIRS and all(self.pre[1].takes_pairs(min(n, q + chunk) - q, conv_out_size(fh, 7, 2, 3), conv_out_size(fw, 7, 2, 3), sdtype)
                          for q in range(0, n, chunk))

@@ -621,3 +621,42 @@ def test_split_stem_at_the_bench_chunk_of_32_frames():
     rev = ops.Act.empty(32, 256, 256, 128, torch.float32, dev)
     plan.from_nchw(torch.flip(x, dims=[0]).contiguous(), rev)
     assert torch.equal(torch.flip(rev.t, dims=[0]), out.t)
+
+
+def test_whole_batch_views_beyond_2_gib_equal_the_chunked_pass():
+    """float32x3 at batch 64: the stem's map of the whole batch is 2.1 GB (fp32 or pair format).  The split-product stem kernel writes it and
+    the patch-resident kernel reads it frame by frame (64-bit frame base, frame-relative 32-bit offsets: include/okp.h), so the stem and
+    pre[1] run as ONE launch each on all 64 frames - same bits as the two 32-frame chunks under the 2 GiB view limit (backbone.BIG_VIEWS);
+    a launch that is not on the patch-resident kernel still refuses such a view."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from object_keypoints_amd.perception.backbone import conv_taps
+    case = cases.NET_CASES["valve_k3"]
+    net = _net(case, ops.F32X3)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    x = torch.randn((64, 3, 511, 511), generator=gen, device="cuda")
+    assert bb.BIG_VIEWS
+    with torch.no_grad():
+        l0 = ops.COUNTERS["launches"]
+        big = [t.clone() for t in net.deployed(x)]
+        n_big = ops.COUNTERS["launches"] - l0
+        bb.BIG_VIEWS = False
+        try:
+            l0 = ops.COUNTERS["launches"]
+            chunked = net.deployed(x)
+            n_chunked = ops.COUNTERS["launches"] - l0
+        finally:
+            bb.BIG_VIEWS = True
+    assert n_chunked == n_big + 3                                 # one stem launch and two pre[1] launches fewer
+    for a, b in zip(big, chunked):
+        assert torch.equal(a, b)
+    # a gather-tile launch on a view of 2 GiB and more is refused
+    w = (torch.randn((256, 128, 1, 1)) / 12).numpy()
+    with ops.f32_split():
+        plan = ops.ConvPlan(torch.float32, [128], [1], 256, conv_taps(w), np.zeros(256, np.float32), relu=True)
+    src = ops.Act(torch.zeros((65, 256, 256, 128), device="cuda"))      # 2.18 GB
+    out = ops.Act.empty(65, 256, 256, 256, torch.float32, "cuda") if False else None
+    with pytest.raises(ops.OkpError, match="2 GiB"):
+        plan([src], ops.Act(torch.empty((1, 256, 256, 256), device="cuda")), 256, 256)
+    del src
+    torch.cuda.empty_cache()
