@@ -38,10 +38,7 @@
 #ifdef OKP_F2_ABL_NOSTORE
 #define F2_STORE(v, rs, off) do { if ((off) == 0x7ffffff0u) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(off), 0, 0); } while (0)
 #else
-#ifndef OKP_F2_STORE_AUX
-#define OKP_F2_STORE_AUX 0         // cache-policy bits of the output stores (experiment builds: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
-#define F2_STORE(v, rs, off) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(off), 0, OKP_F2_STORE_AUX)
+#define F2_STORE(v, rs, off) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(off), 0, 0)
 #endif
 
 
