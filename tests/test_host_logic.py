@@ -634,3 +634,36 @@ def test_camera_helpers_agree_with_the_oracle_restatement():
         np.testing.assert_allclose(np.asarray(p[k], dtype=np.float64), np.asarray(q[k], dtype=np.float64), rtol=0, atol=1e-15)
     stereo = cu.StereoCamera.from_file(calib)
     np.testing.assert_allclose(stereo.F, og.StereoCamera.from_file(calib).F, rtol=1e-12, atol=1e-18)
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/okp.h is the drop-in boundary for ANY host language: it must be valid ISO C99 (no C++-isms, no HIP / torch types), and a C
+    program that includes it links against libokp_hip.so and reads the ABI version - no GPU needed for that call."""
+    import shutil
+    import subprocess
+    from object_keypoints_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler in this environment")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "okp.h"\n'
+                   "int main(void) {\n"
+                   "  okp_conv_args a; okp_fire_args f; okp_head_out_args h; okp_camera c; okp_tap t; okp_tensor v;\n"
+                   "  (void)a; (void)f; (void)h; (void)c; (void)t; (void)v;\n"
+                   '  printf("%d %d %d %d %d %d %d %d\\n", okp_abi_version(), OKP_ABI_VERSION, (int)sizeof(okp_conv_args), (int)sizeof(okp_fire_args),\n'
+                   '         (int)sizeof(okp_head_out_args), (int)sizeof(okp_camera), (int)sizeof(okp_tap), (int)sizeof(okp_tensor));\n'
+                   "  return okp_abi_version() == OKP_ABI_VERSION ? 0 : 1;\n}\n")
+    inc = os.path.join(REPO, "include")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    r = subprocess.run([gcc, "-std=c99", "-I" + inc, str(src), "-o", str(exe), "-L" + libdir, "-lokp_hip", "-Wl,-rpath," + libdir,
+                        "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    version, declared, *sizes = [int(x) for x in r.stdout.split()]
+    import ctypes
+    mirrors = (_lib.okp_conv_args, _lib.okp_fire_args, _lib.okp_head_out_args, _lib.okp_camera, _lib.okp_tap, _lib.okp_tensor)
+    assert version == declared == _lib.OKP_ABI and sizes == [ctypes.sizeof(m) for m in mirrors]      # the ctypes mirrors of the structs have the C layout
