@@ -52,6 +52,15 @@ constexpr int SP = 128;                          // squeeze-tile rows in LDS
 constexpr int PBI = 6;                           // interior pixel blocks of 16 (IP <= 96)
 constexpr int NST = 4;                           // x ring stages
 constexpr int MAXIH = 6;                         // interior rows per tile (depth-wise phase keeps a column's residuals in registers)
+// DWM instances: interior rows per tile (16 columns wide).  5: seven squeeze rows of 18 pixels = 126 <= SP.  Four rows (108 squeeze pixels: seven pixel
+// blocks instead of eight) divide the 64-, 32- and 16-row maps and give the 512 resident workgroups a whole number of tiles at 64 x 64 (8 each; 5-row
+// tiles: 6.5) - measured level at 32 x 32 and 16 x 16 and 5 % slower at 64 x 64 (profiles/r06t_ab_fire2_fixed_geometry.txt): the per-tile fixed
+// cost (eight k-step barriers, the phase changes) outweighs the even split
+#ifndef OKP_F2_DIH
+#define OKP_F2_DIH 5
+#endif
+constexpr int kDwmIH = OKP_F2_DIH;
+static_assert(kDwmIH >= 1 && kDwmIH <= 5, "DWM tile: (rows + 2) x 18 squeeze pixels <= SP");
 // bytes per ring stage.  +64: a depth-wise thread takes its skip values from FOUR stages of one ring row (RING_SKIP: stage = channel group / 4);
 // with stages a multiple of 256 bytes apart those four 64-byte pieces sit in the same banks (4-way conflict), 64 bytes further each they cover
 // the 64 banks once
@@ -131,7 +140,9 @@ template <typename T, int CIN, int MID, int STR, bool DWM = false>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
   static_assert(STR == 1 || STR == 2, "stride of both branches");
   static_assert(!DWM || STR == 1, "depth-wise branch on the matrix pipe: the stride-1 instances");
-  constexpr int DIH = 5;                           // DWM: interior rows per tile (7 squeeze rows of 18 pixels = 126 <= SP)
+  constexpr int DIH = kDwmIH;                      // DWM: interior rows per tile, 16 columns wide: (DIH + 2) squeeze rows of DSW = 18 pixels
+  constexpr int DSW = 18;
+  constexpr int NSB = DWM ? ((DIH + 2) * DSW + 15) / 16 : SP / 16;   // pixel blocks of the squeeze GEMM (the ring keeps its SP / 16 row blocks)
   constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
   constexpr int NT = 64 * NW;
   constexpr int HALF = MID;
@@ -390,9 +401,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 
     // ---- phase 1: s = W1 x + b1 on the halo'd tile, x through the LDS ring -------------------------------------
     // The first NST-1 ring steps of this tile were issued during the previous tile's phase 2 (or above).
-    f32x4 acc[SP / 16][2];
+    f32x4 acc[NSB][2];
 #pragma unroll
-    for (int pb = 0; pb < SP / 16; ++pb) {
+    for (int pb = 0; pb < NSB; ++pb) {
       acc[pb][0] = b1v0;
       acc[pb][1] = b1v1;
     }
@@ -424,15 +435,15 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       else if constexpr (!RES) { if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % 3]); }
       if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
       const char* st = smem + OFF_X + (ks % NST) * XST + xfrag_off;
-      u32x4 a[SP / 16], wr[2] = {};
+      u32x4 a[NSB], wr[2] = {};
       if constexpr (WRING) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) wr[b] = *reinterpret_cast<const u32x4*>(smem + OFF_W1 + ((ks % DW) * NW + w) * 2048 + b * 1024 + lane * 16);
       }
 #pragma unroll
-      for (int pb = 0; pb < SP / 16; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
+      for (int pb = 0; pb < NSB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
 #pragma unroll
-      for (int pb = 0; pb < SP / 16; ++pb)
+      for (int pb = 0; pb < NSB; ++pb)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           acc[pb][b] = H16<T>::mfma16(WRING ? wr[b] : w1f[RES ? ks : ks % 3][b], a[pb], acc[pb][b]);
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) mq[i] = mk[i] >> l16t;
 #pragma unroll
-      for (int pb = 0; pb < SP / 16; ++pb) {
+      for (int pb = 0; pb < NSB; ++pb) {
         const bool ok = (mq[pb >> 1] >> (16 * (pb & 1))) & 1u;
         u32x4 v;
 #pragma unroll
@@ -477,7 +488,54 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     __syncthreads();
     F2_STAMP(2);
     // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
-    {
+    uint32_t dwm_o[DIH];                                    // DWM: output offset of this lane's pixel (row iy, column l16), channels chq ..
+    if constexpr (DWM) {
+      // Fixed geometry (pixel block = interior row, 16 columns, map width a multiple of 16): a pixel's offsets are a lane constant plus a
+      // wave-uniform row term, the only edge is the map's last row (wave-uniform) - no table reads, no per-block branches, and with every
+      // trip count known the fragment reads of a k-step are all in flight before its MFMAs (the general form below has a tile-shape
+      // condition per block: ds_read -> s_waitcnt -> 2 MFMAs chains, 5.3 k clocks for 768 of matrix pipe: profiles/r05g_fire2_stamps.txt)
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
+      const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
+      const uint32_t lane_x = (uint32_t)l16t * (uint32_t)(p.x_ps * 2) + (uint32_t)chq * 2u, lane_o = (uint32_t)l16t * (uint32_t)(p.out_ps * 2) + (uint32_t)chq * 2u;
+      u32x4 rsk[DIH];
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) {
+        const bool ok = iy < p.IH && y0 + iy < p.Ho;                                        // wave-uniform
+        const uint32_t sx = ok ? (pix0 + (uint32_t)(iy * p.W)) * (uint32_t)(p.x_ps * 2) : kInvalid;
+        const uint32_t so = ok ? (pix0 + (uint32_t)(iy * p.Wo)) * (uint32_t)(p.out_ps * 2) : kInvalid;
+        dwm_o[iy] = lane_o + so;                                                            // (kInvalid + a lane term stays beyond every view)
+        rsk[iy] = u32x4{0u, 0u, 0u, 0u};
+        if (p.skip) rsk[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(lane_x + sx), 0, 0);
+      }
+      f32x4 ac2[DIH][2];
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) {
+        ac2[iy][0] = bav0;
+        ac2[iy][1] = bav1;
+      }
+      // squeeze pixel of (iy, l16): row (iy + 1) DSW + 1 + l16 of the LDS tile
+      const uint32_t s_lane = (uint32_t)OFF_S + (uint32_t)(DSW + 1 + l16t) * (uint32_t)(MID * 2);
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        u32x4 a[DIH];
+#pragma unroll
+        for (int iy = 0; iy < DIH; ++iy) {
+          const uint32_t key = (uint32_t)(l16t + (iy + 1) * DSW + 1) & (uint32_t)SWM;
+          a[iy] = *reinterpret_cast<const u32x4*>(smem + s_lane + (uint32_t)(iy * DSW * MID * 2) + (((uint32_t)(4 * ks + qt) ^ key) << 4));
+        }
+#pragma unroll
+        for (int iy = 0; iy < DIH; ++iy)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            ac2[iy][b] = H16<T>::mfma16(waf[b][ks], a[iy], ac2[iy][b]);
+      }
+#pragma unroll
+      for (int iy = 0; iy < DIH; ++iy) {
+        const u32x4 v = relu_add_pack8<T>(ac2[iy][0], ac2[iy][1], rsk[iy]);
+        F2_STORE(v, rs_o, dwm_o[iy]);
+      }
+    } else {
       // residuals first: their latency hides behind the MFMAs.  Interior tiles take the byte offsets of their
       // pixels from the per-workgroup table (one 16-byte LDS read per block); edge tiles do the arithmetic.
       const bool full = y0 + p.IH <= p.Ho && x0 + p.IW <= p.Wo;
@@ -535,29 +593,21 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       // On the matrix pipe (see the kernel's head).  Lane (l16 = pixel column ix = row i of the A operand, q): channels chq .. chq + 7.
       int l16t = l16;
       asm volatile("" : "+v"(l16t));
-      const bool full = y0 + p.IH <= p.Ho && x0 + p.IW <= p.Wo;
-      const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
-      const uint32_t ob = pix0 * (uint32_t)(p.out_ps * 2) + (uint32_t)(HALF + chq) * 2u;
       u32x4 rr2[DIH];
       uint32_t oo2[DIH];
 #pragma unroll
       for (int iy = 0; iy < DIH; ++iy) {
-        const int ip = 16 * iy + l16t;
-        uint32_t orr = kInvalid, xr = kInvalid;
-        if (iy < p.IH) {
-          orr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + (96 + ip) * 4);
-          xr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + ip * 4);
-          if (!full && (y0 + iy >= p.Ho || x0 + l16t >= p.Wo)) { orr = kInvalid; xr = kInvalid; }
-        }
-        oo2[iy] = orr == kInvalid ? kInvalid : ob + orr;
+        oo2[iy] = dwm_o[iy] + (uint32_t)(HALF * 2);          // the same pixel's second half of the channels
         rr2[iy] = u32x4{0u, 0u, 0u, 0u};
-        if (p.skip && iy < p.IH) {
-          if constexpr (RING_SKIP) {      // x[:, MID + chq ..] = k-step KS1/2 + w of the ring, chunk q of squeeze row (iy + 1, ix + 1)
-            const int row = (iy + 1) * p.SW + l16t + 1;
-            rr2[iy] = *reinterpret_cast<const u32x4*>(smem + OFF_X + ((KS1 / 2 + w) % NST) * XST + row * 64 + ((qt + 2 * (row >> 2)) & 3) * 16);
+        if (p.skip) {
+          if constexpr (RING_SKIP) {      // x[:, MID + chq ..] = k-step KS1/2 + w of the ring, chunk q of squeeze row (iy + 1, ix + 1); rows beyond the tile: never stored
+            const uint32_t row = (uint32_t)((iy + 1) * DSW + 1) + (uint32_t)l16t;
+            rr2[iy] = *reinterpret_cast<const u32x4*>(smem + OFF_X + ((KS1 / 2 + w) % NST) * XST + row * 64u + (((uint32_t)qt + 2u * (row >> 2)) & 3u) * 16u);
           } else {
-            const uint32_t xb2 = pix0 * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + chq) * 2u;
-            rr2[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xr == kInvalid ? kInvalid : xb2 + xr), 0, 0);
+            const bool ok = iy < p.IH && y0 + iy < p.Ho;
+            const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
+            const uint32_t sx = ok ? (pix0 + (uint32_t)(iy * p.W)) * (uint32_t)(p.x_ps * 2) : kInvalid;
+            rr2[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((uint32_t)l16t * (uint32_t)(p.x_ps * 2) + (uint32_t)(HALF + chq) * 2u + sx), 0, 0);
           }
         }
       }
@@ -602,7 +652,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
         u32x4 bf[DIH + 2];
 #pragma unroll
         for (int r = 0; r < DIH + 2; ++r) {
-          const uint32_t sp = (uint32_t)(r * p.SW + dx) + (uint32_t)l16t;
+          const uint32_t sp = (uint32_t)(r * DSW + dx) + (uint32_t)l16t;
           bf[r] = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (MID * 2) + ((cx ^ (sp & SWM)) << 4));
         }
 #pragma unroll
@@ -766,13 +816,13 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
       const long score = ty * tx * 4096 - iw;
       if (best < 0 || score < best) { best = score; p.IH = ih; p.IW = iw; p.SH = sh; p.SW = sw; p.tiles_y = (int)ty; p.tiles_x = (int)tx; }
     }
-  // the 256 -> 128 stride-1 instance on maps whose width is a multiple of 16: tiles of 5 x 16 interior pixels, depth-wise branch on the matrix
+  // the 256 -> 128 stride-1 instance on maps whose width is a multiple of 16: tiles of kDwmIH x 16 interior pixels, depth-wise branch on the matrix
   // pipe (okp_fire2_kernel<..., DWM>; OKP_F2_DWM=0 keeps the vector-ALU form for A/B)
   static const bool dwm_on = [] { const char* e = getenv("OKP_F2_DWM"); return !(e && e[0] == '0'); }();
   static const int dwm_mid = [] { const char* e = getenv("OKP_F2_DWM_MID"); return e ? atoi(e) : 256; }();      // (A/B: largest squeeze width that takes it)
   const bool dwm = dwm_on && stride == 1 && p.Wo % 16 == 0 && mid <= dwm_mid;
   if (dwm) {
-    p.IH = p.Ho < 5 ? p.Ho : 5; p.IW = 16; p.SH = p.IH + 2; p.SW = 18;
+    p.IH = p.Ho < kDwmIH ? p.Ho : kDwmIH; p.IW = 16; p.SH = p.IH + 2; p.SW = 18;
     p.tiles_y = (p.Ho + p.IH - 1) / p.IH; p.tiles_x = p.Wo / 16;
   }
   p.IP = p.IH * p.IW;
