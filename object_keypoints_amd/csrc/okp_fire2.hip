@@ -121,9 +121,11 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
 // Debug build (OKP_EXTRA_CFLAGS=-DOKP_FIRE_STAMPS, printed with OKP_FIRE_STAMPS_PRINT=1; scripts/probe_fire2.py): shader-clock stamps of every
 // wave at the phase boundaries of its workgroup's SECOND tile, workgroups 0..15: [wg][wave 8][8] u32.  OKP_FIRE_NOSKIP=1: timing ablation
 // without the skip requests (wrong results).
+#define F2_STAMP_ANY(i) do { if (lane == 0 && blockIdx.x < 16) { uint64_t t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(blockIdx.x * 8 + w) * 8 + (i)] = (uint32_t)t_; } } while (0)
 #define F2_STAMP(i) do { if (second && lane == 0 && blockIdx.x < 16) { uint64_t t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(blockIdx.x * 8 + w) * 8 + (i)] = (uint32_t)t_; } } while (0)
 #else
 #define F2_STAMP(i) do {} while (0)
+#define F2_STAMP_ANY(i) do {} while (0)
 #endif
 
 // DWM: the depth-wise branch on the MATRIX pipe (stride 1, interior tiles 16 pixels wide).  The kernel is bound by vector-ALU issue
@@ -172,12 +174,27 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   // 2-3 us to return under load, most of the expand phase's 5.3 k clocks (profiles/r05g_fire2_stamps.txt: 48 MFMAs = 768 clocks of pipe).
   // OKP_F2_RESIDENT_WA: the 256 -> 128 instance keeps them in registers for the whole kernel (32 per lane) and gives the depth-wise phase
   // smaller read batches in exchange.
+  // (-DOKP_F2_RESWA=1: the matrix-pipe depth-wise 256 -> 128 instance only; 64 x 64 alone 66.5 -> 64.6 us, 32 x 32 and the step level:
+  //  profiles/r06t_ab_fire2_prologue_pack.txt; the stride-2 instance loses 7 % with resident expand weights)
+#ifndef OKP_F2_RESWA
+#define OKP_F2_RESWA 0
+#endif
 #ifdef OKP_F2_RESIDENT_WA
   constexpr bool RESWA = CIN == 256 && MID == 128;
 #else
-  constexpr bool RESWA = false;
+  constexpr bool RESWA = OKP_F2_RESWA && DWM && CIN == 256 && MID == 128;
 #endif
   constexpr bool WRING = !RES && MID >= 192;
+  // PIPE (-DOKP_F2_PIPE=1, an experiment that stays in the source): the squeeze k-loop software-pipelined by one step - behind barrier ks come the
+  // requests, the fragment reads of step ks and THEN the MFMAs of step ks - 1, which cover the reads' latency (two fragment sets, four rotating
+  // weight sets; 234 registers).  Left alone hipcc sinks a step's MFMAs below the next barrier too, but feeds them from two fragment registers
+  // (ds_read x 2 -> s_waitcnt -> 4 MFMAs, four times per step).  Measured level to 1.5 % SLOWER (64 x 64 alone 69.9 -> 71.1 us,
+  // profiles/r06t_ab_fire2_pipeline_resident_wa.txt): the k-loop does not wait for its fragment reads - the other workgroup of the CU fills the gaps.
+#ifndef OKP_F2_PIPE
+#define OKP_F2_PIPE 0
+#endif
+  constexpr bool PIPE = OKP_F2_PIPE && DWM && CIN == 256 && MID == 128 && !RES && !WRING;
+  constexpr int NWS = PIPE ? 4 : 3;                // rotating squeeze-weight sets
   constexpr int DW = !WRING ? 0 : MID == 192 ? 5 : 3;
   constexpr int SWM = ((MID / 8) % 16 == 0) ? 15 : 7;   // swizzle key bits (chunks per row must be a multiple of key range)
   constexpr int CG = MID / 8;                      // 8-channel groups of the depth-wise branch; NT / CG = 16 column slots
@@ -204,15 +221,18 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   const int chq = 32 * w + 8 * q;                           // this lane's eight channels chq .. chq + 7 (block b, register r: chq + 4 b + r) in both GEMMs
   // weights in fragment order [wave][block b][k-step][lane][16 B] (okp_ensure_frags): one load = 1 KiB contiguous per
   // wave (the packed plan layout would give 16 separate 64-byte segments per load: measured 4x slower to stream)
-  const u32x4* const w1_lane = static_cast<const u32x4*>(p.w1) + (size_t)w * 2 * KS1 * 64 + lane;
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, NW * 2 * KS1 * 1024, 0x00020000);
+  const uint32_t w1_voff = (uint32_t)lane * 16u;
   auto load_w1 = [&](int ks, u32x4 (&dst)[2]) {
 #ifdef OKP_F2_ABL_NOWEIGHTS        // timing ablation (wrong results): every k-step multiplies with the weights of k-step 0, requested once per tile
     if (ks != 0) { dst[0] = u32x4{0x3c003c00u, 0u, 0u, 0u}; dst[1] = dst[0]; return; }
 #endif
+    // (buffer loads: ONE lane offset register + a scalar offset per fragment; as global loads every fragment beyond the 4 KiB immediate range
+    //  had its own 64-bit pointer pair, kept in registers across the whole k-loop - a dozen pairs)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) dst[b] = w1_lane[(size_t)(b * KS1 + ks) * 64];
+    for (int b = 0; b < 2; ++b)
+      dst[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_w1, (int)w1_voff, (int)(((uint32_t)(w * 2 + b) * KS1 + (uint32_t)ks) * 1024u), 0);
   };
-  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, NW * 2 * KS1 * 1024, 0x00020000);
   auto issue_w = [&](int ks) {                                // this wave's two fragment blocks of k-step ks -> ring slot ks % DW
     if constexpr (WRING) {
 #pragma unroll
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
                                                  (int)(((uint32_t)(w * 2 + b) * KS1 + (uint32_t)ks) * 1024u + (uint32_t)lane * 16u), 0, 0, 0);
     }
   };
-  auto first_weights = [&](u32x4 (&f)[RES ? KS1 : 3][2]) {    // what a tile needs before its k-loop starts
+  auto first_weights = [&](u32x4 (&f)[RES ? KS1 : NWS][2]) {    // what a tile needs before its k-loop starts
     if constexpr (WRING) {
 #pragma unroll
       for (int ks = 0; ks < DW; ++ks) issue_w(ks);
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       load_w1(0, f[0]); load_w1(1, f[1]);
     }
   };
-  u32x4 w1f[RES ? KS1 : 3][2];                                // resident: all k-steps; streamed: three rotating sets
+  u32x4 w1f[RES ? KS1 : NWS][2];                              // resident: all k-steps; streamed: three (PIPE: four) rotating sets
   if constexpr (RES) {
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) load_w1(ks, w1f[ks]);
@@ -244,22 +264,6 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
   }
   const f32x4 b1v0 = *reinterpret_cast<const f32x4*>(p.b1 + chq), b1v1 = *reinterpret_cast<const f32x4*>(p.b1 + chq + 4);
   const f32x4 bav0 = *reinterpret_cast<const f32x4*>(p.ba + chq), bav1 = *reinterpret_cast<const f32x4*>(p.ba + chq + 4);
-  for (int i = tid; i < 10 * HALF; i += NT) {
-    if constexpr (DWM) {
-      // [tap][channel]: the weight rounded to T, in the half of the dword its channel's parity selects (the A operand's element), bias as fp32
-      if (i < 9 * HALF) reinterpret_cast<uint32_t*>(smem + OFF_WD)[i] = (i & 1) ? okp_pack2<T>(0.f, p.wd[i]) : okp_pack2<T>(p.wd[i], 0.f);
-      else reinterpret_cast<float*>(smem + OFF_WD)[i] = p.bd[i - 9 * HALF];
-    } else {
-      reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * HALF ? p.wd[i] : p.bd[i - 9 * HALF];
-    }
-  }
-  if (tid < 16 * PBI) {
-    const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
-    // (the x table serves the skip connection: stride 1, where input and output geometry coincide)
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? (uint32_t)(iy * p.W + ix) * (uint32_t)(p.x_ps * 2) : kInvalid;
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? (uint32_t)(iy * p.Wo + ix) * (uint32_t)(p.out_ps * 2) : kInvalid;
-  }
-
   // interior pixel block pb, row l16 -> squeeze-tile row (constant over tiles: depends on the tile geometry only)
   uint32_t a_row[PBI], a_key[PBI];
 #pragma unroll
@@ -341,11 +345,45 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
 
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
-  __syncthreads();                                           // depth-wise constants are in LDS
+  F2_STAMP_ANY(5);
+  // the first tile's requests go out BEFORE the per-workgroup constants are fetched: both are cold reads (2-3 us each right behind a launch, when
+  // every workgroup asks at once), and one behind the other they cost every launch that time twice - 30 launches per network pass
   tile_setup(tile);
   first_weights(w1f);
 #pragma unroll
   for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+  // ---- once per workgroup: depth-wise constants and the pixel tables -> LDS (first read behind the k-loop's barriers) ----
+  {
+    // 10 HALF values = 5 per thread (NT = 2 HALF), all five loads in flight before the first is used (as a loop hipcc waited for each by itself:
+    // five cold-read latencies in front of every launch's first tile - 6.8 k of the 35 k clocks of a 32 x 32 launch, profiles/r06t_fire2_stamps.txt)
+    static_assert(10 * HALF == 5 * NT, "depth-wise constants per thread");
+    float cv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = tid + k * NT;
+      cv[k] = *(i < 9 * HALF ? p.wd + i : p.bd + (i - 9 * HALF));
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = tid + k * NT;
+      if constexpr (DWM) {
+        // [tap][channel]: the weight rounded to T, in the half of the dword its channel's parity selects (the A operand's element), bias as fp32
+        const uint32_t wq = (i & 1) ? okp_pack2<T>(0.f, cv[k]) : okp_pack2<T>(cv[k], 0.f);
+        reinterpret_cast<uint32_t*>(smem + OFF_WD)[i] = i < 9 * HALF ? wq : __builtin_bit_cast(uint32_t, cv[k]);
+      } else {
+        reinterpret_cast<float*>(smem + OFF_WD)[i] = cv[k];
+      }
+    }
+  }
+  if (tid < 16 * PBI) {
+    const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
+    // (the x table serves the skip connection: stride 1, where input and output geometry coincide)
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? (uint32_t)(iy * p.W + ix) * (uint32_t)(p.x_ps * 2) : kInvalid;
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? (uint32_t)(iy * p.Wo + ix) * (uint32_t)(p.out_ps * 2) : kInvalid;
+  }
+
+  __syncthreads();
+  F2_STAMP_ANY(6);
 
   for (; tile < p.n_tiles; tile += gridDim.x) {
     int n, y0, x0;
@@ -407,6 +445,34 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       acc[pb][0] = b1v0;
       acc[pb][1] = b1v1;
     }
+    if constexpr (PIPE) {
+      // at the top of step ks >= 3 the queue holds, behind x(ks): w(ks), x(ks + 1), w(ks + 1), x(ks + 2) - all of them may stay in flight
+      // (the register loads of the weights are waited for by the compiler where their MFMAs are)
+      u32x4 a[2][NSB];
+#pragma unroll
+      for (int ks = 0; ks <= KS1; ++ks) {
+        if (ks < KS1) {
+          if (ks == 0) wait_vm(0);
+          else if (ks >= 3) wait_vm(2 + (ks + 1 < KS1 ? nd + 2 : 0) + (ks + 2 < KS1 ? nd : 0));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (ks + 2 < KS1) load_w1(ks + 2, w1f[(ks + 2) % NWS]);
+          if (ks + NST - 1 < KS1) issue_x(ks + NST - 1, (ks + NST - 1) % NST);
+          const char* st = smem + OFF_X + (ks % NST) * XST + xfrag_off;
+#pragma unroll
+          for (int pb = 0; pb < NSB; ++pb) a[ks & 1][pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ks > 0) {
+#pragma unroll
+          for (int pb = 0; pb < NSB; ++pb)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[pb][b] = H16<T>::mfma16(w1f[(ks - 1) % NWS][b], a[(ks - 1) & 1][pb], acc[pb][b]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       // ks == 0: everything older (the previous tile's stores, the prefetched steps and weight sets) must be done,
@@ -442,6 +508,9 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       }
 #pragma unroll
       for (int pb = 0; pb < NSB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(st + pb * 1024);
+#ifdef OKP_F2_PIN_READS
+      __builtin_amdgcn_sched_barrier(0);       // every fragment read of the step in flight before its first MFMA (hipcc otherwise issues them two at a time)
+#endif
 #pragma unroll
       for (int pb = 0; pb < NSB; ++pb)
 #pragma unroll
@@ -499,14 +568,16 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
       const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
       const uint32_t lane_x = (uint32_t)l16t * (uint32_t)(p.x_ps * 2) + (uint32_t)chq * 2u, lane_o = (uint32_t)l16t * (uint32_t)(p.out_ps * 2) + (uint32_t)chq * 2u;
       u32x4 rsk[DIH];
+      // (branch-free: a row outside the map - or a module without skip - turns into an offset beyond every view: the load returns zeros, the store is dropped)
+      const uint32_t rowx = (uint32_t)(p.W * p.x_ps * 2), rowo = (uint32_t)(p.Wo * p.out_ps * 2), noskip = p.skip ? 0u : kInvalid;
+      uint32_t sx = pix0 * (uint32_t)(p.x_ps * 2), so = pix0 * (uint32_t)(p.out_ps * 2);
 #pragma unroll
       for (int iy = 0; iy < DIH; ++iy) {
-        const bool ok = iy < p.IH && y0 + iy < p.Ho;                                        // wave-uniform
-        const uint32_t sx = ok ? (pix0 + (uint32_t)(iy * p.W)) * (uint32_t)(p.x_ps * 2) : kInvalid;
-        const uint32_t so = ok ? (pix0 + (uint32_t)(iy * p.Wo)) * (uint32_t)(p.out_ps * 2) : kInvalid;
-        dwm_o[iy] = lane_o + so;                                                            // (kInvalid + a lane term stays beyond every view)
-        rsk[iy] = u32x4{0u, 0u, 0u, 0u};
-        if (p.skip) rsk[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(lane_x + sx), 0, 0);
+        const uint32_t bad = (iy < p.IH && y0 + iy < p.Ho) ? 0u : kInvalid;                 // wave-uniform (valid offsets are < 2 GiB)
+        dwm_o[iy] = lane_o + (so | bad);
+        rsk[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(lane_x + (sx | bad | noskip)), 0, 0);
+        sx += rowx;
+        so += rowo;
       }
       f32x4 ac2[DIH][2];
 #pragma unroll
@@ -788,6 +859,7 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     F2_STAMP(4);
     // no barrier here: phase 2 does not read what the next tile's phase 1 writes before its own barriers
   }
+  F2_STAMP_ANY(7);
 }
 
 }  // namespace
@@ -859,6 +931,10 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
         ++cnt;
       }
     if (cnt) printf("mean: %.0f | %.0f | %.0f | %.0f  = %.0f clocks per tile\n", sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, (sum[0] + sum[1] + sum[2] + sum[3]) / cnt);
+    double pro = 0, all = 0; int c2 = 0;
+    for (int wg = 0; wg < 16; ++wg)
+      for (int w = 0; w < nw; ++w) { const uint32_t* a = &h[(wg * 8 + w) * 8]; if (!a[7]) continue; pro += a[6] - a[5]; all += a[7] - a[5]; ++c2; }
+    if (c2) printf("whole kernel: prologue (first requests + constants -> LDS + barrier) %.0f clocks, entry to exit %.0f clocks\n", pro / c2, all / c2);
   } } print_at_exit{p, mid, stream, dbg};
 #endif
   if (stride == 1) {

@@ -81,17 +81,6 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
     for (int ks = 0; ks < KS1; ++ks) { w1h[ks] = w1[ks * 64]; w1l[ks] = w1[(KS1 + ks) * 64]; }
   }
   const u32x4* const wa_lane = static_cast<const u32x4*>(p.wa) + (size_t)w * 2 * KS2 * 64 + lane;      // expand weights: re-fetched per tile (L2)
-  if (tid < MID) {
-    float* const bs = reinterpret_cast<float*>(smem + OFF_BS);
-    bs[tid] = p.b1[tid]; bs[MID + tid] = p.s1[tid]; bs[2 * MID + tid] = p.ba[tid]; bs[3 * MID + tid] = p.sa[tid];
-  }
-  for (int i = tid; i < 10 * MID; i += NT)
-    reinterpret_cast<float*>(smem + OFF_WD)[i] = i < 9 * MID ? p.wd[i] : p.bd[i - 9 * MID];
-  if (tid < 16 * PBI) {
-    const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? (uint32_t)(iy * p.W + ix) * (uint32_t)(p.x_ps * 4) : kInvalidOff;
-    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? (uint32_t)(iy * p.Wo + ix) * (uint32_t)(p.out_ps * 4) : kInvalidOff;
-  }
   // ring fragment read: row 16 pb + l16, this lane's hi chunk (logical 2q) at position 2q ^ key(row); key depends on l16 only
   const uint32_t xfrag_off = (uint32_t)l16 * 128u + (((uint32_t)(2 * q) ^ ring_key(l16)) << 4);
   const uint32_t xfrag_lo = xfrag_off ^ 16u;                  // its lo chunk: the other one of the aligned pair
@@ -155,10 +144,36 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
   int tile = blockIdx.x;
   if (tile >= p.n_tiles) return;
   int stores_behind_ring = 0;                                // stores this wave issued behind its ring requests of the tile about to start
-  __syncthreads();                                           // depth-wise constants and tables are in LDS
+  // the first tile's requests go out BEFORE the per-workgroup constants are fetched (both are cold reads right behind a launch), and the
+  // constants' loads are all in flight before the first is used (as a loop hipcc waited for each load by itself): okp_fire2.hip, round 6
   tile_setup(tile);
 #pragma unroll
   for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+  {
+    constexpr int NC = (10 * MID + NT - 1) / NT;
+    float cv[NC], bsv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int i = tid + k * NT;
+      cv[k] = i < 10 * MID ? *(i < 9 * MID ? p.wd + i : p.bd + (i - 9 * MID)) : 0.f;
+    }
+    if (tid < MID) { bsv[0] = p.b1[tid]; bsv[1] = p.s1[tid]; bsv[2] = p.ba[tid]; bsv[3] = p.sa[tid]; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int i = tid + k * NT;
+      if (i < 10 * MID) reinterpret_cast<float*>(smem + OFF_WD)[i] = cv[k];
+    }
+    if (tid < MID) {
+      float* const bs = reinterpret_cast<float*>(smem + OFF_BS);
+      bs[tid] = bsv[0]; bs[MID + tid] = bsv[1]; bs[2 * MID + tid] = bsv[2]; bs[3 * MID + tid] = bsv[3];
+    }
+  }
+  if (tid < 16 * PBI) {
+    const int iy = fastdiv(tid, p.div_iw), ix = tid - iy * p.IW;
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[tid] = tid < p.IP ? (uint32_t)(iy * p.W + ix) * (uint32_t)(p.x_ps * 4) : kInvalidOff;
+    reinterpret_cast<uint32_t*>(smem + OFF_TAB)[96 + tid] = tid < p.IP ? (uint32_t)(iy * p.Wo + ix) * (uint32_t)(p.out_ps * 4) : kInvalidOff;
+  }
+  __syncthreads();                                           // depth-wise constants and tables are in LDS
 
   for (; tile < p.n_tiles; tile += gridDim.x) {
     int n, y0, x0;

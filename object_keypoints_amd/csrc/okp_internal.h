@@ -109,9 +109,11 @@ static __device__ __forceinline__ void okp_raise_range_flag(int32_t* flag, bool 
 }
 
 template <typename T> __device__ __forceinline__ uint32_t okp_pack2(float a, float b) {     // two fp32 -> one packed dword (RNE)
-  typename H16<T>::x2 v;
-  v[0] = (T)a; v[1] = (T)b;
-  return __builtin_bit_cast(uint32_t, v);
+  // ONE vector conversion (v_cvt_pk_{bf16,f16}_f32 d, a, b).  Two scalar conversions packed afterwards are the same instruction only as long as
+  // nothing else touches the dword: with a packed integer operation behind it (the 16-bit ReLU of okp_fire2's epilogue) hipcc converted each
+  // value by itself and joined the halves with a v_perm_b32 - three instructions per pair
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, typename H16<T>::x2));
 }
 inline int okp_esz(int dtype) { return (dtype == OKP_F32 || dtype == OKP_F32X3) ? 4 : 2; }
 inline bool okp_is16(int dtype) { return dtype == OKP_BF16 || dtype == OKP_F16; }
