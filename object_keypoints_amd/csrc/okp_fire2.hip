@@ -877,17 +877,32 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride) {
 
 template <typename T>
 static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStream_t stream) {
-  // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the
-  // squeeze pixels computed per frame (halo + partial tiles), ties -> wider rows
+  // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels.  First the rounds of the persistent grid; then,
+  // with several rounds, the fewest tiles (least halo), ties -> wider rows - and with ONE round the smallest tile, because the launch then takes one
+  // tile's time: at 16 x 16 -> 8 x 8 (N = 64) 2 x 8 tiles (256, one per CU; 16.9 us) instead of 3 x 8 (192: a quarter of the CUs idle; 19.0 us).
+  // (A cost model - rounds x (squeeze pixels + a fixed part) - chose 4 x 6 at 64 x 64 -> 32 x 32 and lost 6 % there: the depth-wise phase's cost
+  //  follows rows per thread and active column slots, not pixels.  profiles/r06w_fire2_stride2_tiles.txt)
+  const long resident_wg = 256 * (mid == 128 ? 2 : 1);
   long best = -1;
   for (int ih = 1; ih <= p.Ho && ih <= MAXIH; ++ih)
     for (int iw = 1; iw <= p.Wo && iw <= 96; ++iw) {
       const int sh = stride * (ih - 1) + 3, sw = stride * (iw - 1) + 3;
       if (sh * sw > SP || ih * iw > 16 * PBI) continue;
       const long ty = (p.Ho + ih - 1) / ih, tx = (p.Wo + iw - 1) / iw;
-      const long score = ty * tx * 4096 - iw;
+      const long rounds = ((long)p.N * ty * tx + resident_wg - 1) / resident_wg;
+      // (one round: squeeze pixels + 8 per idle column slot of the depth-wise phase - 2 x 8 before 4 x 4, measured 16.9 / 17.4 us)
+      const long score = (rounds << 40) + (rounds == 1 ? (long)sh * sw + 8 * (16 - (iw < 16 ? iw : 16)) : ty * tx) * 4096 - iw;
       if (best < 0 || score < best) { best = score; p.IH = ih; p.IW = iw; p.SH = sh; p.SW = sw; p.tiles_y = (int)ty; p.tiles_x = (int)tx; }
     }
+  // (experiment switch: OKP_F2_S2_TILE="ih,iw" forces the interior rectangle of the stride-2 launches)
+  if (stride == 2) {
+    static const char* const e = getenv("OKP_F2_S2_TILE");
+    int ih = 0, iw = 0;
+    if (e && sscanf(e, "%d,%d", &ih, &iw) == 2 && ih >= 1 && ih <= MAXIH && iw >= 1 && (2 * (ih - 1) + 3) * (2 * (iw - 1) + 3) <= SP && ih * iw <= 16 * PBI) {
+      p.IH = ih < p.Ho ? ih : p.Ho; p.IW = iw < p.Wo ? iw : p.Wo; p.SH = 2 * (p.IH - 1) + 3; p.SW = 2 * (p.IW - 1) + 3;
+      p.tiles_y = (p.Ho + p.IH - 1) / p.IH; p.tiles_x = (p.Wo + p.IW - 1) / p.IW;
+    }
+  }
   // the 256 -> 128 stride-1 instance on maps whose width is a multiple of 16: tiles of kDwmIH x 16 interior pixels, depth-wise branch on the matrix
   // pipe (okp_fire2_kernel<..., DWM>; OKP_F2_DWM=0 keeps the vector-ALU form for A/B)
   static const bool dwm_on = [] { const char* e = getenv("OKP_F2_DWM"); return !(e && e[0] == '0'); }();

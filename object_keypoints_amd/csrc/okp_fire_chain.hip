@@ -17,6 +17,8 @@
 // the start of the module.
 #include <cstring>
 
+#include <type_traits>
+
 #include "okp_internal.h"
 
 namespace {
@@ -80,31 +82,35 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
   const int HW = p.H * p.W;
   const int ch0 = 32 * w + 2 * l16;                    // this lane's channel pair in both GEMMs
 
-  // frame -> LDS (buffer 0), squeeze tile cleared once: its halo stays zero for the whole chain
+  // frame -> LDS (buffer 0), squeeze tile cleared once: its halo stays zero for the whole chain.
+  // Prologue order (round 6): everything the first module waits for is requested BEFORE anything is waited for - its constants (LDS-DMA), its
+  // first PF weight fragments (registers) and the frame (LDS-DMA).  As a plain loop hipcc compiled the frame copy to
+  // `global_load -> s_waitcnt vmcnt(0) -> ds_write` per iteration (6-8 cold reads one behind the other), followed by the constants' round trip and
+  // the fragments' round trip: ~10 memory latencies in front of a 25-70 us kernel.
   const int HWe = p.He * p.We;                          // (EE) pixels of the entry module's input map
-  if constexpr (EE) {
-    const char* src = static_cast<const char*>(p.x) + (size_t)n * HWe * p.x_ps * 2;
-    for (int i = tid; i < C::ENPX * (C::ECIN / 8); i += NT) {
-      const int px = i / (C::ECIN / 8), c = i % (C::ECIN / 8);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (px < HWe) v = *reinterpret_cast<const u32x4*>(src + (size_t)px * p.x_ps * 2 + c * 16);
-      *reinterpret_cast<u32x4*>(smem + C::OFF_X + xoff<15>(px, c, C::EXROW)) = v;
+  auto stage_frame = [&](auto ncin_c, auto npx_c, auto key_c, int n_valid) {
+    // by LDS-DMA (no registers, nothing waits): instruction k fills the LDS bytes [1024 k, +1024) of the buffer - row px = i / NCH, chunk POSITION
+    // pos = i % NCH for lane index i = 64 k + lane - so the lane fetches the chunk that belongs there, c = pos ^ (px & KEY); pixels beyond the map
+    // read zeros through an out-of-range offset
+    constexpr int NCH = decltype(ncin_c)::value / 8, TOT = decltype(npx_c)::value * NCH, KEYV = decltype(key_c)::value, NINST = TOT / 64;
+    static_assert(TOT % 64 == 0 && NCH % (KEYV + 1) == 0, "whole LDS-DMA instructions, swizzle inside the row");
+    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.x) + (size_t)n * n_valid * p.x_ps * 2), 0,
+                                                                         n_valid * p.x_ps * 2, 0x00020000);
+#pragma unroll
+    for (int k0 = 0; k0 < NINST; k0 += C::NW) {
+      const int k = k0 + w;
+      if (k < NINST) {
+        const int i = 64 * k + lane;
+        const int px = i / NCH, pos = i % NCH;
+        const int c = pos ^ (px & KEYV);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(smem + C::OFF_X + k * 1024), 16,
+                                                 (int)(px < n_valid ? (uint32_t)(px * p.x_ps * 2 + c * 16) : 0x80000000u), 0, 0, 0);
+      }
     }
-    for (int i = tid; i < C::ESROWS * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
-  } else {
-    const char* src = static_cast<const char*>(p.x) + (size_t)n * HW * p.x_ps * 2;
-    for (int i = tid; i < NPX * (CIN / 8); i += NT) {
-      const int px = i / (CIN / 8), c = i % (CIN / 8);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (px < HW) v = *reinterpret_cast<const u32x4*>(src + (size_t)px * p.x_ps * 2 + c * 16);
-      *reinterpret_cast<u32x4*>(smem + C::OFF_X + xoff<XK>(px, c, XROW)) = v;
-    }
-    for (int i = tid; i < C::SROWS * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
+  };
   // interior pixel l16 -> squeeze-tile row (zero halo of one pixel around the H x W map, row pitch W + 2)
   const int SW = p.W + 2;
   auto srow = [&](int px) { const int py = px / p.W; return (py + 1) * SW + (px - py * p.W) + 1; };
-  __syncthreads();
 
   // per-module constants -> LDS by LDS-DMA (no registers, nobody waits until the module that needs them starts):
   // a module then has no dependent global round trips besides its streamed weight fragments
@@ -127,16 +133,23 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
       if (k % C::NW == w) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + C::WD_BYTES + 2 * C::B_BYTES + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
   };
   fetch_consts(p.mod[0], 0, MID);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   auto frag = [&](const u32x4* base, int ksteps, int ks, int b) { return base[(size_t)(b * ksteps + ks) * 64]; };
   u32x4 wf[PF][2];
-  if constexpr (!EE) {
-    const u32x4* w1_first = static_cast<const u32x4*>(p.mod[0].w1) + (size_t)w * 2 * KS1 * 64 + lane;
+  {
+    constexpr int FKS1 = EE ? C::EKS1 : KS1;                 // first module: the entry module (EE) or the first chain module
+    const u32x4* w1_first = static_cast<const u32x4*>(p.mod[0].w1) + (size_t)w * 2 * FKS1 * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) { wf[i][0] = w1_first[(size_t)i * 64]; wf[i][1] = w1_first[(size_t)(KS1 + i) * 64]; }
+    for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_first, FKS1, i, 0); wf[i][1] = frag(w1_first, FKS1, i, 1); }
   }
+  if constexpr (EE) {
+    stage_frame(std::integral_constant<int, C::ECIN>{}, std::integral_constant<int, C::ENPX>{}, std::integral_constant<int, 15>{}, HWe);
+    for (int i = tid; i < C::ESROWS * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  } else {
+    stage_frame(std::integral_constant<int, CIN>{}, std::integral_constant<int, NPX>{}, std::integral_constant<int, XK>{}, HW);
+    for (int i = tid; i < C::SROWS * (MID / 8); i += NT) *reinterpret_cast<u32x4*>(smem + C::OFF_S + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           // the frame, the cleared squeeze tile and the first module's constants are in LDS
   int cur = 0;
 
   // ---- EE: entry module (p.mod[0]): s8 = W1 x8 + b1 on the He x We map; y[:, :256] = relu(Wa s8[::2, ::2] + ba);
@@ -160,8 +173,7 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
       f32x4 acc0[4], acc1[4];
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) { acc0[pb] = f32x4{b0, b0, b0, b0}; acc1[pb] = f32x4{b1, b1, b1, b1}; }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) { wf[i][0] = frag(w1_lane, EKS1, i, 0); wf[i][1] = frag(w1_lane, EKS1, i, 1); }
+      // (the first PF fragment sets were requested in the prologue)
 #pragma unroll
       for (int ks = 0; ks < EKS1; ++ks) {
         u32x4 a[4];
