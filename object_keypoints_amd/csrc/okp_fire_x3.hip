@@ -36,7 +36,10 @@ constexpr int CIN = 256, MID = 128;
 constexpr int SP = 128;                          // squeeze-tile rows in LDS
 constexpr int PBI = 6;                           // interior pixel blocks of 16 (IP <= 96)
 constexpr int NST = 4;                           // x ring stages
-constexpr int MAXIH = 6;                         // interior rows per tile
+constexpr int MAXIH = 5;                         // interior rows per tile (5 x 16 tiles on every map of the network; a sixth row cost the depth-wise phase 9 registers)
+#ifndef OKP_FX3_DWB
+#define OKP_FX3_DWB 4
+#endif
 constexpr int KS1 = CIN / 32, KS2 = MID / 32;    // k-steps of the squeeze / expand GEMM
 constexpr int NW = 8, NT = 64 * NW;
 constexpr int XST = SP * 128;                    // bytes per ring stage (128 pixels x 32 fp32)
@@ -193,9 +196,9 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
     for (int pb = 0; pb < SP / 16; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (the depth-wise phase of the previous tile issued MAXIH loads - consumed - and MAXIH stores per column iteration behind the ring
     //  requests: with one iteration, the usual case, those stores may stay in flight)
-    if (stores_behind_ring == MAXIH) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    if (stores_behind_ring == MAXIH) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    static_assert(MAXIH == 6, "the counted wait above names MAXIH");
+    static_assert(MAXIH == 5, "the counted wait above names MAXIH");
     __builtin_amdgcn_s_barrier();                            // stages 0 .. 2 have landed (every wave's part)
     FX3_STAMP(1);
     split_stage(0);
@@ -386,28 +389,46 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
           f32x4 wt[3];
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) wt[dy] = *reinterpret_cast<const f32x4*>(wl + (dy * 3 + dx) * MID);
+          // ALL squeeze rows of the column position in flight before the first FMA.  With a tile-height condition per row hipcc made every read a
+          // basic block of its own - ds_read -> s_waitcnt -> 12 FMAs, 21 LDS latencies one behind the other per column, most of this phase's
+          // 9-10 k clocks.  Rows beyond the tile are read too (clamped into the tile): they feed only accumulator rows that are never stored
+          // - and that the range maximum below leaves out.
+          constexpr int BT = OKP_FX3_DWB;                      // rows per batch (registers: 4 per row)
 #pragma unroll
-          for (int sr = 0; sr < MAXIH + 2; ++sr) {             // squeeze row sr is tap row dy of output row sr - dy
-            if (sr < p.IH + 2) {
-              const int sp = sr * p.SW + ixc + dx;
-              const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + OFF_S32 + sp * 512 + (((uint32_t)cg ^ (uint32_t)(sp & 15)) << 4));
+          for (int s0 = 0; s0 < MAXIH + 2; s0 += BT) {
+            f32x4 sv[BT];
 #pragma unroll
-              for (int dy = 0; dy < 3; ++dy) {
-                const int iy = sr - dy;
-                if (iy >= 0 && iy < MAXIH) {
+            for (int u = 0; u < BT; ++u) {                     // squeeze row sr is tap row dy of output row sr - dy
+              if (s0 + u < MAXIH + 2) {
+                const int sp = min((s0 + u) * p.SW + ixc + dx, SP - 1);
+                sv[u] = *reinterpret_cast<const f32x4*>(smem + OFF_S32 + sp * 512 + (((uint32_t)cg ^ (uint32_t)(sp & 15)) << 4));
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_fmaf(sv[e], wt[dy][e], v[iy][e]);
+            for (int u = 0; u < BT; ++u) {
+              const int sr = s0 + u;
+              if (sr < MAXIH + 2) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                  const int iy = sr - dy;
+                  if (iy >= 0 && iy < MAXIH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_fmaf(sv[u][e], wt[dy][e], v[iy][e]);
+                  }
                 }
               }
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
 #pragma unroll
         for (int iy = 0; iy < MAXIH; ++iy) {
           const f32x4 r = __builtin_bit_cast(f32x4, rr[iy]);
+          const bool stored = oo[iy] != kInvalidOff;
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = fmaxf(v[iy][e] + r[e], 0.f); range_m3 = okp_range_max(range_m3, o[e]); }
+          for (int e = 0; e < 4; ++e) { o[e] = fmaxf(v[iy][e] + r[e], 0.f); range_m3 = okp_range_max(range_m3, stored ? o[e] : 0.f); }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, (int)oo[iy], 0, 0);
         }
       }
