@@ -141,10 +141,16 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
 template <typename T, int CIN, int MID, int STR, bool DWM = false>
 __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(const OkpFire2Params p) {
   static_assert(STR == 1 || STR == 2, "stride of both branches");
-  static_assert(!DWM || STR == 1, "depth-wise branch on the matrix pipe: the stride-1 instances");
+  // DWM at stride 2 (round 6, last): tiles of 3 x 8 OUTPUT pixels, pixel block = 2 rows x 8 columns (lane l16 -> row 2 pb + (l16 >> 3), column
+  // l16 & 7; the fourth row does not exist), squeeze tile 7 x 17.  Nothing in the matrix-pipe form needs the 16 pixels of a fragment to be a row:
+  // every lane reads its own 16-byte chunk at its own address.  Nine taps x two blocks: 18 fragment reads, 36 MFMAs - where the vector-ALU form
+  // walks 7 squeeze rows x 3 positions per thread with half of the column slots idle (8.1 k of a tile's 18.2 k clocks, profiles/r06t_fire2_stamps.txt)
+  constexpr bool DWM2 = DWM && STR == 2;
+  constexpr int D2H = 3, D2W = 8, D2SW = 2 * (D2W - 1) + 3, D2SH = 2 * (D2H - 1) + 3, D2B = 2;
+  static_assert(D2SH * D2SW <= SP && D2B * 16 >= D2H * D2W + 8, "stride-2 matrix-pipe tile");
   constexpr int DIH = kDwmIH;                      // DWM: interior rows per tile, 16 columns wide: (DIH + 2) squeeze rows of DSW = 18 pixels
   constexpr int DSW = 18;
-  constexpr int NSB = DWM ? ((DIH + 2) * DSW + 15) / 16 : SP / 16;   // pixel blocks of the squeeze GEMM (the ring keeps its SP / 16 row blocks)
+  constexpr int NSB = !DWM ? SP / 16 : STR == 1 ? ((DIH + 2) * DSW + 15) / 16 : (D2SH * D2SW + 15) / 16;   // pixel blocks of the squeeze GEMM (the ring keeps its SP / 16 row blocks)
   constexpr int NW = MID / 32;                     // waves: each owns 32 channels of both GEMMs
   constexpr int NT = 64 * NW;
   constexpr int HALF = MID;
@@ -558,7 +564,46 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     F2_STAMP(2);
     // ---- phase 2a: y_a = relu(Wa s + ba (+x)) on the interior pixels, whole lines straight to HBM --------------
     uint32_t dwm_o[DIH];                                    // DWM: output offset of this lane's pixel (row iy, column l16), channels chq ..
-    if constexpr (DWM) {
+    uint32_t d2_o[D2B];                                     // DWM2: the same for (block pb, lane)
+    if constexpr (DWM2) {
+      // pixel (row 2 pb + (l16 >> 3), column l16 & 7): offsets = lane constant + wave-uniform block term; validity per lane (no skip at stride 2)
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
+      const int liy = l16t >> 3, lix = l16t & 7;
+      const uint32_t pix0 = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + x0);
+      const uint32_t lane_o = (uint32_t)(liy * p.Wo + lix) * (uint32_t)(p.out_ps * 2) + (uint32_t)chq * 2u;
+      const bool col_ok = lix < p.IW && x0 + lix < p.Wo;
+      f32x4 ac2[D2B][2];
+#pragma unroll
+      for (int pb = 0; pb < D2B; ++pb) {
+        const int iy = 2 * pb + liy;
+        const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
+        d2_o[pb] = ok ? lane_o + (pix0 + (uint32_t)(2 * pb * p.Wo)) * (uint32_t)(p.out_ps * 2) : kInvalid;
+        ac2[pb][0] = bav0;
+        ac2[pb][1] = bav1;
+      }
+      // the 1x1 branch samples the squeeze tile at (2 iy + 1, 2 ix + 1): row (4 pb + 2 liy + 1) D2SW + 2 lix + 1
+      const uint32_t sp_lane = (uint32_t)((2 * liy + 1) * D2SW + 2 * lix + 1);
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        u32x4 a[D2B];
+#pragma unroll
+        for (int pb = 0; pb < D2B; ++pb) {
+          const uint32_t sp = sp_lane + (uint32_t)(4 * pb * D2SW);
+          a[pb] = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (uint32_t)(MID * 2) + (((uint32_t)(4 * ks + qt) ^ (sp & (uint32_t)SWM)) << 4));
+        }
+#pragma unroll
+        for (int pb = 0; pb < D2B; ++pb)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            ac2[pb][b] = H16<T>::mfma16(waf[b][ks], a[pb], ac2[pb][b]);
+      }
+#pragma unroll
+      for (int pb = 0; pb < D2B; ++pb) {
+        const u32x4 v = relu_add_pack8<T>(ac2[pb][0], ac2[pb][1], u32x4{0u, 0u, 0u, 0u});
+        F2_STORE(v, rs_o, d2_o[pb]);
+      }
+    } else if constexpr (DWM) {
       // Fixed geometry (pixel block = interior row, 16 columns, map width a multiple of 16): a pixel's offsets are a lane constant plus a
       // wave-uniform row term, the only edge is the map's last row (wave-uniform) - no table reads, no per-block branches, and with every
       // trip count known the fragment reads of a k-step are all in flight before its MFMAs (the general form below has a tile-shape
@@ -660,7 +705,55 @@ __global__ __launch_bounds__(MID * 2, MID == 128 ? 2 : 1) void okp_fire2_kernel(
     F2_STAMP(3);
 
     // ---- phase 2b: y_b = relu(dw3x3(s) + bd (+x)) from the LDS squeeze tile -------------------------------------
-    if constexpr (DWM) {
+    if constexpr (DWM2) {
+      int l16t = l16;
+      asm volatile("" : "+v"(l16t));
+      const int liy = l16t >> 3, lix = l16t & 7;
+      {
+        const int next = tile + gridDim.x;                   // (the ring is free: every wave is behind the barrier that follows the squeeze tile's writes)
+        if (next < p.n_tiles) {
+          tile_setup(next);
+          first_weights(w1f);
+#pragma unroll
+          for (int ks = 0; ks < NST - 1; ++ks) issue_x(ks, ks);
+        }
+      }
+      const float* const bl = reinterpret_cast<const float*>(smem + OFF_WD) + 9 * HALF + chq;
+      const f32x4 bdv0 = *reinterpret_cast<const f32x4*>(bl), bdv1 = *reinterpret_cast<const f32x4*>(bl + 4);
+      f32x4 acd[D2B][2];
+#pragma unroll
+      for (int pb = 0; pb < D2B; ++pb) { acd[pb][0] = bdv0; acd[pb][1] = bdv1; }
+      const uint32_t am = (qt == (l16t >> 2)) ? 0xffffffffu : 0u;                            // A operand: as in the stride-1 form below
+      const uint32_t m_lo = (l16t & 2) ? 0u : am, m_hi = (l16t & 2) ? am : 0u;
+      const uint32_t wt_lane = (uint32_t)OFF_WD + (uint32_t)(chq + (l16t & 3)) * 4u;
+      const uint32_t cx = (uint32_t)(4 * w) + (uint32_t)qt;
+      const uint32_t sp_lane = (uint32_t)(2 * liy * D2SW + 2 * lix);                         // tap (dy, dx) of pixel (2 pb + liy, lix): squeeze row (4 pb + 2 liy + dy) D2SW + 2 lix + dx
+      u32x4 a0 = {0u, 0u, 0u, 0u}, a1 = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const uint32_t v0 = *reinterpret_cast<const uint32_t*>(smem + wt_lane + (tap * HALF) * 4);
+        const uint32_t v1 = *reinterpret_cast<const uint32_t*>(smem + wt_lane + (tap * HALF + 4) * 4);
+        a0[0] = v0 & m_lo; a0[1] = v0 & m_hi;
+        a1[2] = v1 & m_lo; a1[3] = v1 & m_hi;
+        u32x4 bf[D2B];
+#pragma unroll
+        for (int pb = 0; pb < D2B; ++pb) {
+          const uint32_t sp = sp_lane + (uint32_t)((4 * pb + dy) * D2SW + dx);
+          bf[pb] = *reinterpret_cast<const u32x4*>(smem + OFF_S + sp * (uint32_t)(MID * 2) + ((cx ^ (sp & (uint32_t)SWM)) << 4));
+        }
+#pragma unroll
+        for (int pb = 0; pb < D2B; ++pb) {
+          acd[pb][0] = H16<T>::mfma16(a0, bf[pb], acd[pb][0]);
+          acd[pb][1] = H16<T>::mfma16(a1, bf[pb], acd[pb][1]);
+        }
+      }
+#pragma unroll
+      for (int pb = 0; pb < D2B; ++pb) {
+        const u32x4 o = relu_add_pack8<T>(acd[pb][0], acd[pb][1], u32x4{0u, 0u, 0u, 0u});
+        F2_STORE(o, rs_o, d2_o[pb] == kInvalid ? kInvalid : d2_o[pb] + (uint32_t)(HALF * 2));
+      }
+    } else if constexpr (DWM) {
       // On the matrix pipe (see the kernel's head).  Lane (l16 = pixel column ix = row i of the A operand, q): channels chq .. chq + 7.
       int l16t = l16;
       asm volatile("" : "+v"(l16t));
@@ -870,9 +963,10 @@ bool okp_fire2_supported(int cin, int mid, int half, int stride) {
   if (stride == 1)
     return (cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 512 && mid == 256) ||
            (cin == 384 && mid == 128) || (cin == 512 && mid == 192);
-  // (256 -> 192 at stride 2, 32x32 -> 16x16, N=64: 163 us with resident squeeze weights - six waves spill - and 40 us with
-  //  streamed ones against 37.6 us for the two-launch path, no change of the step: left to the two launches)
-  return stride == 2 && ((cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 384 && mid == 256));
+  // (256 -> 192 at stride 2, 32x32 -> 16x16, N=64: as a vector-ALU depth-wise instance 40 us against 37.6 us for the two-launch path - left to the
+  //  two launches until round 6; with the depth-wise branch on the matrix pipe the one launch is ahead, and it is ONE persistent launch
+  //  where the two gather-tile launches were stretched to 102 + 34 us by the side streams' kernels: profiles/r06y_ab_fire2_stride2_dwm.txt)
+  return stride == 2 && ((cin == 256 && mid == 128) || (cin == 384 && mid == 192) || (cin == 384 && mid == 256) || (cin == 256 && mid == 192));
 }
 
 template <typename T>
@@ -911,6 +1005,17 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
   if (dwm) {
     p.IH = p.Ho < kDwmIH ? p.Ho : kDwmIH; p.IW = 16; p.SH = p.IH + 2; p.SW = 18;
     p.tiles_y = (p.Ho + p.IH - 1) / p.IH; p.tiles_x = p.Wo / 16;
+  }
+  // the stride-2 instances on output maps a multiple of 8 wide: tiles of 3 x 8 output pixels (OKP_F2_DWM_S2=0: the vector-ALU form, for A/B) -
+  // or 2 x 8 when both fit the resident grid in one round (16 x 16 -> 8 x 8 at N = 64: 256 tiles, one per CU, instead of 192)
+  static const bool dwm2_on = [] { const char* e = getenv("OKP_F2_DWM_S2"); return !(e && e[0] == '0'); }();
+  const bool dwm2 = dwm_on && dwm2_on && stride == 2 && p.Wo % 8 == 0 && mid <= dwm_mid;
+  if (dwm2) {
+    const long tx = p.Wo / 8;
+    int ih = p.Ho < 3 ? p.Ho : 3;
+    if (ih == 3 && (long)p.N * ((p.Ho + 1) / 2) * tx <= resident_wg) ih = 2;
+    p.IH = ih; p.IW = 8; p.SH = 2 * (ih - 1) + 3; p.SW = 17;
+    p.tiles_y = (p.Ho + ih - 1) / ih; p.tiles_x = (int)tx;
   }
   p.IP = p.IH * p.IW;
   p.RPR = (p.IW + 3) / 4;
@@ -964,7 +1069,12 @@ static int launch_fire2_t(OkpFire2Params p, int cin, int mid, int stride, hipStr
     else if (cin == 384 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 128, 1>), grid, block, 0, stream, p);
     else if (cin == 512 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 512, 192, 1>), grid, block, 0, stream, p);
     else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d", cin, mid); return OKP_EINVAL; }
-  } else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 2>), grid, block, 0, stream, p);
+  } else if (dwm2 && cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 2, true>), grid, block, 0, stream, p);
+  else if (dwm2 && cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 2, true>), grid, block, 0, stream, p);
+  else if (dwm2 && cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 256, 2, true>), grid, block, 0, stream, p);
+  else if (dwm2 && cin == 256 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 192, 2, true>), grid, block, 0, stream, p);
+  else if (cin == 256 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 192, 2>), grid, block, 0, stream, p);
+  else if (cin == 256 && mid == 128) hipLaunchKernelGGL((okp_fire2_kernel<T, 256, 128, 2>), grid, block, 0, stream, p);
   else if (cin == 384 && mid == 192) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 192, 2>), grid, block, 0, stream, p);
   else if (cin == 384 && mid == 256) hipLaunchKernelGGL((okp_fire2_kernel<T, 384, 256, 2>), grid, block, 0, stream, p);
   else { okp_set_error("okp_fire_forward: no streaming kernel for %d -> %d stride %d", cin, mid, stride); return OKP_EINVAL; }

@@ -504,7 +504,9 @@ FUSE_FIRE_MIN_HW = 8    # 4x4 maps: two launches are faster (25 vs 20 us)
 
 
 _FIRE2_CONFIGS = {1: {(256, 128), (384, 192), (512, 256), (384, 128), (512, 192)},      # stride -> (cin, mid) instances of okp_fire2.hip
-                  2: {(256, 128), (384, 192), (384, 256)}}
+                  2: {(256, 128), (384, 192), (384, 256), (256, 192)}}
+if os.environ.get("OKP_FIRE2_S2_256_192", "1") == "0":      # A/B switch (scripts/README.md): the 32 x 32 -> 16 x 16 module as squeeze + fused tail, as until round 6
+    _FIRE2_CONFIGS[2].discard((256, 192))
 FUSE_FIRE_S2 = True
 
 

@@ -130,9 +130,11 @@ class EmuNet:
         shift2 = (sd[f"{name}.bn2.bias"].double() - sd[f"{name}.bn2.running_mean"].double() * scale2).float()
         wa = (sd[f"{name}.conv_1x1.weight"].double() * scale2[:half].view(-1, 1, 1, 1)).float()
         wd = (sd[f"{name}.conv_3x3.weight"].double() * scale2[half:].view(-1, 1, 1, 1)).float()     # depth-wise: fp32 weights on the vector ALUs ...
-        if stride == 1 and s.shape[3] % 16 == 0:
-            # ... except where the one-launch kernel runs the branch on the matrix pipe (okp_fire2_kernel<..., DWM>: stride 1, maps 16 k pixels
-            # wide - the 64 x 64, 32 x 32 and 16 x 16 levels): there the tap weights are rounded to the activation type (round 6)
+        wo = (s.shape[3] - 1) // stride + 1
+        if (stride == 1 and s.shape[3] % 16 == 0) or (stride == 2 and wo % 8 == 0 and (x.shape[1], s.shape[1]) in ((256, 128), (384, 192), (384, 256), (256, 192))):
+            # ... except where the one-launch kernel runs the branch on the matrix pipe (okp_fire2_kernel<..., DWM>: stride 1 on maps 16 k pixels
+            # wide - the 64 x 64, 32 x 32 and 16 x 16 levels - and its stride-2 instances on output maps 8 k wide): there the tap weights are
+            # rounded to the activation type (round 6)
             wd = p.weight(f"{name}.conv_3x3", wd)
         ya = p.conv(s, p.weight(f"{name}.conv_1x1", wa), shift2[:half], stride=stride)
         yd = F.conv2d(s, wd, shift2[half:], stride=stride, padding=1, groups=s.shape[1])
