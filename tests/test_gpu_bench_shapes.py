@@ -106,6 +106,43 @@ def test_streaming_fire_kernel_at_bench_shapes(c, co, h, stride, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c,co,n,h,w", [(256, 256, 2, 16, 16),      # one round of the grid: 2 x 8 tiles (okp_fire2's launcher), second pixel block empty
+                                        (256, 256, 64, 22, 32),     # 3 x 8 tiles, the last tile row holds two of its three rows
+                                        (256, 384, 64, 32, 32),     # the 256 -> 192 instance (the 32 x 32 -> 16 x 16 module of the hourglass)
+                                        (384, 512, 5, 16, 48),      # 384 -> 256, three tiles per row
+                                        (384, 384, 7, 18, 16)])     # 384 -> 192 on a 9 x 8 output map
+def test_stride2_fire_on_the_matrix_pipe(c, co, n, h, w, dtype):
+    """The stride-2 instances of okp_fire2 with the depth-wise branch on the matrix pipe (output maps a multiple of 8 wide: tiles of 3 x 8 or
+    2 x 8 output pixels, pixel block = 2 rows x 8 columns) against the oracle's fire_module: ragged last tile rows, the one-round tile choice,
+    every (cin, mid) instance; one launch, deterministic."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    _need(dtype)
+    o = onet.load_synthetic(onet.fire_module(c, co, stride=2), seed=33)
+    m = bb.fire_module(c, co, stride=2)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(6)
+    x = torch.randn((n, h, w, c), generator=gen, device="cuda").to(dtype)
+    l0 = ops.COUNTERS["launches"]
+    got = m(ops.Act(x))
+    assert ops.COUNTERS["launches"] - l0 == 1
+    assert tuple(got.t.shape) == (n, (h + 1) // 2, (w + 1) // 2, co)
+    sample = sorted({0, n // 2, n - 1})
+    with torch.no_grad():
+        ref = o(x[sample].float().permute(0, 3, 1, 2).cpu())
+    g = got.t[sample].float().permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    eps = 0.03 if dtype == torch.bfloat16 else 0.004
+    assert float((g - ref).abs().max()) <= eps * scale + eps
+    assert torch.equal(m(ops.Act(x)).t, got.t)
+    # a frame's values do not depend on the batch it is in (the tile shape may: 2 x 8 against 3 x 8 tiles)
+    one = m(ops.Act(x[n - 1:n].contiguous()))
+    assert torch.equal(one.t[0], got.t[n - 1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("form", ["innermost_level", "pair_384", "single_384"])
 def test_resident_chains_at_bench_batch(form, dtype):
     """okp_fire_chain at N=64 as the bench launches it: the innermost hourglass level in one launch (stride-2 fire(384, 512) from 8x8,
