@@ -1102,7 +1102,7 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
   if (x3) {
     // split-product plans: fp32 tensors; okp_fire_x3.hip has the 256 -> 128 -> 256 module with skip at stride 1
     if (!okp_fire_x3_supported(cin, mid, half, a->stride, a->skip) || squeeze->n_single_slices || expand->n_single_slices || !squeeze->fragT_dev || !expand->fragT_dev) {
-      okp_set_error("okp_fire_forward: the split-product one-launch kernel takes 256 -> 128 -> 256 at stride 1 with skip (three-term plans); run the squeeze plan and the fused tail instead");
+      okp_set_error("okp_fire_forward: the split-product one-launch kernel takes 256 -> 128 -> 256 at stride 1 with skip or at stride 2 without (three-term plans); run the squeeze plan and the fused tail instead");
       return OKP_EINVAL;
     }
     if (a->x.pix_stride % 4 || a->out.pix_stride % 4 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half || ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) {
@@ -1117,7 +1117,7 @@ extern "C" int okp_fire_forward(const okp_conv* squeeze, const okp_conv* expand,
     q.w1 = squeeze->fragT_dev; q.w1_cout_pad = squeeze->cout_pad; q.b1 = squeeze->bias_dev; q.s1 = squeeze->oscale_dev;
     q.wa = expand->fragT_dev; q.wa_cout_pad = expand->cout_pad; q.ba = expand->bias_dev; q.sa = expand->oscale_dev;
     q.wd = dw_w_dev; q.bd = dw_bias_dev; q.range_flag = squeeze->range_flag;
-    return okp_launch_fire_x3(q, (hipStream_t)stream);
+    return okp_launch_fire_x3(q, a->stride, (hipStream_t)stream);
   }
   if (a->x.pix_stride % 8 || a->out.pix_stride % 8 || a->x.pix_stride < cin || a->out.pix_stride < 2 * half ||
       ((uintptr_t)a->x.data) % 16 || ((uintptr_t)a->out.data) % 16) { okp_set_error("okp_fire_forward: views must be 16-byte aligned and wide enough"); return OKP_EINVAL; }

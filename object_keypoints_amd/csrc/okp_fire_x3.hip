@@ -65,7 +65,16 @@ __device__ __forceinline__ uint32_t ring_key(int row) { return (0x54541010u >> (
 #define FX3_STAMP(i) do {} while (0)
 #endif
 
+// STR = 2 (round 6, last): the stride-2 module 256 -> 128 -> 256 WITHOUT skip (64 x 64 -> 32 x 32: until now a squeeze launch plus the fused tail -
+// the fp32 squeeze tensor, 134 MB per 64 frames, written and read back).  The squeeze tile is the input pixels under a tile of OH2 x 8 output
+// pixels (7 x 17); the 1x1 branch samples it at (2 iy + 1, 2 ix + 1), the depth-wise branch walks every squeeze row, row sr feeding output row
+// (sr - dy) / 2 where that is whole.
+constexpr int OH2 = 3;                           // stride 2: output rows per tile
+template <int STR>
 __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p) {
+  static_assert(STR == 1 || STR == 2, "stride");
+  constexpr int OH = STR == 1 ? MAXIH : OH2;     // output rows a thread of the depth-wise phase holds (loads, stores per column iteration)
+  constexpr int NSR = STR * (OH - 1) + 3;        // squeeze rows it walks
   __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,13 +123,13 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
     for (int i = 0; i < 2; ++i) {
       const int row = 8 * (w + NW * i) + (lt >> 3);
       const int sy = fastdiv(row, p.div_sw), sx = row - sy * p.SW;
-      const int y = y0 - 1 + sy, x = x0 - 1 + sx;
+      const int y = STR * y0 - 1 + sy, x = STR * x0 - 1 + sx;
       const bool ok = row < p.SH * p.SW && y >= 0 && y < p.H && x >= 0 && x < p.W;
       d_off[i] = ok ? (uint32_t)(((long)n * p.H + y) * p.W + x) * (uint32_t)(p.x_ps * 4) + (((uint32_t)lt & 7u) ^ ring_key(row)) * 16u : kInvalidOff;
     }
     if (tid < SP) {
       const int m_sy = fastdiv(tt, p.div_sw), m_sx = tt - m_sy * p.SW;
-      const int y = y0 - 1 + m_sy, x = x0 - 1 + m_sx;
+      const int y = STR * y0 - 1 + m_sy, x = STR * x0 - 1 + m_sx;
       const unsigned long long m = __ballot(tt < p.SH * p.SW && y >= 0 && y < p.H && x >= 0 && x < p.W);
       if (lane == 0) {
         uint32_t* mk = reinterpret_cast<uint32_t*>(smem + OFF_MASK);
@@ -196,9 +205,11 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
     for (int pb = 0; pb < SP / 16; ++pb) acc[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (the depth-wise phase of the previous tile issued MAXIH loads - consumed - and MAXIH stores per column iteration behind the ring
     //  requests: with one iteration, the usual case, those stores may stay in flight)
-    if (stores_behind_ring == MAXIH) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    static_assert(MAXIH == 5, "the counted wait above names MAXIH");
+    if (stores_behind_ring == OH) {
+      if constexpr (OH == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    static_assert(OH == 5 || OH == 3, "the counted waits above name OH");
     __builtin_amdgcn_s_barrier();                            // stages 0 .. 2 have landed (every wave's part)
     FX3_STAMP(1);
     split_stage(0);
@@ -297,9 +308,10 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
         const bool in = ip < p.IP;
         if (!in) ip = 0;
         const int iy = fastdiv(ip, p.div_iw), ix = ip - iy * p.IW;
-        const int sp = (iy + 1) * p.SW + ix + 1;
+        const int sp = (STR * iy + 1) * p.SW + STR * ix + 1;     // the squeeze pixel the 1x1 branch samples
         a_row = (uint32_t)sp * 512u + (uint32_t)(sp & 15);
         uint32_t xr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + ip * 4);
+        if (STR == 2 || !p.skip) xr = kInvalidOff;               // no skip connection: the load below returns zeros
         uint32_t orr = *reinterpret_cast<const uint32_t*>(smem + OFF_TAB + (96 + ip) * 4);
         if (!in || (!full && (y0 + iy >= p.Ho || x0 + ix >= p.Wo))) { xr = kInvalidOff; orr = kInvalidOff; }
         o_off = orr == kInvalidOff ? kInvalidOff : ob + orr;
@@ -365,25 +377,25 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
       stores_behind_ring = 0;
       float range_m3 = 0.f;
       for (int ix = tidt >> 5; ix < ((p.IW + 15) & ~15); ix += 16) {
-        stores_behind_ring += MAXIH;
+        stores_behind_ring += OH;
         const int ox = x0 + ix;
         const bool col_ok = ix < p.IW && ox < p.Wo;
         const uint32_t pix = (uint32_t)(((long)n * p.Ho + y0) * p.Wo + ox);
         uint32_t xo = pix * (uint32_t)(p.x_ps * 4) + (uint32_t)(MID + cg * 4) * 4u, oof = pix * (uint32_t)(p.out_ps * 4) + (uint32_t)(MID + cg * 4) * 4u;
-        u32x4 rr[MAXIH];
-        uint32_t oo[MAXIH];
+        u32x4 rr[OH];
+        uint32_t oo[OH];
 #pragma unroll
-        for (int iy = 0; iy < MAXIH; ++iy) {
+        for (int iy = 0; iy < OH; ++iy) {
           const bool ok = col_ok && iy < p.IH && y0 + iy < p.Ho;
           oo[iy] = ok ? oof : kInvalidOff;
-          rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? xo : kInvalidOff), 0, 0);
+          rr[iy] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok && STR == 1 && p.skip ? xo : kInvalidOff), 0, 0);
           xo += (uint32_t)(p.W * p.x_ps * 4);
           oof += (uint32_t)(p.Wo * p.out_ps * 4);
         }
         const int ixc = ix < p.IW ? ix : 0;
-        f32x4 v[MAXIH];
+        f32x4 v[OH];
 #pragma unroll
-        for (int iy = 0; iy < MAXIH; ++iy) v[iy] = breg;
+        for (int iy = 0; iy < OH; ++iy) v[iy] = breg;
 #pragma unroll 1
         for (int dx = 0; dx < 3; ++dx) {
           f32x4 wt[3];
@@ -395,12 +407,12 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
           // - and that the range maximum below leaves out.
           constexpr int BT = OKP_FX3_DWB;                      // rows per batch (registers: 4 per row)
 #pragma unroll
-          for (int s0 = 0; s0 < MAXIH + 2; s0 += BT) {
+          for (int s0 = 0; s0 < NSR; s0 += BT) {
             f32x4 sv[BT];
 #pragma unroll
-            for (int u = 0; u < BT; ++u) {                     // squeeze row sr is tap row dy of output row sr - dy
-              if (s0 + u < MAXIH + 2) {
-                const int sp = min((s0 + u) * p.SW + ixc + dx, SP - 1);
+            for (int u = 0; u < BT; ++u) {                     // squeeze row sr is tap row dy of output row (sr - dy) / STR
+              if (s0 + u < NSR) {
+                const int sp = min((s0 + u) * p.SW + STR * ixc + dx, SP - 1);
                 sv[u] = *reinterpret_cast<const f32x4*>(smem + OFF_S32 + sp * 512 + (((uint32_t)cg ^ (uint32_t)(sp & 15)) << 4));
               }
             }
@@ -408,11 +420,11 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
 #pragma unroll
             for (int u = 0; u < BT; ++u) {
               const int sr = s0 + u;
-              if (sr < MAXIH + 2) {
+              if (sr < NSR) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                  const int iy = sr - dy;
-                  if (iy >= 0 && iy < MAXIH) {
+                  const int iy = (sr - dy) / STR;
+                  if (sr - dy >= 0 && (sr - dy) % STR == 0 && iy < OH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[iy][e] = __builtin_fmaf(sv[u][e], wt[dy][e], v[iy][e]);
                   }
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
           }
         }
 #pragma unroll
-        for (int iy = 0; iy < MAXIH; ++iy) {
+        for (int iy = 0; iy < OH; ++iy) {
           const f32x4 r = __builtin_bit_cast(f32x4, rr[iy]);
           const bool stored = oo[iy] != kInvalidOff;
           f32x4 o;
@@ -442,16 +454,16 @@ __global__ __launch_bounds__(NT) void okp_fire_x3_kernel(const OkpFire2Params p)
 }  // namespace
 
 bool okp_fire_x3_supported(int cin, int mid, int half, int stride, int skip) {
-  return cin == CIN && mid == MID && half == MID && stride == 1 && skip;
+  return cin == CIN && mid == MID && half == MID && ((stride == 1 && skip) || (stride == 2 && !skip));
 }
 
-int okp_launch_fire_x3(OkpFire2Params p, hipStream_t stream) {
+int okp_launch_fire_x3(OkpFire2Params p, int stride, hipStream_t stream) {
   // interior rectangle IH x IW: halo'd footprint <= 128 squeeze pixels, <= 96 interior pixels; minimise the squeeze pixels
   // computed per frame (halo + partial tiles), ties -> wider rows (as okp_fire2's launcher)
   long best = -1;
-  for (int ih = 1; ih <= p.Ho && ih <= MAXIH; ++ih)
+  for (int ih = 1; ih <= p.Ho && ih <= (stride == 1 ? MAXIH : OH2); ++ih)
     for (int iw = 1; iw <= p.Wo && iw <= 96; ++iw) {
-      const int sh = ih + 2, sw = iw + 2;
+      const int sh = stride * (ih - 1) + 3, sw = stride * (iw - 1) + 3;
       if (sh * sw > SP || ih * iw > 16 * PBI) continue;
       const long ty = (p.Ho + ih - 1) / ih, tx = (p.Wo + iw - 1) / iw;
       const long score = ty * tx * 4096 - iw;
@@ -472,7 +484,8 @@ int okp_launch_fire_x3(OkpFire2Params p, hipStream_t stream) {
   (void)hipMemsetAsync(dbg, 0, 16 * NW * 8 * 4, stream);
   p.dbg = dbg;
 #endif
-  hipLaunchKernelGGL(okp_fire_x3_kernel, grid, block, 0, stream, p);
+  if (stride == 1) hipLaunchKernelGGL(okp_fire_x3_kernel<1>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(okp_fire_x3_kernel<2>, grid, block, 0, stream, p);
 #ifdef OKP_FIRE_STAMPS
   if (getenv("OKP_FIRE_STAMPS_PRINT")) {
     (void)hipStreamSynchronize(stream);

@@ -294,7 +294,7 @@ int okp_ensure_frags(const okp_conv* plan, hipStream_t stream);   // okp_fire_ch
 bool okp_fire2_supported(int cin, int mid, int half, int stride);
 int okp_launch_fire2(int dtype, const OkpFire2Params& p, int cin, int mid, int stride, hipStream_t stream);
 bool okp_fire_x3_supported(int cin, int mid, int half, int stride, int skip);     // okp_fire_x3.hip: one-launch fire module of split-product plans
-int okp_launch_fire_x3(OkpFire2Params p, hipStream_t stream);
+int okp_launch_fire_x3(OkpFire2Params p, int stride, hipStream_t stream);
 bool okp_patch_supported(const okp_conv* plan, const OkpIgemmParams& p);   // okp_igemm_patch.hip
 int okp_launch_igemm_patch(const okp_conv* plan, const OkpIgemmParams& p, hipStream_t stream);
 int okp_fill_patch_params(const okp_conv* plan, const OkpIgemmParams& q, OkpPatchParams& p);             // okp_igemm_patch.hip (shared by both patch kernels)

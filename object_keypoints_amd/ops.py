@@ -520,8 +520,15 @@ FUSE_FIRE_X3 = True     # split-product plans: the one-launch fire module okp_fi
 FUSE_FIRE_X3_MIN_HW = 16
 
 
+FUSE_FIRE_X3_S2 = True  # ... and its stride-2 form without skip (64 x 64 -> 32 x 32: low1[0] of the outermost hourglass level)
+
+
 def fire_fusable_x3(inp_dim, mid, stride, skip, h, w):
-    return FUSE_FIRE_X3 and (inp_dim, mid) == (256, 128) and stride == 1 and skip and min(h, w) >= FUSE_FIRE_X3_MIN_HW
+    if not (FUSE_FIRE_X3 and (inp_dim, mid) == (256, 128)):
+        return False
+    if stride == 1:
+        return bool(skip) and min(h, w) >= FUSE_FIRE_X3_MIN_HW
+    return FUSE_FIRE_X3_S2 and stride == 2 and not skip and min(h, w) // 2 >= FUSE_FIRE_X3_MIN_HW
 
 
 LIGHT_EVENTS = True     # forks / joins through okp_stream_wait_stream (events without a system-scope fence); False: torch's wait_stream

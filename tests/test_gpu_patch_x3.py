@@ -326,3 +326,66 @@ def test_fire_x3_random_map_sizes_against_the_two_launch_path():
             finally:
                 ops.FUSE_FIRE_X3 = True
         assert float((got.t - two.t).abs().max()) <= 1e-5 * (1.0 + float(two.t.abs().max())), (case, n, h, w)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 32, 32), (2, 38, 50), (3, 33, 47), (64, 64, 64)])
+def test_split_stride2_fire_module_in_one_launch(n, h, w):
+    """okp_fire_x3_kernel<2> (fire_module 256 -> 128 -> 256 at stride 2, no skip: the 64 x 64 -> 32 x 32 module of the hourglass) against the
+    oracle's fire_module and against the squeeze + fused-tail launches it replaces: odd input sizes (the last input row / column is a
+    padding neighbour only), partial tiles, the bench's batch; bit-reproducible."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    o = onet.load_synthetic(onet.fire_module(256, 256, stride=2), seed=41)
+    m = bb.fire_module(256, 256, stride=2)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    x = torch.randn((n, h, w, 256), generator=gen, device="cuda")
+    with ops.f32_split():
+        l0 = ops.COUNTERS["launches"]
+        got = m(ops.Act(x))
+        assert ops.COUNTERS["launches"] - l0 == 1
+        again = m(ops.Act(x))
+        ops.FUSE_FIRE_X3_S2 = False
+        try:
+            two = m(ops.Act(x))
+            assert ops.COUNTERS["launches"] - l0 == 4
+        finally:
+            ops.FUSE_FIRE_X3_S2 = True
+    assert tuple(got.t.shape) == (n, (h + 1) // 2, (w + 1) // 2, 256)
+    assert torch.equal(again.t, got.t)
+    sample = sorted({0, n // 2, n - 1})
+    with torch.no_grad():
+        ref = o(x[sample].permute(0, 3, 1, 2).cpu())
+    g = got.t[sample].permute(0, 3, 1, 2).cpu()
+    scale = 1.0 + float(ref.abs().max())
+    assert float((g - ref).abs().max()) <= 2e-5 * scale
+    assert float((got.t - two.t).abs().max()) <= 1e-5 * scale
+
+
+def test_stride2_fire_x3_random_map_sizes_against_the_two_launch_path():
+    """Seeded sweep of the stride-2 okp_fire_x3 over input maps of 32..90 pixels per side and 1..4 frames against the two launches of the module."""
+    from object_keypoints_amd import ops
+    from object_keypoints_amd.perception import backbone as bb
+    from oracle import net as onet
+    o = onet.load_synthetic(onet.fire_module(256, 256, stride=2), seed=43)
+    m = bb.fire_module(256, 256, stride=2)
+    m.load_state_dict(o.state_dict())
+    m.eval()
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda:0")
+    for case in range(10):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(32, 91)), int(rng.integers(32, 91))
+        g = torch.Generator(device=dev); g.manual_seed(100 + case)
+        x = ops.Act(torch.randn((n, h, w, 256), generator=g, device=dev))
+        with ops.f32_split():
+            l0 = ops.COUNTERS["launches"]
+            got = m(x)
+            assert ops.COUNTERS["launches"] - l0 == 1, (case, n, h, w)
+            ops.FUSE_FIRE_X3_S2 = False
+            try:
+                two = m(x)
+            finally:
+                ops.FUSE_FIRE_X3_S2 = True
+        assert float((got.t - two.t).abs().max()) <= 1e-5 * (1.0 + float(two.t.abs().max())), (case, n, h, w)
