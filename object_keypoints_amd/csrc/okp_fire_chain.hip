@@ -182,6 +182,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (ks + PF < EKS1) { wf[ks % PF][0] = frag(w1_lane, EKS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, EKS1, ks + PF, 1); }
         else { wf[ks % PF][0] = frag(wa_lane, KS2, ks + PF - EKS1, 0); wf[ks % PF][1] = frag(wa_lane, KS2, ks + PF - EKS1, 1); }   // expand step ks - 4 -> slot (ks - 4 + 4) % 8
+#ifndef OKP_CHAIN_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);     // the refill is REQUESTED here, PF steps ahead of its use (hipcc otherwise sinks the loads down to their MFMAs)
+#endif
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
           acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
@@ -216,6 +219,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         const u32x4 f0 = wf[(e + 4) % PF][0], f1 = wf[(e + 4) % PF][1];
         // the slot is free: the first chain module's squeeze step with that slot ((e + 4) % 8; the chain ring keeps step k in slot k % 8)
         wf[(e + 4) % PF][0] = frag(w1_next, KS1, (e + 4) % PF, 0); wf[(e + 4) % PF][1] = frag(w1_next, KS1, (e + 4) % PF, 1);
+#ifndef OKP_CHAIN_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);     // the refill is REQUESTED here, PF steps ahead of its use (hipcc otherwise sinks the loads down to their MFMAs)
+#endif
         acc0 = H16<T>::mfma16(a, f0, acc0);
         acc1 = H16<T>::mfma16(a, f1, acc1);
       }
@@ -290,6 +296,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
         else { wf[ks % PF][0] = frag(wa_lane, KS2, ks + PF - KS1, 0); wf[ks % PF][1] = frag(wa_lane, KS2, ks + PF - KS1, 1); }   // expand step ks + PF - KS1
+#ifndef OKP_CHAIN_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);     // the refill is REQUESTED here, PF steps ahead of its use (hipcc otherwise sinks the loads down to their MFMAs)
+#endif
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
           acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
@@ -330,6 +339,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         for (int pb = 0; pb < PXB; ++pb) a[pb] = *reinterpret_cast<const u32x4*>(smem + C::OFF_S + xoff<SK>(arow[pb], 4 * ks + q, SROW));
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (more) { wf[ks % PF][0] = frag(w1_next, KS1, ks, 0); wf[ks % PF][1] = frag(w1_next, KS1, ks, 1); }      // the next module's squeeze step ks
+#ifndef OKP_CHAIN_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);     // the refill is REQUESTED here, PF steps ahead of its use (hipcc otherwise sinks the loads down to their MFMAs)
+#endif
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
           acc0[pb] = H16<T>::mfma16(a[pb], f0, acc0[pb]);
@@ -411,6 +423,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         const u32x4 f0 = wf[ks % PF][0], f1 = wf[ks % PF][1];
         if (ks + PF < KS1) { wf[ks % PF][0] = frag(w1_lane, KS1, ks + PF, 0); wf[ks % PF][1] = frag(w1_lane, KS1, ks + PF, 1); }
         else if (ks + PF - KS1 < XKS2) { wf[ks % PF][0] = frag(wa_lane, XKS2, ks + PF - KS1, 0); wf[ks % PF][1] = frag(wa_lane, XKS2, ks + PF - KS1, 1); }
+#ifndef OKP_CHAIN_NO_PIN
+        __builtin_amdgcn_sched_barrier(0);     // the refill is REQUESTED here, PF steps ahead of its use (hipcc otherwise sinks the loads down to their MFMAs)
+#endif
         acc0 = H16<T>::mfma16(a, f0, acc0);
         acc1 = H16<T>::mfma16(a, f1, acc1);
       }
