@@ -365,29 +365,49 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
 
     // ---- depth-wise: y[:, MID:] = relu(dw3x3(s) + bd + x[:, MID:]) -----------------------------------------------------
     // thread = (8-channel group cg, pixel slot); NT / (MID / 8) = 16 pixel slots per pass
-    for (int dpx = tid / (MID / 8); dpx < NPX; dpx += 16) {
-      float v[8];
+    // The NPX / 16 pixels of a thread are worked TOGETHER, tap by tap: a tap's weights are read from LDS once for all of them (pixel by pixel
+    // they were re-read for every pixel: 27 LDS reads per pixel, 18 of them weights - 108 per thread and module at 8 x 8), and the pixels'
+    // squeeze reads of a tap are in flight together.  Same FMA order per pixel: same bits.
+    {
+      constexpr int NP = NPX / 16;
+      static_assert(NT / (MID / 8) == 16 && NPX % 16 == 0, "pixel slots");
+      const int slot = tid / (MID / 8);
+      float v[NP][8];
+      int base[NP];
       {
         const f32x4 u0 = *reinterpret_cast<const f32x4*>(cbd + cg * 8), u1 = *reinterpret_cast<const f32x4*>(cbd + cg * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
-      }
-      const int px = dpx < HW ? dpx : 0;
-      const int py = px / p.W, pxx = px - py * p.W;
+        for (int i = 0; i < NP; ++i) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int row = (py + t / 3) * SW + pxx + t % 3;         // (py + 1 + dy) * SW + pxx + 1 + dx with dy, dx in -1..1
-        const x8_t sv = *reinterpret_cast<const x8_t*>(smem + C::OFF_S + xoff<SK>(row, cg, SROW));
+          for (int e = 0; e < 4; ++e) { v[i][e] = u0[e]; v[i][4 + e] = u1[e]; }
+          const int dpx = slot + 16 * i;
+          const int px = dpx < HW ? dpx : 0;
+          const int py = px / p.W;
+          base[i] = py * SW + (px - py * p.W);                  // tap (dy, dx): row base + dy SW + dx  (= (py + 1 + dy - 1) SW + pxx + 1 + dx - 1)
+        }
+      }
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {                             // (not unrolled: nine taps x NP pixels in one block made hipcc hoist every read and spill 180 registers)
+        const int dy = (t * 11) >> 5, dx = t - 3 * dy;          // t / 3, t % 3 for t < 9
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8), w1 = *reinterpret_cast<const f32x4*>(cst + t * MID + cg * 8 + 4);
+        x8_t sv[NP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = fmaf((float)sv[e], w0[e], v[e]); v[4 + e] = fmaf((float)sv[4 + e], w1[e], v[4 + e]); }
+        for (int i = 0; i < NP; ++i) sv[i] = *reinterpret_cast<const x8_t*>(smem + C::OFF_S + xoff<SK>(base[i] + dy * SW + dx, cg, SROW));
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[i][e] = fmaf((float)sv[i][e], w0[e], v[i][e]); v[i][4 + e] = fmaf((float)sv[i][4 + e], w1[e], v[i][4 + e]); }
       }
-      const uint32_t o = xoff<XK>(dpx, (MID * 2) / 16 + cg, XROW);
-      const x8_t xv = *reinterpret_cast<const x8_t*>(xc + o);
-      x8_t out;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) out[e] = (T)(dpx < HW ? fmaxf(v[e] + (float)xv[e], 0.f) : 0.f);
-      *reinterpret_cast<x8_t*>(xn + o) = out;
+      for (int i = 0; i < NP; ++i) {
+        const int dpx = slot + 16 * i;
+        const uint32_t o = xoff<XK>(dpx, (MID * 2) / 16 + cg, XROW);
+        const x8_t xv = *reinterpret_cast<const x8_t*>(xc + o);
+        x8_t out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = (T)(dpx < HW ? fmaxf(v[i][e] + (float)xv[e], 0.f) : 0.f);
+        *reinterpret_cast<x8_t*>(xn + o) = out;
+      }
     }
     // the next module's constants have landed (this wave's share); its first 2 PF squeeze fragments, issued after them, may stay in flight
     if (more) {
