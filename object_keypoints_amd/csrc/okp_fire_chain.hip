@@ -15,6 +15,8 @@
 // [32 w, 32 w + 32) of both GEMMs, columns interleaved (2 j + b) so that a lane's two accumulator blocks are adjacent
 // channels (one dword per pixel).  The depth-wise branch: thread = (8-channel group, pixel), its 72 weights fetched at
 // the start of the module.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <type_traits>
@@ -61,6 +63,14 @@ struct ChainCfg {
 template <int KEY>
 __device__ __forceinline__ uint32_t xoff(int row, int chunk, int rowbytes) { return (uint32_t)row * rowbytes + (uint32_t)((chunk ^ (row & KEY)) << 4); }
 
+#ifdef OKP_FIRE_STAMPS
+// Debug build (OKP_EXTRA_CFLAGS=-DOKP_FIRE_STAMPS, printed with OKP_FIRE_STAMPS_PRINT=1): shader-clock stamps of every wave of workgroups 0..15 at the
+// phase boundaries of the chain's SECOND chain module, and at kernel entry / before the first chain module / exit: [wg][wave 8][8] u32
+#define FC_STAMP(cond, i) do { if ((cond) && lane == 0 && blockIdx.x < 16) { uint64_t t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(blockIdx.x * 8 + w) * 8 + (i)] = (uint32_t)t_; } } while (0)
+#else
+#define FC_STAMP(cond, i) do {} while (0)
+#endif
+
 template <typename T, int CIN, int PXB, bool EE>
 __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_kernel(const OkpFireChainParams p) {
   using C = ChainCfg<CIN, PXB, EE>;
@@ -80,6 +90,7 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
   const int l16 = lane & 15, q = lane >> 4;
   const int n = blockIdx.x;
   const int HW = p.H * p.W;
+  FC_STAMP(true, 5);
   const int ch0 = 32 * w + 2 * l16;                    // this lane's channel pair in both GEMMs
 
   // frame -> LDS (buffer 0), squeeze tile cleared once: its halo stays zero for the whole chain.
@@ -265,8 +276,13 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
   }
 
   const int m_first = EE ? 1 : 0, m_end = EE ? p.n_modules - 1 : p.n_modules;      // the chain modules proper
+  FC_STAMP(true, 6);
   for (int m = m_first; m < m_end; ++m) {
     const OkpFireChainModule mod = p.mod[m];
+#ifdef OKP_FIRE_STAMPS
+    const bool second = m == m_first + 1;
+#endif
+    FC_STAMP(second, 0);
     const float* cst = reinterpret_cast<const float*>(smem + C::OFF_C + (m & 1) * C::CONST_BYTES);   // [9][MID] depth-wise weights
     const float* cbd = cst + C::WD_BYTES / 4;              // then bd, b1, ba
     const float* cb1 = cbd + C::B_BYTES / 4;
@@ -319,7 +335,9 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
           }
         }
     }
+    FC_STAMP(second, 1);
     __syncthreads();
+    FC_STAMP(second, 2);
 
     // ---- expand: y[:, :MID] = relu(Wa s + ba + x[:, :MID]) -> next activation buffer ----------------------------------
     {
@@ -363,6 +381,7 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
         }
     }
 
+    FC_STAMP(second, 3);
     // ---- depth-wise: y[:, MID:] = relu(dw3x3(s) + bd + x[:, MID:]) -----------------------------------------------------
     // thread = (8-channel group cg, pixel slot); NT / (MID / 8) = 16 pixel slots per pass
     // The NPX / 16 pixels of a thread are worked TOGETHER, tap by tap: a tap's weights are read from LDS once for all of them (pixel by pixel
@@ -417,9 +436,11 @@ __global__ __launch_bounds__((ChainCfg<CIN, PXB, EE>::NT)) void okp_fire_chain_k
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    FC_STAMP(second, 4);
     __syncthreads();
     cur ^= 1;
   }
+  FC_STAMP(true, 7);
 
   // ---- EE: exit module (the last one): 512 -> 192 -> 384, no skip; waves 0..5 own its 192 squeeze / expand channels ----------------
   if constexpr (EE) {
@@ -527,6 +548,29 @@ int okp_ensure_frags(const okp_conv* plan, hipStream_t) {
 }
 
 
+#ifdef OKP_FIRE_STAMPS
+static uint32_t* g_chain_dbg = nullptr;
+static void chain_stamps_print(const char* what, int nw, hipStream_t stream) {
+  if (!getenv("OKP_FIRE_STAMPS_PRINT")) return;
+  (void)hipStreamSynchronize(stream);
+  uint32_t h[16 * 8 * 8];
+  (void)hipMemcpy(h, g_chain_dbg, sizeof(h), hipMemcpyDeviceToHost);
+  double sum[5] = {0, 0, 0, 0, 0}, pro = 0, all = 0; int cnt = 0;
+  for (int wg = 0; wg < 16; ++wg)
+    for (int w = 0; w < nw; ++w) {
+      const uint32_t* a = &h[(wg * 8 + w) * 8];
+      if (!a[7]) continue;
+      sum[0] += a[1] - a[0]; sum[1] += a[2] - a[1]; sum[2] += a[3] - a[2]; sum[3] += a[4] - a[3];
+      pro += a[6] - a[5]; all += a[7] - a[5]; ++cnt;
+    }
+  if (cnt) printf("fire_chain stamps (%s, %d waves): second chain module: squeeze GEMM + s -> LDS %.0f | barrier %.0f | expand GEMM %.0f | depth-wise + constants' wait %.0f clocks;"
+                  " entry to first chain module %.0f, entry to behind the last chain module %.0f\n", what, nw, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, pro / cnt, all / cnt);
+}
+#define CHAIN_STAMPS_PRINT(what, nw) chain_stamps_print(what, nw, (hipStream_t)stream)
+#else
+#define CHAIN_STAMPS_PRINT(what, nw) do {} while (0)
+#endif
+
 extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeeze, okp_conv* const* expand,
                                       const float* const* dw_w_dev, const float* const* dw_bias_dev,
                                       int32_t n, const okp_tensor* x, const okp_tensor* out, void* stream) {
@@ -535,6 +579,11 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
   if (n < 1) return OKP_OK;
   OkpFireChainParams p;
   std::memset(&p, 0, sizeof(p));
+#ifdef OKP_FIRE_STAMPS
+  if (!g_chain_dbg) (void)hipMalloc((void**)&g_chain_dbg, 16 * 8 * 8 * 4);
+  (void)hipMemsetAsync(g_chain_dbg, 0, 16 * 8 * 8 * 4, (hipStream_t)stream);
+  p.dbg = g_chain_dbg;
+#endif
   // EE form: module 0 is the stride-2 entry module 384 -> 256 -> 512 (x is the twice larger map), the last one the exit module
   // 512 -> 192 -> 384, at least one fire(512, 512) in between - the whole innermost hourglass level in one launch
   const bool ee = n_modules >= 3 && squeeze[0] && squeeze[n_modules - 1] && squeeze[0]->cin[0] == 384 && squeeze[0]->cout == 256 &&
@@ -577,6 +626,7 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
     p.n_modules = n_modules; p.x = x->data; p.out = out->data; p.x_ps = x->pix_stride; p.out_ps = out->pix_stride; p.H = ho; p.W = wo; p.He = x->h; p.We = x->w;
     if (bf) hipLaunchKernelGGL((okp_fire_chain_kernel<__bf16, 512, 1, true>), dim3(n), dim3(ChainCfg<512, 1, true>::NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((okp_fire_chain_kernel<_Float16, 512, 1, true>), dim3(n), dim3(ChainCfg<512, 1, true>::NT), 0, (hipStream_t)stream, p);
+    CHAIN_STAMPS_PRINT("512-wide entry / exit form", 8);
     return okp_check_hip(hipGetLastError(), "okp_fire_chain launch");
   }
   const bool small = x->h <= 4 && x->w <= 4;
@@ -603,5 +653,6 @@ extern "C" int okp_fire_chain_forward(int32_t n_modules, okp_conv* const* squeez
     if (bf) hipLaunchKernelGGL((okp_fire_chain_kernel<__bf16, 384, 4, false>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((okp_fire_chain_kernel<_Float16, 384, 4, false>), dim3(n), dim3(ChainCfg<384, 4>::NT), 0, (hipStream_t)stream, p);
   }
+  CHAIN_STAMPS_PRINT(cin == 512 ? "512-wide" : "384-wide", cin / 64);
   return okp_check_hip(hipGetLastError(), "okp_fire_chain launch");
 }

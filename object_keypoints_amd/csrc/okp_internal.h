@@ -255,6 +255,9 @@ struct OkpFireChainParams {
   const void* x; void* out; int32_t x_ps, out_ps, H, W, n_modules;
   int32_t He, We;               // EE form (entry + exit modules): size of the map the stride-2 entry module reads
   OkpFireChainModule mod[OKP_FIRE_CHAIN_MAX];
+#ifdef OKP_FIRE_STAMPS
+  uint32_t* dbg;                // debug build: shader-clock stamps at the phase boundaries of the chain's second module
+#endif
 };
 
 struct okp_conv {
